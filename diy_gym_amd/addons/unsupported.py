@@ -1,0 +1,22 @@
+"""Registry names that resolve but are outside this round's hot-path scope
+(SURVEY.md 2 rows 9, 12, 13, 17, 19-22 and 8(f)).  Constructing one raises
+``NotImplementedError`` with the reason, instead of silently doing nothing."""
+from .addon import Addon
+
+
+def _stub(name, why):
+    def __init__(self, parent, config):
+        raise NotImplementedError("addon '%s' is not implemented in the MI355X backend: %s" % (name, why))
+
+    return type(name, (Addon, ), {'__init__': __init__, '__doc__': why})
+
+
+AdmittanceController = _stub('admittance_controller', 'needs batched Jacobian + inverse dynamics (SURVEY 8(f) N1)')
+Camera = _stub('camera', 'batched depth/segmentation rasteriser is scheduled after the state-only configs (SURVEY 8(a) A13)')
+ForceTorqueSensor = _stub('force_torque_sensor', 'joint reaction wrench output is not wired yet (SURVEY 8(f) N1)')
+StuckJointCost = _stub('stuck_joint_cost', 'the reference implementation raises NameError on first use '
+                       '(stuck_joint_cost.py:16-21); there is no behaviour to match')
+SpawnMultiple = _stub('spawn_multiple', 'SURVEY 8(f) N1')
+DrawCoords = _stub('draw_coords', 'GUI-only debug drawing')
+VisualRandomizer = _stub('visual_randomizer', 'GUI-only cosmetics; downloads a dataset over HTTP in the reference')
+DynamicsRandomizer = _stub('dynamics_randomizer', 'per-env mass/damping tables are scheduled next (SURVEY 8(f) N1)')

@@ -1,0 +1,278 @@
+// dg_api.hip -- kernels' entry points and the C-ABI (include/diygym_hip.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared dg_api.hip -o libdiygym_hip.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/diygym_hip.h"
+#include "dg_solver.h"
+
+using namespace dg;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf; return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- kernels
+template <int LANES>
+__global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
+                                                   float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x; if (lane >= LANES) return;
+  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, valid);
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
+  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+  sim_step(ln, diag);
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x; if (lane >= LANES) return;
+  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, valid);
+  const bool doit = valid && (mask == nullptr || mask[e] != 0);
+  if (doit) {
+    ln.Sset(DG_ST_STEP, 0.0f);
+    run_reset_ops(ln);
+    for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr);
+  }
+  if (obs) {
+    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+    run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term,
+                                                      float* rew_sum, uint8_t* term_flag) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x; if (lane >= LANES) return;
+  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, false);  // never stores state
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x; if (lane >= LANES) return;
+  const int env = blockIdx.x * LANES + lane; if (env >= sc.num_envs) return;
+  Lane<LANES> ln(sc, mt, smem + lane, state + env, env, false);
+  ln.kinematics(body);
+  V3 p, v, w; Q4 q; ln.frame_state(body, frame, com != 0, p, q, v, w, true);
+  float* o = out + (size_t)env * 13;
+  o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w; o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+}
+
+__global__ void init_state_kernel(const float* init, float* state, int state_dim, int stride) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= stride) return;
+  for (int k = 0; k < state_dim; k++) state[(size_t)k * stride + e] = init[k];
+}
+
+// ------------------------------------------------------------------ world
+struct dg_world {
+  DevScene sc; MotorTable mt;
+  std::vector<int32_t> I; std::vector<double> F;
+  int device = 0, lanes = 64, lds_bytes = 0, num_envs = 0, stride = 0;
+  void* d_blob_i = nullptr; void* d_blob_f = nullptr; void* d_plan = nullptr; float* d_init = nullptr;
+  int32_t* diag = nullptr;
+};
+
+extern "C" {
+
+int32_t dg_version(void) { return (0 << 16) | 3; }
+const char* dg_last_error(void) { return g_err.c_str(); }
+
+int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t n_f, int32_t num_envs, int32_t env_stride,
+                        int32_t device, uint64_t seed, int64_t env_index_base, dg_world** out) {
+  if (!I || !F || !out || n_i < DG_H_INT_COUNT) return fail(DG_ERR_ARG, "null or short scene arrays");
+  if (I[DG_H_MAGIC] != DG_MAGIC || I[DG_H_VERSION] != DG_VERSION) return fail(DG_ERR_BAD_SCENE, "bad scene magic/version (%x, %d)", I[DG_H_MAGIC], I[DG_H_VERSION]);
+  if (num_envs <= 0 || env_stride < num_envs) return fail(DG_ERR_ARG, "num_envs=%d env_stride=%d", num_envs, env_stride);
+  const int nb = I[DG_H_N_BODIES], nl = I[DG_H_N_LINKS];
+  if (nl > DG_MAX_LINKS) return fail(DG_ERR_UNSUPPORTED, "%d links > %d supported", nl, DG_MAX_LINKS);
+  if (nb > DG_MAX_BODIES) return fail(DG_ERR_UNSUPPORTED, "%d bodies > %d supported", nb, DG_MAX_BODIES);
+  HIP_TRY(hipSetDevice(device));
+  dg_world* w = new dg_world();
+  w->I.assign(I, I + n_i); w->F.assign(F, F + n_f); w->device = device; w->num_envs = num_envs; w->stride = env_stride;
+  const int32_t* BI = I + I[DG_H_OFF_BODY_I]; const int32_t* LI = I + I[DG_H_OFF_LINK_I]; const int32_t* OI = I + I[DG_H_OFF_OP_I];
+  // ---- LDS plan (slots per lane)
+  std::vector<int32_t> plan((size_t)nb * PLB_STRIDE + (size_t)nl * PLL_STRIDE);
+  int32_t* PLB = plan.data(); int32_t* PLL = plan.data() + (size_t)nb * PLB_STRIDE;
+  int slot = 0, nvmax = 0, nmax = 0;
+  for (int b = 0; b < nb; b++) {
+    const int32_t* B = BI + b * DG_BI_STRIDE; const bool fx = B[DG_BI_FLAGS] & DG_BODY_FIXED; const int n = B[DG_BI_N_LINKS];
+    const int nv = (fx ? 0 : 6) + n;
+    PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 9;
+    PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * (nv + 1) / 2;
+    PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += nv;
+    PLB[b * PLB_STRIDE + PLB_NV] = nv;
+    nvmax = std::max(nvmax, nv); nmax = std::max(nmax, n);
+  }
+  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 12; PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; }
+  const int maxc = I[DG_H_MAX_CONTACTS];
+  const int cont_off = slot; slot += 1 + maxc * CL_STRIDE;
+  int tr = AB_STRIDE + nmax * AW_STRIDE;
+  tr = std::max(tr, 3 * maxc * (4 * nvmax + 7));
+  for (int op = 0; op < I[DG_H_N_OPS]; op++)
+    if (OI[op * DG_OI_STRIDE + DG_OI_CODE] == DG_OP_IK_CONTROL) {
+      const int n = BI[OI[op * DG_OI_STRIDE + DG_OI_BODY] * DG_BI_STRIDE + DG_BI_N_LINKS];
+      if (!(OI[op * DG_OI_STRIDE + DG_OI_FLAGS] & DG_IK_NULLSPACE)) { delete w; return fail(DG_ERR_UNSUPPORTED, "joint-space DLS IK (non null-space variant) is not implemented on device yet"); }
+      tr = std::max(tr, 9 * n);
+    }
+  const int tr_off = slot; slot += tr;
+  const int total = slot;
+  int lanes = 64; const int LDS_MAX = 160 * 1024;
+  while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
+  if (lanes < 16) { delete w; return fail(DG_ERR_UNSUPPORTED, "scene needs %d LDS slots per env; does not fit 160 KiB even at 16 envs per wavefront", total); }
+  w->lanes = lanes; w->lds_bytes = total * lanes * 4;
+  // ---- device tables (floats converted once)
+  std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
+  HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, I, sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&w->d_blob_f, sizeof(float) * (size_t)n_f)); HIP_TRY(hipMemcpy(w->d_blob_f, Ff.data(), sizeof(float) * (size_t)n_f, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
+  const int32_t* dI = (const int32_t*)w->d_blob_i; const float* dF = (const float*)w->d_blob_f;
+  DevScene& sc = w->sc; memset(&sc, 0, sizeof sc);
+  sc.BI = dI + I[DG_H_OFF_BODY_I]; sc.LI = dI + I[DG_H_OFF_LINK_I]; sc.FI = dI + I[DG_H_OFF_FRAME_I]; sc.SI = dI + I[DG_H_OFF_SHAPE_I];
+  sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
+  sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
+  sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
+  sc.PLB = (const int32_t*)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE;
+  sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.nops = I[DG_H_N_OPS];
+  sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
+  sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
+  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
+  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total;
+  sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
+  sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
+  // ---- default velocity motors on every joint
+  memset(&w->mt, 0, sizeof w->mt);
+  for (int l = 0; l < nl; l++) { w->mt.v[3 * l] = 0.f; w->mt.v[3 * l + 1] = 1.f; w->mt.v[3 * l + 2] = -(float)F[DG_HF_DEFAULT_MOTOR_IMPULSE]; }
+  // ---- load-time state vector
+  std::vector<float> init((size_t)sc.state_dim, 0.f);
+  const double* BF = F + I[DG_H_OFF_BODY_F];
+  for (int b = 0; b < nb; b++) {
+    const int so = BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF];
+    for (int k = 0; k < 3; k++) init[so + DG_BS_POS + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_POS + k];
+    for (int k = 0; k < 4; k++) init[so + DG_BS_QUAT + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_QUAT + k];
+  }
+  (void)LI;
+  HIP_TRY(hipMalloc((void**)&w->d_init, sizeof(float) * init.size())); HIP_TRY(hipMemcpy(w->d_init, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
+  // allow > 64 KiB of dynamic LDS
+#define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
+  if (lanes == 64) { SET_ATTR(step_kernel<64>); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); }
+  else if (lanes == 32) { SET_ATTR(step_kernel<32>); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); }
+  else { SET_ATTR(step_kernel<16>); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); }
+#undef SET_ATTR
+  *out = w;
+  return DG_OK;
+}
+
+void dg_world_destroy(dg_world* w) {
+  if (!w) return;
+  hipFree(w->d_blob_i); hipFree(w->d_blob_f); hipFree(w->d_plan); hipFree(w->d_init);
+  delete w;
+}
+
+int32_t dg_world_dims(const dg_world* w, int32_t dims[8]) {
+  if (!w || !dims) return fail(DG_ERR_ARG, "null argument");
+  dims[0] = w->sc.state_dim; dims[1] = w->sc.act_dim; dims[2] = w->sc.obs_dim; dims[3] = w->sc.rew_dim; dims[4] = w->sc.term_dim;
+  dims[5] = w->sc.nl; dims[6] = w->lds_bytes; dims[7] = w->lanes;
+  return DG_OK;
+}
+int32_t dg_world_get_motor_cfg(const dg_world* w, double* cfg) {
+  if (!w || !cfg) return fail(DG_ERR_ARG, "null argument");
+  for (int k = 0; k < 3 * w->sc.nl; k++) cfg[k] = w->mt.v[k];
+  return DG_OK;
+}
+int32_t dg_world_set_motor_cfg(dg_world* w, const double* cfg) {
+  if (!w || !cfg) return fail(DG_ERR_ARG, "null argument");
+  for (int k = 0; k < 3 * w->sc.nl; k++) w->mt.v[k] = (float)cfg[k];
+  return DG_OK;
+}
+int32_t dg_world_set_diag_buffer(dg_world* w, int32_t* diag) { if (!w) return fail(DG_ERR_ARG, "null world"); w->diag = diag; return DG_OK; }
+
+int32_t dg_world_init_state(dg_world* w, float* state, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  hipLaunchKernelGGL(init_state_kernel, dim3((w->stride + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->d_init, state, w->sc.state_dim, w->stride);
+  HIP_TRY(hipGetLastError());
+  return DG_OK;
+}
+
+#define LAUNCH(KERNEL, ...)                                                                                              \
+  do {                                                                                                                   \
+    const dim3 grid((w->num_envs + w->lanes - 1) / w->lanes), block(64);                                                 \
+    if (w->lanes == 64) hipLaunchKernelGGL(KERNEL<64>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__);     \
+    else if (w->lanes == 32) hipLaunchKernelGGL(KERNEL<32>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<16>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__);                    \
+    HIP_TRY(hipGetLastError());                                                                                          \
+  } while (0)
+
+int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  LAUNCH(reset_kernel, w->sc, w->mt, state, mask, obs);
+  return DG_OK;
+}
+
+int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t update_mask, float* obs, float* rew, uint8_t* term,
+                      float* rew_sum, uint8_t* term_flag, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  if (actions) {
+    // motor gains / force limits are uniform over envs: the controller ops selected by the mask set them here
+    // (p.setJointMotorControlArray's positionGains / velocityGains / forces; joint_controller.py:53-58, ik_controller.py:71-80)
+    const int32_t* I = w->I.data(); const double* F = w->F.data();
+    const int32_t* OI = I + I[DG_H_OFF_OP_I]; const int32_t* IL = I + I[DG_H_OFF_ILIST]; const double* OF = F + I[DG_H_OFF_OP_F]; const double* LF = F + I[DG_H_OFF_LINK_F];
+    for (int op = 0; op < w->sc.nops; op++) {
+      const int32_t* oi = OI + op * DG_OI_STRIDE; const double* of = OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+      if (code != DG_OP_JOINT_CONTROL && code != DG_OP_IK_CONTROL) continue;
+      if (!((update_mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
+      if (code == DG_OP_JOINT_CONTROL && oi[DG_OI_FLAGS] == DG_JC_TORQUE) continue;
+      const bool vel = code == DG_OP_JOINT_CONTROL && oi[DG_OI_FLAGS] == DG_JC_VELOCITY;
+      for (int k = 0; k < oi[DG_OI_N]; k++) {
+        const int gl = IL[oi[DG_OI_ILIST] + k];
+        w->mt.v[3 * gl] = vel ? 0.f : (float)of[0]; w->mt.v[3 * gl + 1] = (float)of[1]; w->mt.v[3 * gl + 2] = (float)LF[gl * DG_LF_STRIDE + DG_LF_MAX_FORCE];
+      }
+    }
+  }
+  LAUNCH(step_kernel, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag);
+  return DG_OK;
+}
+
+int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  LAUNCH(observe_kernel, w->sc, w->mt, const_cast<float*>(state), obs, rew, term, rew_sum, term_flag);
+  return DG_OK;
+}
+
+int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int32_t frame, int32_t com, float* out, void* stream) {
+  if (!w || !state || !out) return fail(DG_ERR_ARG, "null argument");
+  if (body < 0 || body >= w->sc.nb) return fail(DG_ERR_ARG, "body %d out of range", body);
+  // `frame` is the body-local pybullet joint index; the kernels use the global frame index
+  int gf = -1;
+  if (frame >= 0) {
+    const int32_t* I = w->I.data(); const int32_t* FI = I + I[DG_H_OFF_FRAME_I]; int seen = 0; bool found = false;
+    for (int f = 0; f < w->sc.nfr; f++) if (FI[f * DG_FI_STRIDE + DG_FI_BODY] == body) { if (seen == frame) { gf = f; found = true; break; } seen++; }
+    if (!found) return fail(DG_ERR_ARG, "body %d has no frame %d", body, frame);
+  }
+  LAUNCH(frame_kernel, w->sc, w->mt, const_cast<float*>(state), body, gf, com, out);
+  return DG_OK;
+}
+
+}  // extern "C"

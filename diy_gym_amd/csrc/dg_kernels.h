@@ -1,0 +1,384 @@
+// dg_kernels.h -- the batched DIYGym step path as hand-written HIP for gfx950.
+//
+// One environment per lane.  A workgroup is ONE wavefront (64 threads); LANES of
+// its lanes own an environment each (64 normally; 32 or 16 when a scene's
+// per-env scratch would not fit 160 KiB of LDS at 64).  There is no
+// __syncthreads anywhere: all cross-lane traffic is wave ballots.
+//
+// What the kernels replace (reference call sites):
+//   step_kernel   : DIYGym.step (diy_gym/diy_gym.py:187-209) = addon.update for
+//                   every controller + p.stepSimulation + observe/reward/terminal
+//   reset_kernel  : DIYGym.reset (diy_gym.py:130-148), per-env masked
+//   observe_kernel: DIYGym.observe/reward/is_terminal (diy_gym.py:150-185)
+//
+// Algorithm per substep (same mathematics as oracle/dgsim_oracle.c, different
+// organisation): world kinematics -> narrow-phase contacts -> per body:
+// articulated-body algorithm in link coordinates (block-form articulated
+// inertias) + velocity update + the body's inverse mass matrix M^-1 from ABA
+// impulse responses -> velocity-level rows (motors, joint limits, contact
+// normal + 2 friction) with world-frame Jacobians and M^-1 J^T responses ->
+// projected Gauss-Seidel with a per-env residual early-out and a wave-level
+// "everyone converged" exit -> semi-implicit position update.
+#pragma once
+#include "dg_device.h"
+#include "../../include/diygym_scene.h"
+
+namespace dg {
+
+#define DG_MAX_LINKS 64   // total 1-DoF links in a scene (motor table travels in kernarg)
+#define DG_MAX_BODIES 192
+
+// Everything wave-uniform the kernels need.  Passed by value (kernarg -> SGPRs / scalar loads).
+struct DevScene {
+  const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
+  const float *BF, *LF, *FF, *SF, *PF, *OF, *FL, *HF;
+  const int32_t* PLB;  // per body: [R0_off, minv_off, dv_off, nv]
+  const int32_t* PLL;  // per link: [pose_off, mrow_off]
+  int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
+  int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
+  int32_t tr_off, tr_slots, cont_off, nv_max, total_slots;  // LDS plan
+  int32_t num_envs, stride;
+  uint64_t seed; int64_t env_base;
+  float h, gx, gy, gz;
+};
+struct MotorTable { float v[DG_MAX_LINKS * 3]; };  // kp, kd, max_force (<0 raw impulse)
+
+enum { PLB_R0 = 0, PLB_MINV, PLB_DV, PLB_NV, PLB_STRIDE };
+enum { PLL_POSE = 0, PLL_MROW, PLL_STRIDE };
+// transient ABA workspace per link
+enum { AW_E = 0, AW_R = 9, AW_V = 12, AW_PA = 18, AW_U = 24, AW_D = 30, AW_UU = 31, AW_IA = 32, AW_STRIDE = 53 };
+// transient base block (before the per-link blocks)
+enum { AB_IA = 0, AB_PA = 21, AB_L = 27, AB_V = 48, AB_A = 54, AB_STRIDE = 60 };
+// contact list entry
+enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_STRIDE = 8 };
+// motor / limit row block per link: b_motor acc_motor b_lo acc_lo b_hi acc_hi
+enum { MR_B = 0, MR_ACC, MR_LO_B, MR_LO_ACC, MR_HI_B, MR_HI_ACC, MR_STRIDE };
+
+template <int LANES>
+struct Lane {
+  const DevScene& sc;
+  const MotorTable& mt;
+  float* lds;   // workspace base for this lane (already offset by lane)
+  float* st;    // state base for this env (already offset by env)
+  int env;      // clamped env index
+  bool valid;   // this lane owns a real env (stores allowed)
+
+  DGD Lane(const DevScene& s, const MotorTable& m, float* l, float* state, int e, bool v) : sc(s), mt(m), lds(l), st(state), env(e), valid(v) {}
+
+  DGD float& L(int slot) const { return lds[slot * LANES]; }
+  DGD float S(int k) const { return st[(size_t)k * sc.stride]; }
+  DGD void Sset(int k, float v) const { if (valid) st[(size_t)k * sc.stride] = v; }
+
+  DGD V3 L3(int o) const { return v3(L(o), L(o + 1), L(o + 2)); }
+  DGD void L3set(int o, V3 v) const { L(o) = v.x; L(o + 1) = v.y; L(o + 2) = v.z; }
+  DGD M3 LM(int o) const { M3 A; _Pragma("unroll") for (int k = 0; k < 9; k++) A.m[k] = L(o + k); return A; }
+  DGD void LMset(int o, const M3& A) const { _Pragma("unroll") for (int k = 0; k < 9; k++) L(o + k) = A.m[k]; }
+  DGD S6 L6(int o) const { S6 s = {L3(o), L3(o + 3)}; return s; }
+  DGD void L6set(int o, const S6& s) const { L3set(o, s.a); L3set(o + 3, s.l); }
+  DGD void L6add(int o, const S6& s) const { L(o) += s.a.x; L(o + 1) += s.a.y; L(o + 2) += s.a.z; L(o + 3) += s.l.x; L(o + 4) += s.l.y; L(o + 5) += s.l.z; }
+  DGD AI LAI(int o) const {
+    AI A; A.I.xx = L(o); A.I.xy = L(o + 1); A.I.xz = L(o + 2); A.I.yy = L(o + 3); A.I.yz = L(o + 4); A.I.zz = L(o + 5);
+    _Pragma("unroll") for (int k = 0; k < 9; k++) A.H.m[k] = L(o + 6 + k);
+    A.M.xx = L(o + 15); A.M.xy = L(o + 16); A.M.xz = L(o + 17); A.M.yy = L(o + 18); A.M.yz = L(o + 19); A.M.zz = L(o + 20);
+    return A;
+  }
+  DGD void LAIset(int o, const AI& A) const {
+    L(o) = A.I.xx; L(o + 1) = A.I.xy; L(o + 2) = A.I.xz; L(o + 3) = A.I.yy; L(o + 4) = A.I.yz; L(o + 5) = A.I.zz;
+    _Pragma("unroll") for (int k = 0; k < 9; k++) L(o + 6 + k) = A.H.m[k];
+    L(o + 15) = A.M.xx; L(o + 16) = A.M.xy; L(o + 17) = A.M.xz; L(o + 18) = A.M.yy; L(o + 19) = A.M.yz; L(o + 20) = A.M.zz;
+  }
+  DGD void LAIadd(int o, const AI& A) const {
+    L(o) += A.I.xx; L(o + 1) += A.I.xy; L(o + 2) += A.I.xz; L(o + 3) += A.I.yy; L(o + 4) += A.I.yz; L(o + 5) += A.I.zz;
+    _Pragma("unroll") for (int k = 0; k < 9; k++) L(o + 6 + k) += A.H.m[k];
+    L(o + 15) += A.M.xx; L(o + 16) += A.M.xy; L(o + 17) += A.M.xz; L(o + 18) += A.M.yy; L(o + 19) += A.M.yz; L(o + 20) += A.M.zz;
+  }
+
+  // ---- scene table accessors (wave-uniform indices) ----
+  DGD const int32_t* bi(int b) const { return sc.BI + b * DG_BI_STRIDE; }
+  DGD const float* bf(int b) const { return sc.BF + b * DG_BF_STRIDE; }
+  DGD const int32_t* li(int l) const { return sc.LI + l * DG_LI_STRIDE; }
+  DGD const float* lf(int l) const { return sc.LF + l * DG_LF_STRIDE; }
+  DGD const int32_t* plb(int b) const { return sc.PLB + b * PLB_STRIDE; }
+  DGD const int32_t* pll(int l) const { return sc.PLL + l * PLL_STRIDE; }
+  DGD bool fixed(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
+  DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
+  DGD int minv_idx(int i, int j) const { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+
+  DGD V3 base_pos(int b) const { int o = bi(b)[DG_BI_STATE_OFF]; return v3(S(o), S(o + 1), S(o + 2)); }
+  DGD Q4 base_quat(int b) const { int o = bi(b)[DG_BI_STATE_OFF] + DG_BS_QUAT; Q4 q = {S(o), S(o + 1), S(o + 2), S(o + 3)}; return q; }
+
+  // link (global index, -1 = base of body b) world frame from the POSE region
+  DGD void link_world(int b, int gl, M3& R, V3& p) const {
+    if (gl < 0) { R = LM(plb(b)[PLB_R0]); p = base_pos(b); }
+    else { int o = pll(gl)[PLL_POSE]; R = LM(o); p = L3(o + 9); }
+  }
+
+  // parent->child rotation (Rpc) and offset r for link gl at joint value q
+  DGD void joint_xform(int gl, float q, M3& Rpc, V3& r) const {
+    const float* f = lf(gl);
+    M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = f[DG_LF_ROT + k];
+    V3 pT = v3(f[DG_LF_POS], f[DG_LF_POS + 1], f[DG_LF_POS + 2]);
+    V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
+    if (li(gl)[DG_LI_TYPE] == 0) { Rpc = mul(RT, rot_axis(ax, q)); r = pT; }
+    else { Rpc = RT; r = pT + mul(RT, ax * q); }
+  }
+
+  // ------------------------------------------------------------ kinematics
+  // world pose of every link of body b into the POSE region (q from state, or from LDS at qoff when qoff >= 0)
+  DGD void kinematics(int b, int qoff = -1) const {
+    const int32_t* B = bi(b);
+    int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
+    LMset(plb(b)[PLB_R0], R0);
+    for (int i = 0; i < n; i++) {
+      int gl = first + i, par = li(gl)[DG_LI_PARENT];
+      float q = qoff >= 0 ? L(qoff + i) : S(li(gl)[DG_LI_STATE_OFF] + DG_LS_Q);
+      M3 Rpc; V3 r; joint_xform(gl, q, Rpc, r);
+      M3 Rp; V3 pp;
+      if (par < 0) { Rp = R0; pp = p0; } else { int o = pll(par)[PLL_POSE]; Rp = LM(o); pp = L3(o + 9); }
+      int o = pll(gl)[PLL_POSE];
+      LMset(o, mul(Rp, Rpc)); L3set(o + 9, pp + mul(Rp, r));
+    }
+  }
+
+  // world pose + velocity of frame fr (global frame index, -1 base) of body b; POSE must be current
+  DGD void frame_state(int b, int fr, bool com, V3& p, Q4& q, V3& v, V3& w, bool want_vel) const {
+    V3 off; Q4 qo; int gl;
+    if (fr < 0) {
+      gl = -1;
+      if (com) { const float* f = bf(b); off = v3(f[DG_BF_REPORT_POS], f[DG_BF_REPORT_POS + 1], f[DG_BF_REPORT_POS + 2]);
+        Q4 t = {f[DG_BF_REPORT_QUAT], f[DG_BF_REPORT_QUAT + 1], f[DG_BF_REPORT_QUAT + 2], f[DG_BF_REPORT_QUAT + 3]}; qo = t; }
+      else { off = v3(0, 0, 0); Q4 t = {0, 0, 0, 1}; qo = t; }
+    } else {
+      gl = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
+      const float* f = sc.FF + fr * DG_FF_STRIDE + (com ? DG_FF_COM_POS : DG_FF_POS);
+      off = v3(f[0], f[1], f[2]); Q4 t = {f[3], f[4], f[5], f[6]}; qo = t;
+    }
+    M3 R; V3 o; link_world(b, gl, R, o);
+    Q4 ql = gl < 0 ? base_quat(b) : qfrom_mat(R);
+    p = o + mul(R, off); q = qnormalize(qmul(ql, qo));
+    if (!want_vel) return;
+    // velocity of the link origin: walk the chain root -> link
+    V3 wl = v3(0, 0, 0), vl = v3(0, 0, 0), po = base_pos(b);
+    if (!fixed(b)) { int so = bi(b)[DG_BI_STATE_OFF]; vl = v3(S(so + DG_BS_LINVEL), S(so + DG_BS_LINVEL + 1), S(so + DG_BS_LINVEL + 2));
+      wl = v3(S(so + DG_BS_ANGVEL), S(so + DG_BS_ANGVEL + 1), S(so + DG_BS_ANGVEL + 2)); }
+    if (gl >= 0) {
+      // ancestors have smaller indices: accumulate along the path by scanning the body's links
+      int first = bi(b)[DG_BI_FIRST_LINK];
+      // path marking: walk up from gl, then process in increasing order
+      unsigned long long path = 0ull; for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) path |= 1ull << (k - first);
+      for (int k = first; k <= gl; k++) {
+        if (!((path >> (k - first)) & 1ull)) continue;
+        int po_off = pll(k)[PLL_POSE]; M3 Rk = LM(po_off); V3 pk = L3(po_off + 9);
+        const float* f = lf(k); V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+        float qd = S(li(k)[DG_LI_STATE_OFF] + DG_LS_QD);
+        vl = vl + cross(wl, pk - po);  // move the reference point to this link's origin (parent's angular velocity)
+        if (li(k)[DG_LI_TYPE] == 0) wl = wl + axw * qd; else vl = vl + axw * qd;
+        po = pk;
+      }
+    }
+    w = wl; v = vl + cross(wl, p - po);
+  }
+
+  // ------------------------------------------------- articulated-body pass
+  DGD int aw(int i) const { return sc.tr_off + AB_STRIDE + i * AW_STRIDE; }
+  DGD int ab() const { return sc.tr_off; }
+
+  DGD S6 damping_force(float m, V3 c, const Sym3& Ic, const S6& v) const {
+    float kl = sc.HF[DG_HF_LIN_DAMPING], ka = sc.HF[DG_HF_ANG_DAMPING];
+    V3 vc = v.l + cross(v.a, c);
+    V3 f = vc * (-m * (kl + kl * norm(vc)));
+    V3 n = mul(Ic, v.a) * (-(ka + ka * norm(v.a)));
+    S6 o = {n + cross(c, f), f};
+    return o;
+  }
+  DGD Sym3 sym6(const float* p) const { Sym3 s = {p[0], p[1], p[2], p[3], p[4], p[5]}; return s; }
+  DGD S6 subspace(int gl) const {
+    const float* f = lf(gl); V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
+    S6 s; if (li(gl)[DG_LI_TYPE] == 0) { s.a = ax; s.l = v3(0, 0, 0); } else { s.a = v3(0, 0, 0); s.l = ax; }
+    return s;
+  }
+
+  // forward dynamics of body b, velocity update, and M^-1 (packed symmetric) into the MINV region
+  DGD void dynamics(int b) const {
+    const int32_t* B = bi(b); const float* Bf = bf(b);
+    const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
+    const bool fx = fixed(b); const float h = sc.h;
+    const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV], nb6 = fx ? 0 : 6;
+    M3 R0 = LM(plb(b)[PLB_R0]);
+    // ---- pass 1
+    S6 v0 = {v3(0, 0, 0), v3(0, 0, 0)};
+    if (!fx) {
+      V3 vw = v3(S(so + DG_BS_LINVEL), S(so + DG_BS_LINVEL + 1), S(so + DG_BS_LINVEL + 2));
+      V3 ww = v3(S(so + DG_BS_ANGVEL), S(so + DG_BS_ANGVEL + 1), S(so + DG_BS_ANGVEL + 2));
+      v0.a = tmul(R0, ww); v0.l = tmul(R0, vw);
+      V3 c = v3(Bf[DG_BF_COM], Bf[DG_BF_COM + 1], Bf[DG_BF_COM + 2]); Sym3 Ic = sym6(Bf + DG_BF_INERTIA);
+      AI I0 = rigid_inertia(Bf[DG_BF_MASS], c, Ic);
+      S6 p0 = crf(v0, mul(I0, v0)) - damping_force(Bf[DG_BF_MASS], c, Ic, v0);
+      int eo = ext_off(b);
+      S6 fx6; fx6.l = tmul(R0, v3(S(eo), S(eo + 1), S(eo + 2))); fx6.a = tmul(R0, v3(S(eo + 3), S(eo + 4), S(eo + 5)));
+      LAIset(ab() + AB_IA, I0); L6set(ab() + AB_PA, p0 - fx6);
+    }
+    L6set(ab() + AB_V, v0);
+    for (int i = 0; i < n; i++) {
+      int gl = first + i, par = li(gl)[DG_LI_PARENT]; const float* f = lf(gl);
+      int lo = li(gl)[DG_LI_STATE_OFF]; float q = S(lo + DG_LS_Q), qd = S(lo + DG_LS_QD);
+      M3 Rpc; V3 r; joint_xform(gl, q, Rpc, r); M3 E = transpose(Rpc);
+      S6 vp = par < 0 ? v0 : L6(aw(par - first) + AW_V);
+      S6 Sx = subspace(gl);
+      S6 v = xmotion(E, r, vp) + Sx * qd;
+      V3 c = v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]); Sym3 Ic = sym6(f + DG_LF_INERTIA);
+      AI I = rigid_inertia(f[DG_LF_MASS], c, Ic);
+      S6 pA = crf(v, mul(I, v)) - damping_force(f[DG_LF_MASS], c, Ic, v);
+      int o = aw(i);
+      LMset(o + AW_E, E); L3set(o + AW_R, r); L6set(o + AW_V, v); L6set(o + AW_PA, pA); LAIset(o + AW_IA, I);
+    }
+    // ---- pass 2
+    for (int i = n - 1; i >= 0; i--) {
+      int gl = first + i, par = li(gl)[DG_LI_PARENT]; const float* f = lf(gl); int o = aw(i);
+      int lo = li(gl)[DG_LI_STATE_OFF]; float qd = S(lo + DG_LS_QD);
+      float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd;
+      AI IA = LAI(o + AW_IA); S6 Sx = subspace(gl); S6 pA = L6(o + AW_PA); S6 v = L6(o + AW_V);
+      S6 U = mul(IA, Sx); float d = dot(Sx, U); float u = tau - dot(Sx, pA); float dinv = 1.0f / d;
+      L6set(o + AW_U, U); L(o + AW_D) = d; L(o + AW_UU) = u;
+      if (par >= 0 || !fx) {
+        // Ia = IA - U U^T / d
+        AI Ia = IA;
+        Ia.I.xx -= U.a.x * U.a.x * dinv; Ia.I.xy -= U.a.x * U.a.y * dinv; Ia.I.xz -= U.a.x * U.a.z * dinv;
+        Ia.I.yy -= U.a.y * U.a.y * dinv; Ia.I.yz -= U.a.y * U.a.z * dinv; Ia.I.zz -= U.a.z * U.a.z * dinv;
+        Ia.M.xx -= U.l.x * U.l.x * dinv; Ia.M.xy -= U.l.x * U.l.y * dinv; Ia.M.xz -= U.l.x * U.l.z * dinv;
+        Ia.M.yy -= U.l.y * U.l.y * dinv; Ia.M.yz -= U.l.y * U.l.z * dinv; Ia.M.zz -= U.l.z * U.l.z * dinv;
+        float ua[3] = {U.a.x, U.a.y, U.a.z}, ul[3] = {U.l.x, U.l.y, U.l.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c2 = 0; c2 < 3; c2++) Ia.H.m[3 * a + c2] -= ua[a] * ul[c2] * dinv;
+        S6 c = crm(v, Sx * qd);
+        S6 pa = pA + mul(Ia, c) + U * (u * dinv);
+        M3 E = LM(o + AW_E); V3 r = L3(o + AW_R);
+        AI Ip = to_parent(Ia, E, r); S6 pf = xforce_to_parent(E, r, pa);
+        int po = par < 0 ? ab() : aw(par - first);
+        LAIadd(po + (par < 0 ? AB_IA : AW_IA), Ip); L6add(po + (par < 0 ? AB_PA : AW_PA), pf);
+      }
+    }
+    // ---- base
+    V3 gb = tmul(R0, v3(sc.gx, sc.gy, sc.gz));
+    S6 a0; float Lb[21];
+    if (fx) { a0.a = v3(0, 0, 0); a0.l = -gb; }
+    else {
+      AI IA0 = LAI(ab() + AB_IA); ai_to_packed(IA0, Lb); chol6(Lb);
+#pragma unroll
+      for (int k = 0; k < 21; k++) L(ab() + AB_L + k) = Lb[k];
+      S6 p0 = L6(ab() + AB_PA);
+      float rhs[6] = {-p0.a.x, -p0.a.y, -p0.a.z, -p0.l.x, -p0.l.y, -p0.l.z}, x[6];
+      chol6_solve(Lb, rhs, x);
+      a0.a = v3(x[0], x[1], x[2]); a0.l = v3(x[3], x[4], x[5]);
+    }
+    L6set(ab() + AB_A, a0);
+    // ---- pass 3 (+ joint velocity update)
+    for (int i = 0; i < n; i++) {
+      int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i); int lo = li(gl)[DG_LI_STATE_OFF];
+      float qd = S(lo + DG_LS_QD);
+      M3 E = LM(o + AW_E); V3 r = L3(o + AW_R); S6 Sx = subspace(gl); S6 v = L6(o + AW_V);
+      S6 ap = par < 0 ? a0 : L6(aw(par - first) + AW_V);  // parents already hold their acceleration
+      S6 a1 = xmotion(E, r, ap) + crm(v, Sx * qd);
+      S6 U = L6(o + AW_U); float qdd = (L(o + AW_UU) - dot(U, a1)) / L(o + AW_D);
+      L6set(o + AW_V, a1 + Sx * qdd);
+      Sset(lo + DG_LS_QD, qd + h * qdd);
+    }
+    if (!fx) {
+      V3 al = a0.l + gb, aa = a0.a;
+      V3 acl = al + cross(v0.a, v0.l);
+      V3 dvw = mul(R0, acl), dww = mul(R0, aa);
+      Sset(so + DG_BS_LINVEL, S(so + DG_BS_LINVEL) + h * dvw.x); Sset(so + DG_BS_LINVEL + 1, S(so + DG_BS_LINVEL + 1) + h * dvw.y);
+      Sset(so + DG_BS_LINVEL + 2, S(so + DG_BS_LINVEL + 2) + h * dvw.z);
+      Sset(so + DG_BS_ANGVEL, S(so + DG_BS_ANGVEL) + h * dww.x); Sset(so + DG_BS_ANGVEL + 1, S(so + DG_BS_ANGVEL + 1) + h * dww.y);
+      Sset(so + DG_BS_ANGVEL + 2, S(so + DG_BS_ANGVEL + 2) + h * dww.z);
+    }
+    // ---- M^-1 by unit impulse responses; column col of generalized coords (base 6 first when floating).
+    // p (bias) reuses AW_PA, link accelerations reuse AW_V.
+    for (int col = 0; col < nv; col++) {
+      const int jdof = col - nb6;  // joint index or negative for a base coordinate
+      S6 p0 = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (jdof >= 0) {
+        // inward from the driven joint; links above it carry no bias
+        for (int i = 0; i < n; i++) { S6 z = {v3(0, 0, 0), v3(0, 0, 0)}; L6set(aw(i) + AW_PA, z); }
+        for (int i = jdof; i >= 0; i--) {
+          int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i);
+          S6 p = L6(o + AW_PA); S6 Sx = subspace(gl);
+          float u = (i == jdof ? 1.0f : 0.0f) - dot(Sx, p);
+          L(o + AW_UU) = u;
+          if (par >= 0 || !fx) {
+            S6 pa = p + L6(o + AW_U) * (u / L(o + AW_D));
+            S6 pf = xforce_to_parent(LM(o + AW_E), L3(o + AW_R), pa);
+            if (par < 0) p0 = p0 + pf; else L6add(aw(par - first) + AW_PA, pf);
+          }
+        }
+        for (int i = jdof + 1; i < n; i++) L(aw(i) + AW_UU) = 0.0f;
+      } else {
+        for (int i = 0; i < n; i++) L(aw(i) + AW_UU) = 0.0f;
+      }
+      S6 a0c = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (!fx) {
+        float rhs[6] = {-p0.a.x, -p0.a.y, -p0.a.z, -p0.l.x, -p0.l.y, -p0.l.z}, x[6];
+        if (jdof < 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) rhs[k] = (k == col) ? 1.0f : 0.0f;
+        }
+        chol6_solve(Lb, rhs, x);
+        a0c.a = v3(x[0], x[1], x[2]); a0c.l = v3(x[3], x[4], x[5]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k <= col) L(mo + minv_idx(k, col)) = x[k];
+      }
+      for (int i = 0; i < n; i++) {
+        int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i);
+        S6 ap = par < 0 ? a0c : L6(aw(par - first) + AW_V);
+        S6 a1 = xmotion(LM(o + AW_E), L3(o + AW_R), ap);
+        float qdd = (L(o + AW_UU) - dot(L6(o + AW_U), a1)) / L(o + AW_D);
+        L6set(o + AW_V, a1 + subspace(gl) * qdd);
+        if (nb6 + i <= col) L(mo + minv_idx(nb6 + i, col)) = qdd;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------ solver rows
+  // generalized velocity of body b dotted with a Jacobian stored at LDS offset jo (length nv)
+  DGD float gen_vel_dot(int b, int jo) const {
+    const int32_t* B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
+    float r = 0.f; int k = 0;
+    if (!fixed(b)) {
+      M3 R0 = LM(plb(b)[PLB_R0]);
+      V3 wb = tmul(R0, v3(S(so + DG_BS_ANGVEL), S(so + DG_BS_ANGVEL + 1), S(so + DG_BS_ANGVEL + 2)));
+      V3 vb = tmul(R0, v3(S(so + DG_BS_LINVEL), S(so + DG_BS_LINVEL + 1), S(so + DG_BS_LINVEL + 2)));
+      r = L(jo) * wb.x + L(jo + 1) * wb.y + L(jo + 2) * wb.z + L(jo + 3) * vb.x + L(jo + 4) * vb.y + L(jo + 5) * vb.z; k = 6;
+    }
+    for (int i = 0; i < n; i++) r += L(jo + k + i) * S(li(first + i)[DG_LI_STATE_OFF] + DG_LS_QD);
+    return r;
+  }
+  // Jacobian (into jo) and response M^-1 J^T (into ro) of body b for a unit force along world direction
+  // dir at world point p on link gl (-1 base).  Returns J M^-1 J^T.
+  DGD float point_row(int b, int gl, V3 p, V3 dir, int jo, int ro) const {
+    const int32_t* B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV]; int k0 = 0;
+    for (int k = 0; k < nv; k++) L(jo + k) = 0.f;
+    if (!fixed(b)) {
+      M3 R0 = LM(plb(b)[PLB_R0]); V3 ja = tmul(R0, cross(p - base_pos(b), dir)), jl = tmul(R0, dir);
+      L3set(jo, ja); L3set(jo + 3, jl); k0 = 6;
+    }
+    for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) {
+      int po = pll(k)[PLL_POSE]; M3 Rk = LM(po); V3 pk = L3(po + 9); const float* f = lf(k);
+      V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+      L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
+    }
+    (void)n;
+    float diag = 0.f;
+    for (int i = 0; i < nv; i++) {
+      float s = 0.f;
+      for (int j = 0; j < nv; j++) s += L(mo + minv_idx(i, j)) * L(jo + j);
+      L(ro + i) = s; diag += s * L(jo + i);
+    }
+    return diag;
+  }
+};
+
+}  // namespace dg

@@ -1,0 +1,550 @@
+// dg_solver.h -- narrow phase, constraint rows, projected Gauss-Seidel, position
+// update, inverse kinematics and the addon program, all per-lane on top of the
+// Lane<> workspace of dg_kernels.h.
+#pragma once
+#include "dg_kernels.h"
+
+namespace dg {
+
+// ---------------------------------------------------------------- narrow phase
+struct WShape { int type, body, glink; M3 R; V3 p; float prm0, prm1, prm2, mu; int poff, npts; };
+
+template <int LANES>
+DGD void shape_world(const Lane<LANES>& ln, int sh, WShape& o) {
+  const int32_t* si = ln.sc.SI + sh * DG_SI_STRIDE; const float* sf = ln.sc.SF + sh * DG_SF_STRIDE;
+  o.type = si[DG_SI_TYPE]; o.body = si[DG_SI_BODY]; o.glink = si[DG_SI_LINK]; o.poff = si[DG_SI_POINT_OFF]; o.npts = si[DG_SI_N_POINTS];
+  M3 Rl; V3 pl; ln.link_world(o.body, o.glink, Rl, pl);
+  M3 Rs; _Pragma("unroll") for (int k = 0; k < 9; k++) Rs.m[k] = sf[DG_SF_ROT + k];
+  o.R = mul(Rl, Rs); o.p = pl + mul(Rl, v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]));
+  o.prm0 = sf[DG_SF_PARAMS]; o.prm1 = sf[DG_SF_PARAMS + 1]; o.prm2 = sf[DG_SF_PARAMS + 2]; o.mu = sf[DG_SF_FRICTION];
+}
+
+struct Hit { bool hit; V3 pa, pb, n; float dist; };
+
+DGD Hit sphere_box(V3 c, float r, const WShape& bx, float margin) {
+  Hit h; V3 lc = tmul(bx.R, c - bx.p);
+  float hx[3] = {bx.prm0, bx.prm1, bx.prm2}, l[3] = {lc.x, lc.y, lc.z}, cl[3]; bool inside = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { cl[k] = fminf(fmaxf(l[k], -hx[k]), hx[k]); inside = inside && (cl[k] == l[k]); }
+  V3 nl; float d;
+  if (!inside) { V3 df = v3(l[0] - cl[0], l[1] - cl[1], l[2] - cl[2]); d = norm(df); nl = df * (1.0f / d); }
+  else {
+    int best = 0; float bd = 3.0e38f, sg = 1.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { float dp = hx[k] - l[k], dm = l[k] + hx[k]; if (dp < bd) { bd = dp; best = k; sg = 1.f; } if (dm < bd) { bd = dm; best = k; sg = -1.f; } }
+    nl = v3(best == 0 ? sg : 0.f, best == 1 ? sg : 0.f, best == 2 ? sg : 0.f); d = -bd;
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k == best) cl[k] = sg * hx[k];
+  }
+  h.hit = (d - r) < margin; h.n = mul(bx.R, nl); h.pb = bx.p + mul(bx.R, v3(cl[0], cl[1], cl[2])); h.pa = c - h.n * r; h.dist = d - r;
+  return h;
+}
+DGD Hit sphere_sphere(V3 ca, float ra, V3 cb, float rb, float margin) {
+  Hit h; V3 d = ca - cb; float len = norm(d);
+  h.hit = (len - ra - rb) < margin; h.n = len > 1e-12f ? d * (1.0f / len) : v3(0, 0, 1);
+  h.pa = ca - h.n * ra; h.pb = cb + h.n * rb; h.dist = len - ra - rb;
+  return h;
+}
+DGD void seg_ends(const WShape& c, V3& e0, V3& e1) {
+  V3 ax = v3(c.R.m[2], c.R.m[5], c.R.m[8]); e0 = c.p - ax * c.prm1; e1 = c.p + ax * c.prm1;
+}
+DGD float clamp01(float t) { return fminf(fmaxf(t, 0.f), 1.f); }
+DGD V3 closest_on_seg(V3 a, V3 b, V3 p) {
+  V3 ab = b - a; float den = dot(ab, ab); float t = den > 0.f ? clamp01(dot(p - a, ab) / den) : 0.f; return a + ab * t;
+}
+DGD void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
+  V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2; float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), sN, tN; const float eps = 1e-12f;
+  if (a <= eps && e <= eps) { c1 = p1; c2 = p2; return; }
+  if (a <= eps) { sN = 0.f; tN = clamp01(f / e); }
+  else {
+    float c = dot(d1, r);
+    if (e <= eps) { tN = 0.f; sN = clamp01(-c / a); }
+    else {
+      float b = dot(d1, d2), den = a * e - b * b;
+      sN = den > eps ? clamp01((b * f - c * e) / den) : 0.f;
+      tN = (b * sN + f) / e;
+      if (tN < 0.f) { tN = 0.f; sN = clamp01(-c / a); } else if (tN > 1.f) { tN = 1.f; sN = clamp01((b - c) / a); }
+    }
+  }
+  c1 = p1 + d1 * sN; c2 = p2 + d2 * tN;
+}
+
+// contact list lives at sc.cont_off: slot 0 = count, then max_contacts entries of CL_STRIDE
+template <int LANES>
+DGD void emit_contact(const Lane<LANES>& ln, int& cnt, int pair, const Hit& h, float flip) {
+  if (!h.hit || cnt >= ln.sc.max_contacts) return;
+  int o = ln.sc.cont_off + 1 + cnt * CL_STRIDE;
+  ln.L(o + CL_PAIR) = (float)pair;
+  ln.L3set(o + CL_P, (h.pa + h.pb) * 0.5f);
+  ln.L3set(o + CL_N, h.n * flip);
+  ln.L(o + CL_DIST) = h.dist;
+  cnt++;
+}
+
+template <int LANES>
+DGD int collide(const Lane<LANES>& ln) {
+  const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
+  for (int pi = 0; pi < sc.npairs; pi++) {
+    WShape A, Bs; shape_world(ln, sc.PI[pi * DG_PI_STRIDE + DG_PI_A], A); shape_world(ln, sc.PI[pi * DG_PI_STRIDE + DG_PI_B], Bs);
+    // canonical order (uniform): lower type first, a box always second.  Normals are reported from
+    // the pair's second shape towards its first, so flip when the roles were swapped.
+    const bool swap = A.type == DG_SHAPE_BOX || (Bs.type != DG_SHAPE_BOX && A.type > Bs.type);
+    const WShape& a = swap ? Bs : A; const WShape& b = swap ? A : Bs; const float flip = swap ? -1.f : 1.f;
+    const bool a_round = a.type == DG_SHAPE_CAPSULE || a.type == DG_SHAPE_POINTS, b_round = b.type == DG_SHAPE_CAPSULE || b.type == DG_SHAPE_POINTS;
+    if (a.type == DG_SHAPE_SPHERE && b.type == DG_SHAPE_SPHERE) emit_contact(ln, cnt, pi, sphere_sphere(a.p, a.prm0, b.p, b.prm0, margin), flip);
+    else if (a.type == DG_SHAPE_SPHERE && b.type == DG_SHAPE_BOX) emit_contact(ln, cnt, pi, sphere_box(a.p, a.prm0, b, margin), flip);
+    else if (a.type == DG_SHAPE_SPHERE && b_round) { V3 e0, e1; seg_ends(b, e0, e1); emit_contact(ln, cnt, pi, sphere_sphere(a.p, a.prm0, closest_on_seg(e0, e1, a.p), b.prm0, margin), flip); }
+    else if (a_round && b_round) { V3 a0, a1, b0, b1, ca, cb; seg_ends(a, a0, a1); seg_ends(b, b0, b1); seg_seg(a0, a1, b0, b1, ca, cb); emit_contact(ln, cnt, pi, sphere_sphere(ca, a.prm0, cb, b.prm0, margin), flip); }
+    else if (a.type == DG_SHAPE_CAPSULE && b.type == DG_SHAPE_BOX) {
+      V3 e0, e1; seg_ends(a, e0, e1); emit_contact(ln, cnt, pi, sphere_box(e0, a.prm0, b, margin), flip);
+      if (a.prm1 > 0.f) emit_contact(ln, cnt, pi, sphere_box(e1, a.prm0, b, margin), flip);
+    } else if (a.type == DG_SHAPE_POINTS && b.type == DG_SHAPE_BOX) {
+      int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+      M3 Rl; V3 pl; ln.link_world(a.body, a.glink, Rl, pl);
+      for (int k = 0; k < a.npts; k++) {
+        const float* pp = sc.PF + 3 * (a.poff + k);
+        Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
+        if (!h.hit) continue;
+        bool placed = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (!placed && h.dist < bd4[j]) {
+#pragma unroll
+            for (int m = 3; m > j; m--) { bd4[m] = bd4[m - 1]; bi4[m] = bi4[m - 1]; }
+            bd4[j] = h.dist; bi4[j] = k; placed = true;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int k = bi4[j] < 0 ? 0 : bi4[j];
+        const float* pp = sc.PF + 3 * (a.poff + k);  // per-lane index: vector load
+        Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
+        h.hit = h.hit && bi4[j] >= 0;
+        emit_contact(ln, cnt, pi, h, flip);
+      }
+    }
+  }
+  ln.L(sc.cont_off) = (float)cnt;
+  return cnt;
+}
+
+// ------------------------------------------------------------------- rows
+// contact row r (3 per contact: normal, t1, t2) in the transient region:
+//   [JA nvmax][RA nvmax][JB nvmax][RB nvmax][b][acc][diag][dvA][nvA][dvB][nvB]
+DGD int crow_stride(int nvmax) { return 4 * nvmax + 7; }
+
+DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
+  if (fabsf(n.z) > 0.70710678118654752f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); t1 = v3(0.f, -n.z * k, n.y * k); t2 = v3(a * k, -n.x * t1.z, n.x * t1.y); }
+  else { float a = n.x * n.x + n.y * n.y, k = 1.0f / sqrtf(a); t1 = v3(-n.y * k, n.x * k, 0.f); t2 = v3(-n.z * t1.y, n.z * t1.x, a * k); }
+}
+
+// builds the three rows of contact slot c for the lanes whose contact belongs to (uniform) pair `pair`
+template <int LANES>
+DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
+  const DevScene& sc = ln.sc; const int nvm = sc.nv_max, rs = crow_stride(nvm);
+  const int32_t* sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; const int32_t* sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
+  const int ba = sa[DG_SI_BODY], la = sa[DG_SI_LINK], bb = sb[DG_SI_BODY], lb = sb[DG_SI_LINK];
+  const bool a_dyn = !(ln.fixed(ba) && ln.bi(ba)[DG_BI_N_LINKS] == 0), b_dyn = !(ln.fixed(bb) && ln.bi(bb)[DG_BI_N_LINKS] == 0);
+  if (!mine) return;
+  const int co = sc.cont_off + 1 + c * CL_STRIDE;
+  V3 p = ln.L3(co + CL_P), n = ln.L3(co + CL_N); float dist = ln.L(co + CL_DIST);
+  V3 t1, t2; tangent_basis(n, t1, t2);
+  const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
+  for (int d = 0; d < 3; d++) {
+    V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
+    int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
+    // first side = the dynamic one of (A, B); the oracle makes the same choice
+    int b1 = a_dyn ? ba : bb, l1 = a_dyn ? la : lb; V3 d1 = a_dyn ? dir : -dir;
+    diag += ln.point_row(b1, l1, p, d1, ro, ro + nvm); jv += ln.gen_vel_dot(b1, ro);
+    ln.L(ro + 4 * nvm + 3) = (float)ln.plb(b1)[PLB_DV]; ln.L(ro + 4 * nvm + 4) = (float)ln.plb(b1)[PLB_NV];
+    if (a_dyn && b_dyn) {
+      diag += ln.point_row(bb, lb, p, -dir, ro + 2 * nvm, ro + 3 * nvm); jv += ln.gen_vel_dot(bb, ro + 2 * nvm);
+      ln.L(ro + 4 * nvm + 5) = (float)ln.plb(bb)[PLB_DV]; ln.L(ro + 4 * nvm + 6) = (float)ln.plb(bb)[PLB_NV];
+    } else { ln.L(ro + 4 * nvm + 5) = 0.f; ln.L(ro + 4 * nvm + 6) = 0.f; }
+    float b = -jv;
+    if (d == 0) { float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
+    ln.L(ro + 4 * nvm) = b; ln.L(ro + 4 * nvm + 1) = 0.f; ln.L(ro + 4 * nvm + 2) = diag;
+  }
+}
+
+// one PGS update of contact row at ro; returns the squared velocity residual
+template <int LANES>
+DGD float solve_crow(const Lane<LANES>& ln, int ro, float lo, float hi, bool live, bool has) {
+  if (!has) return 0.f;  // lanes without this contact slot hold no row data at all
+  const int nvm = ln.sc.nv_max;
+  const int dA = (int)ln.L(ro + 4 * nvm + 3), nA = (int)ln.L(ro + 4 * nvm + 4), dB = (int)ln.L(ro + 4 * nvm + 5), nB = (int)ln.L(ro + 4 * nvm + 6);
+  float jv = 0.f;
+  for (int k = 0; k < nvm; k++) { if (k < nA) jv += ln.L(ro + k) * ln.L(dA + k); if (k < nB) jv += ln.L(ro + 2 * nvm + k) * ln.L(dB + k); }
+  float diag = ln.L(ro + 4 * nvm + 2), acc = ln.L(ro + 4 * nvm + 1);
+  float delta = (ln.L(ro + 4 * nvm) - jv) / diag;
+  float nacc = fminf(fmaxf(acc + delta, lo), hi);
+  delta = live && diag > 1e-18f ? nacc - acc : 0.f;
+  ln.L(ro + 4 * nvm + 1) = acc + delta;
+  for (int k = 0; k < nvm; k++) { if (k < nA) ln.L(dA + k) += ln.L(ro + nvm + k) * delta; if (k < nB) ln.L(dB + k) += ln.L(ro + 3 * nvm + k) * delta; }
+  float res = delta * diag; return res * res;
+}
+
+// ---------------------------------------------------------------- substep
+template <int LANES>
+DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
+  const DevScene& sc = ln.sc; const float h = sc.h;
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  const int ncont = collide(ln);
+  for (int b = 0; b < sc.nb; b++) {
+    if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
+    ln.dynamics(b);
+    const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
+    for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+  }
+  // ---- motor and joint-limit rows (per link, uniform)
+  const float lerp = sc.HF[DG_HF_LIMIT_ERP];
+  for (int gl = 0; gl < sc.nl; gl++) {
+    const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; const float* f = ln.lf(gl);
+    const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
+    const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
+    ln.L(mo + MR_B) = kp * (ln.S(lo + DG_LS_TARGET_POS) - q) / h + kd * (ln.S(lo + DG_LS_TARGET_VEL) - qd);
+    ln.L(mo + MR_ACC) = 0.f;
+    const bool limited = f[DG_LF_LOWER] <= f[DG_LF_UPPER];
+    const float dlo = q - f[DG_LF_LOWER], dhi = f[DG_LF_UPPER] - q;
+    // acc < 0 marks an inactive limit row
+    ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
+    ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
+  }
+  // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
+  const int wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
+  for (int c = 0; c < wave_max_cont; c++) {
+    const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
+    bool todo = has;
+    while (__any(todo)) {
+      const int leader = __ffsll((long long)__ballot(todo)) - 1;
+      const int pair = __shfl(mypair, leader);
+      const bool mine = todo && mypair == pair;
+      build_contact_rows(ln, c, pair, mine);
+      todo = todo && !mine;
+    }
+  }
+  // ---- projected Gauss-Seidel
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int nvm = sc.nv_max, rs = crow_stride(nvm);
+  bool live = ln.valid; int iters_done = 0;
+  for (int it = 0; it < sc.iters; it++) {
+    float maxres = 0.f;
+    for (int gl = 0; gl < sc.nl; gl++) {  // motors
+      const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+      if (!(maximp > 0.f)) continue;
+      const int b = ln.li(gl)[DG_LI_BODY]; const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
+      const int j = gl - ln.bi(b)[DG_BI_FIRST_LINK] + (ln.fixed(b) ? 0 : 6), mo = ln.pll(gl)[PLL_MROW];
+      const float diag = ln.L(mvo + ln.minv_idx(j, j)), acc = ln.L(mo + MR_ACC);
+      float delta = (ln.L(mo + MR_B) - ln.L(dvo + j)) / diag;
+      float nacc = fminf(fmaxf(acc + delta, -maximp), maximp);
+      delta = live ? nacc - acc : 0.f; ln.L(mo + MR_ACC) = acc + delta;
+      for (int k = 0; k < nv; k++) ln.L(dvo + k) += ln.L(mvo + ln.minv_idx(k, j)) * delta;
+      float res = delta * diag; maxres = fmaxf(maxres, res * res);
+    }
+    for (int gl = 0; gl < sc.nl; gl++) {  // joint limits
+      const float* f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
+      const int b = ln.li(gl)[DG_LI_BODY]; const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
+      const int j = gl - ln.bi(b)[DG_BI_FIRST_LINK] + (ln.fixed(b) ? 0 : 6), mo = ln.pll(gl)[PLL_MROW];
+      const float diag = ln.L(mvo + ln.minv_idx(j, j));
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        const float sg = side == 0 ? 1.f : -1.f; const int bo = mo + (side == 0 ? MR_LO_B : MR_HI_B);
+        const float acc = ln.L(bo + 1); const bool act = acc >= 0.f;
+        if (!__any(act)) continue;
+        float delta = (ln.L(bo) - sg * ln.L(dvo + j)) / diag;
+        float nacc = fmaxf(acc + delta, 0.f);
+        delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
+        for (int k = 0; k < nv; k++) ln.L(dvo + k) += sg * ln.L(mvo + ln.minv_idx(k, j)) * delta;
+        float res = delta * diag; maxres = fmaxf(maxres, res * res);
+      }
+    }
+    for (int c = 0; c < wave_max_cont; c++) {  // contact normals
+      const bool has = c < ncont;
+      float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, 0.f, 3.0e38f, live, has);
+      if (has) maxres = fmaxf(maxres, r);
+    }
+    for (int c = 0; c < wave_max_cont; c++) {  // friction
+      const bool has = c < ncont;
+      const int pair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : 0;
+      // per-lane pair id: shape friction is read with per-lane (vector) loads
+      const float mu = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
+      const bool act = has && mu > 0.f;
+      const float lim = act ? mu * ln.L(sc.tr_off + (3 * c) * rs + 4 * nvm + 1) : 0.f;
+#pragma unroll
+      for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
+    }
+    if (live) iters_done = it + 1;
+    live = live && !(maxres <= thr);
+    if (!__any(live)) break;
+  }
+  if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
+  // ---- apply velocity changes and integrate positions
+  const float vmax = sc.HF[DG_HF_MAX_COORD_VEL];
+  for (int gl = 0; gl < sc.nl; gl++) {
+    const int lo = ln.li(gl)[DG_LI_STATE_OFF]; const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+    ln.Sset(lo + DG_LS_APPLIED, maximp > 0.f ? ln.L(ln.pll(gl)[PLL_MROW] + MR_ACC) / h : 0.f);
+  }
+  for (int b = 0; b < sc.nb; b++) {
+    const int32_t* B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
+    const bool fx = ln.fixed(b); if (fx && n == 0) continue;
+    const int dvo = ln.plb(b)[PLB_DV];
+    if (!fx) {
+      M3 R0 = ln.LM(ln.plb(b)[PLB_R0]);
+      V3 dw = mul(R0, ln.L3(dvo)), dl = mul(R0, ln.L3(dvo + 3));
+      V3 w = v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2)) + dw;
+      V3 v = v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)) + dl;
+      ln.Sset(so + DG_BS_ANGVEL, w.x); ln.Sset(so + DG_BS_ANGVEL + 1, w.y); ln.Sset(so + DG_BS_ANGVEL + 2, w.z);
+      ln.Sset(so + DG_BS_LINVEL, v.x); ln.Sset(so + DG_BS_LINVEL + 1, v.y); ln.Sset(so + DG_BS_LINVEL + 2, v.z);
+      ln.Sset(so, ln.S(so) + h * v.x); ln.Sset(so + 1, ln.S(so + 1) + h * v.y); ln.Sset(so + 2, ln.S(so + 2) + h * v.z);
+      float wn = norm(w), th = wn * h; Q4 dq;
+      if (th > 1e-12f) { float sn, cs; sincosf(0.5f * th, &sn, &cs); sn /= wn; dq.x = w.x * sn; dq.y = w.y * sn; dq.z = w.z * sn; dq.w = cs; }
+      else { dq.x = 0.5f * h * w.x; dq.y = 0.5f * h * w.y; dq.z = 0.5f * h * w.z; dq.w = 1.f; }
+      Q4 qn = qnormalize(qmul(dq, ln.base_quat(b)));
+      ln.Sset(so + 3, qn.x); ln.Sset(so + 4, qn.y); ln.Sset(so + 5, qn.z); ln.Sset(so + 6, qn.w);
+    }
+    const int k0 = fx ? 0 : 6;
+    for (int i = 0; i < n; i++) {
+      const int lo = ln.li(first + i)[DG_LI_STATE_OFF];
+      float qd = ln.S(lo + DG_LS_QD) + ln.L(dvo + k0 + i); qd = fminf(fmaxf(qd, -vmax), vmax);
+      ln.Sset(lo + DG_LS_QD, qd); ln.Sset(lo + DG_LS_Q, ln.S(lo + DG_LS_Q) + h * qd);
+    }
+  }
+}
+
+template <int LANES>
+DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out) {
+  const DevScene& sc = ln.sc;
+  for (int k = 0; k < sc.substeps; k++) substep(ln, diag_out);
+  for (int b = 0; b < sc.nb; b++) { const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
+  for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
+}
+
+// ------------------------------------------------------- inverse kinematics
+// Damped-least-squares IK with null-space projection (UR5 path of ik_controller.py:61-69).
+// Transient layout: [q n][J 6n][v0 n][dth n].  POSE of the body is overwritten by trial poses
+// and must be refreshed by the caller afterwards.
+template <int LANES>
+DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane) {
+  const DevScene& sc = ln.sc; const int32_t* oi = sc.OI + op * DG_OI_STRIDE;
+  const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
+  const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS];
+  const int qo = sc.tr_off, jo = qo + n, vo = jo + 6 * n, dto = vo + n;
+  const float* rest = sc.FL + oi[DG_OI_FLIST];
+  for (int i = 0; i < n; i++) ln.L(qo + i) = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q);
+  V3 cp, cv, cw; Q4 cq; ln.frame_state(b, fr, true, cp, cq, cv, cw, false);
+  V3 tp = cp + v3(act[0], act[1], act[2]); Q4 tq = cq;
+  if (use_orn) tq = qmul(cq, qfrom_euler(act[3], act[4], act[5]));
+  const int eel = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
+  const float lam2 = sc.HF[DG_HF_IK_LAMBDA_SQ], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
+  const float resid = sc.HF[DG_HF_IK_RESIDUAL];
+  bool live = live_lane;
+  for (int it = 0; it < sc.ik_iters; it++) {
+    ln.kinematics(b, qo);
+    V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, true, fp, fq, fv, fw, false);
+    V3 ep = tp - fp;
+    if (it > 0 && norm(ep) < resid) live = false;
+    if (!__any(live)) break;
+    float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
+    if (use_orn) {
+      Q4 dq = qmul(tq, qconj(fq)); if (dq.w < 0.f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
+      float sn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0f * atan2f(sn, dq.w), k = sn > 1e-12f ? an / sn : 2.0f;
+      dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
+    }
+    // Jacobian columns (world frame) for the chain root -> end-effector link, zero elsewhere
+    for (int i = 0; i < 6 * n; i++) ln.L(jo + i) = 0.f;
+    for (int k = eel; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
+      int po = ln.pll(k)[PLL_POSE]; M3 Rk = ln.LM(po); V3 pk = ln.L3(po + 9); const float* f = ln.lf(k);
+      V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2])); int i = k - first;
+      V3 jl, ja; if (ln.li(k)[DG_LI_TYPE] == 0) { jl = cross(axw, fp - pk); ja = axw; } else { jl = axw; ja = v3(0, 0, 0); }
+      ln.L(jo + i) = jl.x; ln.L(jo + n + i) = jl.y; ln.L(jo + 2 * n + i) = jl.z;
+      if (use_orn) { ln.L(jo + 3 * n + i) = ja.x; ln.L(jo + 4 * n + i) = ja.y; ln.L(jo + 5 * n + i) = ja.z; }
+    }
+    // U = J J^T + lambda^2 I (rows 3..5 are zero without orientation: block diagonal, same solution)
+    float U[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) U[k] = 0.f;
+    for (int k = 0; k < n; k++) {
+      float col[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) col[r] = ln.L(jo + r * n + k);
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) U[r * (r + 1) / 2 + c] += col[r] * col[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) U[r * (r + 1) / 2 + r] += lam2;
+    chol6(U);
+    float y[6]; chol6_solve(U, dS, y);
+    float Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < n; k++) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 6; r++) t += ln.L(jo + r * n + k) * y[r];
+      float v0 = 0.f;
+      if (nullsp) {
+        float q = ln.L(qo + k), lo = rest[n + k], hi = rest[2 * n + k], rg = rest[3 * n + k];
+        v0 = g0 * (rest[k] - q);
+        if (q > hi) v0 += g1 * (hi - q) / rg;
+        if (q < lo) v0 += g1 * (lo - q) / rg;
+#pragma unroll
+        for (int r = 0; r < 6; r++) Jv[r] += ln.L(jo + r * n + k) * v0;
+      }
+      ln.L(vo + k) = v0; ln.L(dto + k) = t;
+    }
+    float mx = 0.f;
+    if (nullsp) {
+      float z[6]; chol6_solve(U, Jv, z);
+      for (int k = 0; k < n; k++) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 6; r++) t += ln.L(jo + r * n + k) * z[r];
+        float d = ln.L(dto + k) + ln.L(vo + k) - t; ln.L(dto + k) = d; mx = fmaxf(mx, fabsf(d));
+      }
+    } else {
+      for (int k = 0; k < n; k++) mx = fmaxf(mx, fabsf(ln.L(dto + k)));
+    }
+    const float scl = mx > maxang ? maxang / mx : 1.0f;
+    for (int k = 0; k < n; k++) if (live) ln.L(qo + k) += scl * ln.L(dto + k);
+  }
+}
+
+// ------------------------------------------------------------ addon program
+template <int LANES>
+DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask) {
+  const DevScene& sc = ln.sc;
+  for (int op = 0; op < sc.nops; op++) {
+    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
+    if (!((mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
+    const float* a = act_row + oi[DG_OI_IO_OFF]; const int32_t* il = sc.IL + oi[DG_OI_ILIST]; const int n = oi[DG_OI_N];
+    if (code == DG_OP_JOINT_CONTROL) {
+      const int mode = oi[DG_OI_FLAGS];
+      for (int k = 0; k < n; k++) {
+        const int lo = ln.li(il[k])[DG_LI_STATE_OFF];
+        if (mode == DG_JC_POSITION) { ln.Sset(lo + DG_LS_TARGET_POS, a[k]); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f); }
+        else if (mode == DG_JC_VELOCITY) { ln.Sset(lo + DG_LS_TARGET_VEL, a[k]); ln.Sset(lo + DG_LS_TARGET_POS, 0.f); }
+        else ln.Sset(lo + DG_LS_TORQUE, a[k]);
+      }
+    } else if (code == DG_OP_IK_CONTROL) {
+      const int b = oi[DG_OI_BODY];
+      float av[6] = {a[0], a[1], a[2], 0.f, 0.f, 0.f};
+      if (oi[DG_OI_FLAGS] & DG_IK_USE_ORIENTATION) { av[3] = a[3]; av[4] = a[4]; av[5] = a[5]; }
+      run_ik(ln, op, av, true);
+      for (int k = 0; k < n; k++) {
+        const int lo = ln.li(il[k])[DG_LI_STATE_OFF];
+        ln.Sset(lo + DG_LS_TARGET_POS, ln.L(sc.tr_off + (il[k] - ln.bi(b)[DG_BI_FIRST_LINK]))); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f);
+      }
+      ln.kinematics(b);  // restore POSE to the state's joint angles
+    } else if (code == DG_OP_EXTERNAL_FORCE) {
+      const int b = oi[DG_OI_BODY]; if (ln.fixed(b)) continue;
+      const int eo = ln.ext_off(b); V3 f = v3(a[0], a[1], a[2]); V3 t = cross(v3(of[0], of[1], of[2]) - ln.base_pos(b), f);
+      ln.Sset(eo, ln.S(eo) + f.x); ln.Sset(eo + 1, ln.S(eo + 1) + f.y); ln.Sset(eo + 2, ln.S(eo + 2) + f.z);
+      ln.Sset(eo + 3, ln.S(eo + 3) + t.x); ln.Sset(eo + 4, ln.S(eo + 4) + t.y); ln.Sset(eo + 5, ln.S(eo + 5) + t.z);
+    } else if (code == DG_OP_PROPELLOR) {
+      const int b = oi[DG_OI_BODY], so = sc.addon_off + oi[DG_OI_STATE_OFF];
+      float w = ln.S(so); w = w + (a[0] - w) * of[2]; ln.Sset(so, w);
+      if (ln.fixed(b)) continue;
+      V3 fp, fv, fw; Q4 fq; ln.frame_state(b, oi[DG_OI_FRAME], false, fp, fq, fv, fw, false);
+      M3 R = qmat(fq); V3 fwd = mul(R, v3(0.f, 0.f, of[0] * w)), tw = mul(R, v3(0.f, 0.f, of[1] * w));
+      V3 t = cross(fp - ln.base_pos(b), fwd) + tw; const int eo = ln.ext_off(b);
+      ln.Sset(eo, ln.S(eo) + fwd.x); ln.Sset(eo + 1, ln.S(eo + 1) + fwd.y); ln.Sset(eo + 2, ln.S(eo + 2) + fwd.z);
+      ln.Sset(eo + 3, ln.S(eo + 3) + t.x); ln.Sset(eo + 4, ln.S(eo + 4) + t.y); ln.Sset(eo + 5, ln.S(eo + 5) + t.z);
+    }
+  }
+}
+
+template <int LANES>
+DGD void set_base_com_pose(const Lane<LANES>& ln, int b, V3 pc, Q4 qc) {
+  const float* f = ln.bf(b); const int so = ln.bi(b)[DG_BI_STATE_OFF];
+  Q4 qr = {f[DG_BF_REPORT_QUAT], f[DG_BF_REPORT_QUAT + 1], f[DG_BF_REPORT_QUAT + 2], f[DG_BF_REPORT_QUAT + 3]};
+  Q4 ql = qnormalize(qmul(qc, qconj(qr))); M3 R = qmat(ql);
+  V3 pl = pc - mul(R, v3(f[DG_BF_REPORT_POS], f[DG_BF_REPORT_POS + 1], f[DG_BF_REPORT_POS + 2]));
+  ln.Sset(so, pl.x); ln.Sset(so + 1, pl.y); ln.Sset(so + 2, pl.z); ln.Sset(so + 3, ql.x); ln.Sset(so + 4, ql.y); ln.Sset(so + 5, ql.z); ln.Sset(so + 6, ql.w);
+  if (!ln.fixed(b)) for (int k = 0; k < 6; k++) ln.Sset(so + DG_BS_LINVEL + k, 0.f);
+}
+
+template <int LANES>
+DGD void run_reset_ops(const Lane<LANES>& ln) {
+  const DevScene& sc = ln.sc; const uint64_t episode = (uint64_t)ln.S(DG_ST_EPISODE);
+  for (int op = 0; op < sc.nops; op++) {
+    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+    if (code == DG_OP_RESPAWN) {
+      const uint64_t ep = (oi[DG_OI_FLAGS] & DG_RS_ONCE) ? 0ull : episode + 1ull, ge = (uint64_t)(sc.env_base + ln.env);
+      float u[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) u[k] = rng_uniform(sc.seed, ge, ep, (uint64_t)op, (uint64_t)k) - 0.5f;
+      V3 p = v3(of[0] + u[0] * of[7], of[1] + u[1] * of[8], of[2] + u[2] * of[9]);
+      Q4 q0 = {of[3], of[4], of[5], of[6]};
+      set_base_com_pose(ln, oi[DG_OI_BODY], p, qmul(q0, qfrom_euler(u[3] * of[10], u[4] * of[11], u[5] * of[12])));
+    } else if (code == DG_OP_RESET_JOINTS) {
+      const int32_t* il = sc.IL + oi[DG_OI_ILIST]; const float* fl = sc.FL + oi[DG_OI_FLIST];
+      for (int k = 0; k < oi[DG_OI_N]; k++) { const int lo = ln.li(il[k])[DG_LI_STATE_OFF]; ln.Sset(lo + DG_LS_Q, fl[k]); ln.Sset(lo + DG_LS_QD, 0.f); }
+    }
+  }
+  ln.Sset(DG_ST_EPISODE, (float)(episode + 1ull));
+}
+
+template <int LANES>
+DGD float reach_dist(const Lane<LANES>& ln, const int32_t* oi) {
+  V3 pa, pb, v, w; Q4 q;
+  ln.frame_state(oi[DG_OI_BODY2], oi[DG_OI_FRAME2], oi[DG_OI_FRAME2] < 0, pa, q, v, w, false);
+  ln.frame_state(oi[DG_OI_BODY], oi[DG_OI_FRAME], oi[DG_OI_FRAME] < 0, pb, q, v, w, false);
+  return norm(pb - pa);
+}
+
+// observe / reward / terminal ops; POSE must be current for every body
+template <int LANES>
+DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag) {
+  const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
+  for (int op = 0; op < sc.nops; op++) {
+    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE;
+    const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; const int32_t* il = sc.IL + oi[DG_OI_ILIST];
+    if (code == DG_OP_OBS_JOINT_STATE) {
+      const int n = oi[DG_OI_N]; int k2 = n;
+      if (obs) {
+        for (int k = 0; k < n; k++) obs[io + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_Q);
+        if (oi[DG_OI_FLAGS] & DG_JS_VELOCITY) { for (int k = 0; k < n; k++) obs[io + k2 + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_QD); k2 += n; }
+        if (oi[DG_OI_FLAGS] & DG_JS_EFFORT) for (int k = 0; k < n; k++) obs[io + k2 + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_APPLIED);
+      }
+    } else if (code == DG_OP_OBS_OBJECT_STATE) {
+      V3 p, v, w; Q4 q; const bool wv = oi[DG_OI_FLAGS] & DG_OS_VELOCITY;
+      ln.frame_state(oi[DG_OI_BODY], oi[DG_OI_FRAME], true, p, q, v, w, wv);
+      if (oi[DG_OI_BODY2] >= 0) {
+        V3 sp, sv, sw; Q4 sq; ln.frame_state(oi[DG_OI_BODY2], oi[DG_OI_FRAME2], true, sp, sq, sv, sw, wv);
+        p = p - sp; q = qmul(sq, q); if (wv) { v = v - sv; w = w - sw; }
+      }
+      if (obs) {
+        int k = io; obs[k++] = p.x; obs[k++] = p.y; obs[k++] = p.z;
+        if (wv) { obs[k++] = v.x; obs[k++] = v.y; obs[k++] = v.z; }
+        if (oi[DG_OI_FLAGS] & DG_OS_ROTATION) { V3 e = euler_from_q(q); obs[k++] = e.x; obs[k++] = e.y; obs[k++] = e.z; }
+        if (wv && (oi[DG_OI_FLAGS] & DG_OS_ROTATION)) { obs[k++] = w.x; obs[k++] = w.y; obs[k++] = w.z; }
+      }
+    } else if (code == DG_OP_OBS_ADDON_STATE) {
+      if (obs) for (int k = 0; k < oi[DG_OI_N]; k++) obs[io + k] = ln.S(sc.addon_off + oi[DG_OI_STATE_OFF] + k);
+    } else if (code == DG_OP_REW_REACH) { float r = -reach_dist(ln, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
+    else if (code == DG_OP_REW_ELECTRICITY) {
+      const int32_t* B = ln.bi(oi[DG_OI_BODY]); float acc = 0.f;
+      for (int i = 0; i < B[DG_BI_N_LINKS]; i++) { const int lo = ln.li(B[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabsf(ln.S(lo + DG_LS_APPLIED) * ln.S(lo + DG_LS_QD)); }
+      float r = -acc * of[0]; if (rew) rew[io] = r; rsum += r;
+    } else if (code == DG_OP_REW_CONST) { if (rew) rew[io] = of[0]; rsum += of[0]; }
+    else if (code == DG_OP_TERM_REACH || code == DG_OP_TERM_TILT || code == DG_OP_TERM_TIMER) {
+      bool t;
+      if (code == DG_OP_TERM_REACH) t = reach_dist(ln, oi) < of[1];
+      else if (code == DG_OP_TERM_TILT) {
+        V3 p, v, w; Q4 q; ln.frame_state(oi[DG_OI_BODY], -1, true, p, q, v, w, false);
+        t = 2.0f * atan2f(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z), fabsf(q.w)) > of[0];
+      } else t = ln.S(DG_ST_STEP) >= of[0];
+      if (term) term[io] = t ? 1 : 0;
+      if (t) { any = true; groups |= 1ull << (oi[DG_OI_SLOT] & 63); }
+    }
+  }
+  if (rew_sum) *rew_sum = rsum;
+  if (term_flag) {
+    if (sc.term_mode == DG_COLLAPSE_ALL) { const uint64_t want = sc.n_term_groups >= 64 ? ~0ull : ((1ull << sc.n_term_groups) - 1ull); *term_flag = (sc.n_term_groups > 0 && (groups & want) == want) ? 1 : 0; }
+    else *term_flag = any ? 1 : 0;
+  }
+}
+
+}  // namespace dg

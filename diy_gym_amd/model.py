@@ -1,0 +1,82 @@
+"""``Model``: one URDF body of the scene (reference: diy_gym/model.py:11-106).
+
+Same config keys (``model``, ``xyz``, ``rpy``, ``scale``, ``use_fixed_base``,
+``mass``, ``color``) and the same receptor role; instead of ``p.loadURDF`` the
+URDF is parsed and flattened on the host and registered with the environment's
+:class:`~diy_gym_amd.scene.SceneBuilder`.  ``uid`` is the body index in the
+scene (pybullet hands out body ids in load order too).
+"""
+import os
+from collections import OrderedDict
+
+from . import mesh
+from .addons.addon import AddonFactory, Receptor
+from .mathx import quat_from_euler
+from .urdf import FlatBody, UrdfRobot
+
+_PKG_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+
+
+def urdf_search_path():
+    """Same three-entry idea as the reference (model.py:8): the path as given,
+    the package data directory, then a pybullet_data directory -- here the
+    stand-ins authored under ``data/pybullet_data`` (plane, sphere2, ...),
+    or the real one when ``DIYGYM_PYBULLET_DATA`` points to it."""
+    extra = os.environ.get('DIYGYM_PYBULLET_DATA')
+    paths = ['', _PKG_DATA]
+    if extra:
+        paths.append(extra)
+    paths.append(os.path.join(_PKG_DATA, 'pybullet_data'))
+    return paths
+
+
+class Model(Receptor):
+    def __init__(self, config, parent=None, env=None):
+        Receptor.__init__(self)
+        self.env = env if env is not None else getattr(parent, 'env', None)
+        if self.env is None:
+            raise ValueError('Model needs the environment it belongs to')
+        self.name = config.name
+        self.position = [float(v) for v in config.get('xyz', [0., 0., 0.])]
+        self.orientation = [float(v) for v in quat_from_euler(config.get('rpy', [0., 0., 0.]))]
+        use_fixed_base = config.get('use_fixed_base', False)
+        scale = config.get('scale', 1.0)
+        urdf = config.get('model')
+
+        full = None
+        for root in urdf_search_path():
+            cand = os.path.join(root, urdf)
+            if os.path.isfile(cand):
+                full = cand
+                break
+        if full is None:
+            raise ValueError('Could not find URDF: ' + urdf)  # reference model.py:63
+
+        if parent is not None:
+            raise NotImplementedError('child models (fixed constraints between bodies, reference model.py:69-77) '
+                                      'are not supported yet (SURVEY 8(f) N2)')
+
+        self.robot = UrdfRobot(full)
+        self.flat = FlatBody(self.robot, scale=scale, fixed_base=use_fixed_base,
+                             mass_override=config.get('mass') if 'mass' in config else None,
+                             mesh_loader=mesh.load_convex, max_hull_points=self.env.max_hull_points)
+        self.uid = self.env.builder.add_body(self.flat, self.position, self.orientation)
+        self.color = config.get('color') if 'color' in config else None  # visual only
+
+        self.addons = OrderedDict(
+            sorted(((child.name, AddonFactory.build(child.get('addon'), self, child)) for child in config.find_all('addon')),
+                   key=lambda kv: kv[0]))
+        children = list(config.find_all('model'))
+        if children:
+            raise NotImplementedError('child models (reference model.py:90-92) are not supported yet (SURVEY 8(f) N2)')
+        self.models = OrderedDict()
+
+    def get_frame_id(self, frame):
+        """Joint index of the named frame, -1 when absent (reference model.py:94-96)."""
+        return self.flat.frame_id(frame)
+
+    def get_transform(self, frame_id=-1):
+        """World pose of the URDF link frame (``getLinkState`` items 4, 5) or of the
+        base (reference model.py:98-106) for every env: ``(xyz [B,3], quat [B,4])``."""
+        st = self.env.sim.frame_state(self.uid, frame_id, com=frame_id < 0)
+        return st[:, 0:3], st[:, 3:7]

@@ -1,0 +1,379 @@
+"""Scene compiler: flattened bodies + addon ops -> the flat "scene blob".
+
+The blob layout is defined in ``include/diygym_scene.h``; the constants are read
+from that header at import time so Python and C cannot drift apart.  This is the
+host half of what the reference does through ``p.loadURDF`` /
+``p.setPhysicsEngineParameter`` / ``p.setGravity`` while constructing an
+environment (reference: diy_gym/diy_gym.py:74-91, diy_gym/model.py:53-83).
+"""
+import os
+import re
+
+import numpy as np
+
+from .mathx import Transform, quat_from_mat
+from .urdf import SHAPE_BOX, SHAPE_CAPSULE, SHAPE_POINTS, SHAPE_SPHERE
+
+_HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'include', 'diygym_scene.h')
+_HEADER_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'diygym_scene.h')
+
+
+def _parse_header(path):
+    """Evaluate the enums / #defines of diygym_scene.h into a dict."""
+    text = open(path).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    consts = {}
+    for m in re.finditer(r'#define\s+(DG_\w+)\s+(\S+)', text):
+        consts[m.group(1)] = int(m.group(2), 0)
+    for m in re.finditer(r'enum\s*\{(.*?)\}', text, flags=re.S):
+        value = -1
+        for item in m.group(1).split(','):
+            item = item.strip()
+            if not item:
+                continue
+            if '=' in item:
+                name, expr = (t.strip() for t in item.split('=', 1))
+                value = int(eval(expr, {}, consts))
+            else:
+                name, value = item, value + 1
+            consts[name] = value
+    return consts
+
+
+C = _parse_header(_HEADER if os.path.isfile(_HEADER) else _HEADER_PKG)
+
+
+class K:
+    """Namespace holding the DG_* constants without the prefix."""
+
+
+for _k, _v in C.items():
+    setattr(K, _k[3:], _v)
+
+# Solver / engine defaults.  Values tagged [R] are pybullet defaults restated from
+# recollection (DESIGN.md "Restated pybullet behaviours").
+DEFAULTS = dict(
+    residual_threshold=1e-7,  # [R] solverResidualThreshold
+    contact_erp=0.08,  # [R] m_erp2 set by pybullet's world setup
+    limit_erp=0.08,
+    linear_slop=1e-5,  # [R]
+    linear_damping=0.04,  # [R] btMultiBody default
+    angular_damping=0.04,  # [R]
+    max_coordinate_velocity=100.0,  # [R]
+    default_motor_impulse=1.0,  # [R] velocity motor created for every joint at load
+    ik_iterations=20,  # [R] maxNumIterations
+    ik_lambda_sq=0.36,  # [R] Jacobian::DefaultDampingLambda = 0.6, squared
+    ik_joint_damping=0.1,  # [R] jointDamping default
+    ik_residual=1e-4,  # [R] residualThreshold
+    ik_max_angle=np.radians(45.0),  # [R] MaxAngleDLS
+    ik_null_rest_gain=0.001,  # [R] stayCloseToZeroGain
+    ik_null_limit_gain=10.0,  # [R] stayAwayFromLimitsGain
+    contact_margin=0.02,  # [R] contact breaking threshold
+)
+
+
+def fit_capsule(points):
+    """Bounding capsule of a vertex cloud along its principal axis: (Transform, r, half_len)."""
+    pts = np.asarray(points, dtype=np.float64)
+    mean = pts.mean(axis=0)
+    cov = np.cov((pts - mean).T) if len(pts) > 2 else np.eye(3)
+    w, v = np.linalg.eigh(cov)
+    axis = v[:, np.argmax(w)]
+    if axis[np.argmax(np.abs(axis))] < 0:
+        axis = -axis
+    t = (pts - mean) @ axis
+    perp = (pts - mean) - np.outer(t, axis)
+    r = float(np.max(np.linalg.norm(perp, axis=1)))
+    tmin, tmax = float(t.min()), float(t.max())
+    half = max(0.5 * (tmax - tmin) - r, 0.0)
+    centre = mean + axis * 0.5 * (tmin + tmax)
+    # frame with z = axis
+    helper = np.array([1.0, 0.0, 0.0]) if abs(axis[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    x = np.cross(helper, axis)
+    x /= np.linalg.norm(x)
+    y = np.cross(axis, x)
+    R = np.stack([x, y, axis], axis=1)
+    return Transform(R, centre), max(r, 1e-4), half
+
+
+class OpHandle:
+    def __init__(self, index, kind, io_off, io_dim, state_off, slot):
+        self.index = index
+        self.kind = kind
+        self.io_off = io_off
+        self.io_dim = io_dim
+        self.state_off = state_off
+        self.slot = slot
+
+
+class SceneBuilder:
+    def __init__(self, timestep=1.0 / 240.0, substeps=2, solver_iterations=150, gravity=(0.0, 0.0, -9.81),
+                 max_episode_steps=None, hot_start=1, rew_mode=0, term_mode=0, **overrides):
+        self.timestep = float(timestep)
+        self.substeps = max(int(substeps), 1)
+        self.solver_iterations = int(solver_iterations)
+        self.gravity = [float(g) for g in gravity]
+        self.max_episode_steps = -1 if max_episode_steps is None else int(max_episode_steps)
+        self.hot_start = int(hot_start)
+        self.rew_mode = rew_mode
+        self.term_mode = term_mode
+        self.params = dict(DEFAULTS)
+        for k, v in overrides.items():
+            if k not in self.params:
+                raise KeyError('unknown engine parameter: ' + k)
+            self.params[k] = v
+        self.bodies = []  # (FlatBody, pos, quat)
+        self.ops = []
+        self.ilist = []
+        self.flist = []
+        self.dims = {'act': 0, 'obs': 0, 'rew': 0, 'term': 0}
+        self.addon_state = 0
+        self.n_slots = 0
+        self.term_groups = []
+
+    # -- bodies ---------------------------------------------------------
+    def add_body(self, flat, pos, quat):
+        """``pos``/``quat``: pose of the root inertial frame, as passed to
+        ``p.resetBasePositionAndOrientation`` (reference model.py:68)."""
+        q_link = quat_from_mat(Transform.from_xyz_quat([0, 0, 0], quat).R @ flat.T_base_report.R.T)
+        T_link = Transform.from_xyz_quat([0, 0, 0], q_link)
+        p_link = np.asarray(pos, dtype=np.float64) - T_link.R @ flat.T_base_report.p
+        self.bodies.append((flat, p_link, q_link))
+        return len(self.bodies) - 1
+
+    def link_base(self, body):
+        return sum(len(b[0].links) for b in self.bodies[:body])
+
+    def frame_base(self, body):
+        return sum(len(b[0].frames) for b in self.bodies[:body])
+
+    def global_link(self, body, dof):
+        return self.link_base(body) + dof
+
+    def global_frame(self, body, frame_id):
+        return -1 if frame_id < 0 else self.frame_base(body) + frame_id
+
+    # -- ops --------------------------------------------------------------
+    def add_op(self, code, kind, body=-1, frame=-1, body2=-1, frame2=-1, flags=0, ilist=(), flist=(), fparams=(),
+               io_dim=0, state_dim=0, group=None, n=None):
+        """``kind`` in act|obs|rew|term|reset.  Returns an :class:`OpHandle`."""
+        io_off = 0
+        if kind in self.dims:
+            io_off = self.dims[kind]
+            self.dims[kind] += io_dim
+        state_off = self.addon_state
+        self.addon_state += state_dim
+        slot = 0
+        if kind == 'act':
+            slot = self.n_slots
+            self.n_slots += 1
+            if self.n_slots > 64:
+                raise ValueError('more than 64 controller addons in one environment')
+        if kind == 'term':
+            if group not in self.term_groups:
+                self.term_groups.append(group)
+            slot = self.term_groups.index(group)
+        ioff, foff = len(self.ilist), len(self.flist)
+        self.ilist.extend(int(v) for v in ilist)
+        self.flist.extend(float(v) for v in flist)
+        fp = [float(v) for v in fparams]
+        if len(fp) > K.OF_STRIDE:
+            raise ValueError('too many float parameters for one op')
+        fp = fp + [0.0] * (K.OF_STRIDE - len(fp))
+        row = [0] * K.OI_STRIDE
+        row[K.OI_CODE] = code
+        row[K.OI_BODY] = body
+        row[K.OI_FRAME] = self.global_frame(body, frame) if body >= 0 else -1
+        row[K.OI_BODY2] = body2
+        row[K.OI_FRAME2] = self.global_frame(body2, frame2) if body2 >= 0 else -1
+        row[K.OI_FLAGS] = flags
+        row[K.OI_N] = len(ilist) if n is None else int(n)
+        row[K.OI_ILIST] = ioff
+        row[K.OI_FLIST] = foff
+        row[K.OI_IO_OFF] = io_off
+        row[K.OI_STATE_OFF] = state_off
+        row[K.OI_SLOT] = slot
+        self.ops.append((row, fp))
+        return OpHandle(len(self.ops) - 1, kind, io_off, io_dim, state_off, slot)
+
+    # -- emit -----------------------------------------------------------
+    def finalize(self):
+        nb = len(self.bodies)
+        body_i, body_f, link_i, link_f, frame_i, frame_f = [], [], [], [], [], []
+        shape_i, shape_f, points = [], [], []
+        shape_dyn = []
+        state_off = K.ST_PREFIX
+        link_state_offs = []
+        gl = 0
+        for b, (flat, p_link, q_link) in enumerate(self.bodies):
+            first = gl
+            flags = K.BODY_FIXED if flat.fixed_base else 0
+            body_i.append([flags, first, len(flat.links), state_off])
+            state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
+            I = flat.base_inertia
+            rep_q = quat_from_mat(flat.T_base_report.R)
+            body_f.append([flat.base_mass, *flat.base_com, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2], *p_link,
+                           *q_link, *flat.T_base_report.p, *rep_q])
+            for i, fl in enumerate(flat.links):
+                parent = -1 if fl.parent < 0 else first + fl.parent
+                link_i.append([parent, fl.joint_type, b, state_off])
+                link_state_offs.append(state_off)
+                state_off += K.LS_STRIDE
+                I = fl.inertia
+                row = [*fl.origin.p, *fl.origin.R.reshape(-1), *fl.axis, fl.mass, *fl.com, I[0, 0], I[0, 1], I[0, 2],
+                       I[1, 1], I[1, 2], I[2, 2], fl.damping, fl.lower, fl.upper, fl.max_force, fl.max_velocity]
+                link_f.append(row + [0.0] * (K.LF_STRIDE - len(row)))
+                gl += 1
+            for fr in flat.frames:
+                frame_i.append([b, -1 if fr.link < 0 else first + fr.link])
+                frame_f.append([*fr.T.p, *fr.T.quat, *fr.T_com.p, *fr.T_com.quat])
+            dynamic = not (flat.fixed_base and len(flat.links) == 0)
+            for sh in flat.shapes:
+                T, prm, poff, npts = sh.T, np.zeros(3), 0, 0
+                if sh.kind == SHAPE_SPHERE:
+                    prm[0] = sh.params[0]
+                elif sh.kind == SHAPE_BOX:
+                    prm[:] = sh.params
+                elif sh.kind == SHAPE_CAPSULE:
+                    prm[:2] = sh.params
+                elif sh.kind == SHAPE_POINTS:
+                    T, r, half = fit_capsule(sh.points)
+                    prm[:2] = (r, half)
+                    poff, npts = len(points), len(sh.points)
+                    points.extend(sh.points.tolist())
+                shape_i.append([sh.kind, b, -1 if sh.link < 0 else first + sh.link, poff, npts])
+                shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction])
+                shape_dyn.append(dynamic)
+        addon_off = state_off
+        state_dim = state_off + self.addon_state
+
+        # candidate collision pairs: different bodies, at least one of them able to move,
+        # and a narrow-phase routine exists for the pair (no box-box)
+        pairs, max_contacts = [], 0
+        for a in range(len(shape_i)):
+            for c in range(a + 1, len(shape_i)):
+                if shape_i[a][1] == shape_i[c][1] or not (shape_dyn[a] or shape_dyn[c]):
+                    continue
+                ta, tc = shape_i[a][0], shape_i[c][0]
+                if ta == SHAPE_BOX and tc == SHAPE_BOX:
+                    continue
+                pairs.append([a, c])
+                kinds = {ta, tc}
+                if kinds == {SHAPE_POINTS, SHAPE_BOX}:
+                    max_contacts += 4
+                elif kinds == {SHAPE_CAPSULE, SHAPE_BOX}:
+                    max_contacts += 2
+                else:
+                    max_contacts += 1
+        max_contacts = min(max_contacts, 32)
+
+        def arr(rows, width, dtype):
+            if not rows:
+                return np.zeros((0, width), dtype=dtype)
+            return np.asarray(rows, dtype=dtype).reshape(len(rows), width)
+
+        tables_i = [
+            ('OFF_BODY_I', arr(body_i, K.BI_STRIDE, np.int32)),
+            ('OFF_LINK_I', arr(link_i, K.LI_STRIDE, np.int32)),
+            ('OFF_FRAME_I', arr(frame_i, K.FI_STRIDE, np.int32)),
+            ('OFF_SHAPE_I', arr(shape_i, K.SI_STRIDE, np.int32)),
+            ('OFF_PAIR_I', arr(pairs, K.PI_STRIDE, np.int32)),
+            ('OFF_OP_I', arr([o[0] for o in self.ops], K.OI_STRIDE, np.int32)),
+            ('OFF_ILIST', np.asarray(self.ilist, dtype=np.int32).reshape(-1, 1)),
+        ]
+        tables_f = [
+            ('OFF_BODY_F', arr(body_f, K.BF_STRIDE, np.float64)),
+            ('OFF_LINK_F', arr(link_f, K.LF_STRIDE, np.float64)),
+            ('OFF_FRAME_F', arr(frame_f, K.FF_STRIDE, np.float64)),
+            ('OFF_SHAPE_F', arr(shape_f, K.SF_STRIDE, np.float64)),
+            ('OFF_POINT_F', arr(points, 3, np.float64)),
+            ('OFF_OP_F', arr([o[1] for o in self.ops], K.OF_STRIDE, np.float64)),
+            ('OFF_FLIST', np.asarray(self.flist, dtype=np.float64).reshape(-1, 1)),
+        ]
+        H = np.zeros(K.H_INT_COUNT, dtype=np.int32)
+        H[K.H_MAGIC] = K.MAGIC
+        H[K.H_VERSION] = K.VERSION
+        H[K.H_N_BODIES] = nb
+        H[K.H_N_LINKS] = len(link_i)
+        H[K.H_N_FRAMES] = len(frame_i)
+        H[K.H_N_SHAPES] = len(shape_i)
+        H[K.H_N_POINTS] = len(points)
+        H[K.H_N_PAIRS] = len(pairs)
+        H[K.H_N_OPS] = len(self.ops)
+        H[K.H_N_ILIST] = len(self.ilist)
+        H[K.H_N_FLIST] = len(self.flist)
+        H[K.H_ACT_DIM] = self.dims['act']
+        H[K.H_OBS_DIM] = self.dims['obs']
+        H[K.H_REW_DIM] = self.dims['rew']
+        H[K.H_TERM_DIM] = self.dims['term']
+        H[K.H_SUBSTEPS] = self.substeps
+        H[K.H_SOLVER_ITERS] = self.solver_iterations
+        H[K.H_MAX_EPISODE_STEPS] = self.max_episode_steps
+        H[K.H_HOT_START] = self.hot_start
+        H[K.H_IK_ITERS] = int(self.params['ik_iterations'])
+        H[K.H_STATE_DIM] = state_dim
+        H[K.H_ADDON_STATE_OFF] = addon_off
+        H[K.H_N_ADDON_STATE] = self.addon_state
+        H[K.H_MAX_CONTACTS] = max_contacts
+        H[K.H_REW_MODE] = self.rew_mode
+        H[K.H_TERM_MODE] = self.term_mode
+        H[K.H_N_TERM_GROUPS] = len(self.term_groups)
+        off = K.H_INT_COUNT
+        chunks_i = [H]
+        for name, t in tables_i:
+            H[getattr(K, 'H_' + name)] = off
+            chunks_i.append(t.reshape(-1))
+            off += t.size
+        HF = np.zeros(K.HF_FLOAT_COUNT, dtype=np.float64)
+        p = self.params
+        HF[K.HF_DT] = self.timestep / self.substeps
+        HF[K.HF_GRAV_X:K.HF_GRAV_X + 3] = self.gravity
+        HF[K.HF_RESIDUAL_THRESHOLD] = p['residual_threshold']
+        HF[K.HF_CONTACT_ERP] = p['contact_erp']
+        HF[K.HF_LIMIT_ERP] = p['limit_erp']
+        HF[K.HF_LINEAR_SLOP] = p['linear_slop']
+        HF[K.HF_LIN_DAMPING] = p['linear_damping']
+        HF[K.HF_ANG_DAMPING] = p['angular_damping']
+        HF[K.HF_MAX_COORD_VEL] = p['max_coordinate_velocity']
+        HF[K.HF_DEFAULT_MOTOR_IMPULSE] = p['default_motor_impulse']
+        HF[K.HF_IK_LAMBDA_SQ] = p['ik_lambda_sq']
+        HF[K.HF_IK_JOINT_DAMPING] = p['ik_joint_damping']
+        HF[K.HF_IK_RESIDUAL] = p['ik_residual']
+        HF[K.HF_IK_MAX_ANGLE] = p['ik_max_angle']
+        HF[K.HF_IK_NULL_REST_GAIN] = p['ik_null_rest_gain']
+        HF[K.HF_IK_NULL_LIMIT_GAIN] = p['ik_null_limit_gain']
+        HF[K.HF_CONTACT_MARGIN] = p['contact_margin']
+        off = K.HF_FLOAT_COUNT
+        chunks_f = [HF]
+        for name, t in tables_f:
+            H[getattr(K, 'H_' + name)] = off
+            chunks_f.append(t.reshape(-1))
+            off += t.size
+        I = np.ascontiguousarray(np.concatenate(chunks_i).astype(np.int32))
+        F = np.ascontiguousarray(np.concatenate(chunks_f).astype(np.float64))
+        layout = SceneLayout(self, I, F, body_i, link_state_offs, addon_off, state_dim, max_contacts)
+        return layout
+
+
+class SceneLayout:
+    """The finished blob plus the host-side offsets addons need for state access."""
+    def __init__(self, builder, I, F, body_i, link_state_offs, addon_off, state_dim, max_contacts):
+        self.I = I
+        self.F = F
+        self.body_state_off = [r[3] for r in body_i]
+        self.body_fixed = [bool(r[0] & K.BODY_FIXED) for r in body_i]
+        self.body_first_link = [r[1] for r in body_i]
+        self.body_n_links = [r[2] for r in body_i]
+        self.link_state_off = link_state_offs
+        self.addon_off = addon_off
+        self.state_dim = state_dim
+        self.max_contacts = max_contacts
+        self.act_dim = builder.dims['act']
+        self.obs_dim = builder.dims['obs']
+        self.rew_dim = builder.dims['rew']
+        self.term_dim = builder.dims['term']
+        self.n_links = len(link_state_offs)
+        self.n_bodies = len(body_i)
+        self.n_slots = builder.n_slots
+        self.substeps = builder.substeps
+        self.dt = builder.timestep / builder.substeps

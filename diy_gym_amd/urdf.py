@@ -1,0 +1,397 @@
+"""URDF reader and multibody flattener.
+
+Replaces ``p.loadURDF`` + ``p.getNumJoints`` / ``p.getJointInfo`` for this
+backend (reference call sites: diy_gym/model.py:65, :94-96;
+joint_controller.py:21-33; joint_state_sensor.py:29-43).  Parsing uses
+``xml.etree`` only.
+
+Conventions that are restated from pybullet/Bullet **from recollection** (the
+wheel is not available to check; see DESIGN.md "Restated pybullet behaviours"):
+
+* joint indices follow a depth-first walk from the root link, children in file
+  order, fixed joints included; link index ``i`` is the child link of joint ``i``;
+* a link without ``<inertial>`` gets mass 1 and unit inertia, except a link
+  named ``world`` which gets mass 0 (that is what makes a ``world`` root link a
+  fixed base: ur5_robot.urdf:315-320);
+* ``q_index`` (``getJointInfo()[3]``) is -1 for fixed joints;
+* ``maxForce`` / ``maxVelocity`` come from ``<limit effort= velocity=>`` and are
+  0 when the tag is absent; ``continuous`` joints are revolute without limits.
+
+Flattening merges every fixed-joint subtree into the moving link (or base) it
+is rigidly attached to -- inertias are lumped exactly, named frames keep their
+offsets -- so the device kernels only see 1-DoF joints.
+"""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from .mathx import Transform, mat_from_euler, quat_from_mat
+
+JOINT_REVOLUTE = 0
+JOINT_PRISMATIC = 1
+JOINT_FIXED = 4  # pybullet's numeric value; only used for reporting
+
+SHAPE_SPHERE = 0
+SHAPE_BOX = 1
+SHAPE_CAPSULE = 2
+SHAPE_POINTS = 3  # convex vertex cloud
+
+
+def _floats(text, n=None, default=None):
+    if text is None:
+        return None if default is None else np.array(default, dtype=np.float64)
+    vals = np.array([float(t) for t in text.replace(',', ' ').split()], dtype=np.float64)
+    if n is not None and vals.size != n:
+        raise ValueError('expected %d numbers, got %r' % (n, text))
+    return vals
+
+
+def _origin(elem):
+    if elem is None:
+        return Transform()
+    o = elem.find('origin')
+    if o is None:
+        return Transform()
+    return Transform.from_xyz_rpy(_floats(o.get('xyz'), 3, [0, 0, 0]), _floats(o.get('rpy'), 3, [0, 0, 0]))
+
+
+class UrdfShape:
+    def __init__(self, kind, origin, size=None, radius=0.0, length=0.0, mesh=None, mesh_scale=None):
+        self.kind = kind  # 'sphere' | 'box' | 'cylinder' | 'capsule' | 'mesh' | 'plane'
+        self.origin = origin
+        self.size = size
+        self.radius = radius
+        self.length = length
+        self.mesh = mesh
+        self.mesh_scale = mesh_scale
+
+
+class UrdfLink:
+    def __init__(self, name):
+        self.name = name
+        self.mass = 0.0
+        self.inertial_origin = Transform()
+        self.inertia = np.zeros((3, 3))
+        self.has_inertial = False
+        self.collisions = []
+        self.lateral_friction = None
+        self.child_joints = []
+        self.parent_joint = None
+
+
+class UrdfJoint:
+    def __init__(self, name, jtype):
+        self.name = name
+        self.type = jtype
+        self.parent = None
+        self.child = None
+        self.origin = Transform()
+        self.axis = np.array([1.0, 0.0, 0.0])
+        self.lower = 0.0
+        self.upper = -1.0  # lower > upper == "no limit", like Bullet
+        self.effort = 0.0
+        self.velocity = 0.0
+        self.damping = 0.0
+        self.friction = 0.0
+        self.index = -1
+        self.q_index = -1
+
+    @property
+    def movable(self):
+        return self.type in ('revolute', 'continuous', 'prismatic')
+
+
+def _parse_geometry(geom, origin):
+    if geom is None:
+        return None
+    for child in geom:
+        tag = child.tag
+        if tag == 'sphere':
+            return UrdfShape('sphere', origin, radius=float(child.get('radius')))
+        if tag == 'box':
+            return UrdfShape('box', origin, size=_floats(child.get('size'), 3))
+        if tag == 'cylinder':
+            return UrdfShape('cylinder', origin, radius=float(child.get('radius')), length=float(child.get('length')))
+        if tag == 'capsule':
+            return UrdfShape('capsule', origin, radius=float(child.get('radius')), length=float(child.get('length')))
+        if tag == 'mesh':
+            return UrdfShape('mesh', origin, mesh=child.get('filename'),
+                             mesh_scale=_floats(child.get('scale'), 3, [1, 1, 1]))
+        if tag == 'plane':
+            return UrdfShape('plane', origin, size=_floats(child.get('normal'), 3, [0, 0, 1]))
+    return None
+
+
+class UrdfRobot:
+    """Parsed URDF with pybullet-style joint numbering."""
+    def __init__(self, path):
+        self.path = path
+        self.dir = os.path.dirname(os.path.abspath(path))
+        root = ET.parse(path).getroot()
+        self.name = root.get('name', os.path.basename(path))
+        self.links = {}
+        self.link_order = []
+        for le in root.findall('link'):
+            link = UrdfLink(le.get('name'))
+            inertial = le.find('inertial')
+            if inertial is not None:
+                link.has_inertial = True
+                link.inertial_origin = _origin(inertial)
+                m = inertial.find('mass')
+                link.mass = float(m.get('value')) if m is not None else 0.0
+                ie = inertial.find('inertia')
+                if ie is not None:
+                    g = lambda k: float(ie.get(k, 0.0))
+                    link.inertia = np.array([[g('ixx'), g('ixy'), g('ixz')], [g('ixy'), g('iyy'), g('iyz')],
+                                             [g('ixz'), g('iyz'), g('izz')]])
+            elif link.name == 'world':
+                link.mass = 0.0
+            else:
+                # Bullet's URDF importer: "No inertial data for link, using mass=1,
+                # localinertiadiagonal = 1,1,1, identity local inertial frame" [RECOLLECTION]
+                link.mass = 1.0
+                link.inertia = np.eye(3)
+            for ce in le.findall('collision'):
+                shape = _parse_geometry(ce.find('geometry'), _origin(ce))
+                if shape is not None:
+                    link.collisions.append(shape)
+            contact = le.find('contact')
+            if contact is not None:
+                lf = contact.find('lateral_friction')
+                if lf is not None:
+                    link.lateral_friction = float(lf.get('value'))
+            self.links[link.name] = link
+            self.link_order.append(link.name)
+
+        self.joints_by_name = {}
+        file_joints = []
+        for je in root.findall('joint'):
+            j = UrdfJoint(je.get('name'), je.get('type'))
+            j.parent = je.find('parent').get('link')
+            j.child = je.find('child').get('link')
+            j.origin = _origin(je)
+            ax = je.find('axis')
+            if ax is not None:
+                a = _floats(ax.get('xyz'), 3)
+                n = np.linalg.norm(a)
+                j.axis = a / n if n > 0 else a
+            lim = je.find('limit')
+            if lim is not None:
+                j.effort = float(lim.get('effort', 0.0))
+                j.velocity = float(lim.get('velocity', 0.0))
+                if j.type != 'continuous':
+                    j.lower = float(lim.get('lower', 0.0))
+                    j.upper = float(lim.get('upper', 0.0))
+            dyn = je.find('dynamics')
+            if dyn is not None:
+                j.damping = float(dyn.get('damping', 0.0))
+                j.friction = float(dyn.get('friction', 0.0))
+            if j.type not in ('revolute', 'continuous', 'prismatic', 'fixed'):
+                raise ValueError('joint %s: type %r is not supported by this backend' % (j.name, j.type))
+            file_joints.append(j)
+            self.joints_by_name[j.name] = j
+            self.links[j.parent].child_joints.append(j)
+            self.links[j.child].parent_joint = j
+
+        roots = [n for n in self.link_order if self.links[n].parent_joint is None]
+        if len(roots) != 1:
+            raise ValueError('%s: expected exactly one root link, found %r' % (path, roots))
+        self.root = roots[0]
+
+        # depth-first numbering, children in file order
+        self.joints = []
+        stack = list(reversed(self.links[self.root].child_joints))
+        q = 0
+        while stack:
+            j = stack.pop()
+            j.index = len(self.joints)
+            if j.movable:
+                j.q_index = q
+                q += 1
+            self.joints.append(j)
+            stack.extend(reversed(self.links[j.child].child_joints))
+        self.num_dofs = q
+
+    @property
+    def joint_names(self):
+        return [j.name for j in self.joints]
+
+    def joint_info(self, i):
+        """Subset of ``p.getJointInfo`` fields that the reference reads."""
+        j = self.joints[i]
+        return {
+            'index': j.index,
+            'name': j.name,
+            'type': {'revolute': JOINT_REVOLUTE, 'continuous': JOINT_REVOLUTE, 'prismatic': JOINT_PRISMATIC}.get(
+                j.type, JOINT_FIXED),
+            'q_index': j.q_index,
+            'damping': j.damping,
+            'friction': j.friction,
+            'lower': j.lower,
+            'upper': j.upper,
+            'max_force': j.effort,
+            'max_velocity': j.velocity,
+            'link_name': j.child,
+        }
+
+
+class FlatLink:
+    """One moving (1-DoF) link after fixed-joint merging."""
+    def __init__(self):
+        self.parent = -1  # index of parent moving link, -1 = base
+        self.joint_type = JOINT_REVOLUTE
+        self.joint_index = -1  # pybullet joint index that moves this link
+        self.name = ''
+        self.origin = Transform()  # joint frame (q = 0) in the parent's reference frame
+        self.axis = np.array([0.0, 0.0, 1.0])
+        self.mass = 0.0
+        self.com = np.zeros(3)
+        self.inertia = np.zeros((3, 3))  # about the COM, link axes
+        self.damping = 0.0
+        self.lower = 0.0
+        self.upper = -1.0
+        self.max_force = 0.0
+        self.max_velocity = 0.0
+
+
+class FlatFrame:
+    """A named frame rigidly attached to a moving link (or the base)."""
+    def __init__(self, name, link, T_link_frame, T_link_com):
+        self.name = name
+        self.link = link  # moving link index, -1 = base
+        self.T = T_link_frame  # URDF link frame (getLinkState items 4, 5)
+        self.T_com = T_link_com  # inertial frame (getLinkState items 0, 1)
+
+
+class FlatShape:
+    def __init__(self, kind, link, T, params, points=None, friction=1.0):
+        self.kind = kind
+        self.link = link
+        self.T = T  # shape frame in the link's reference frame
+        self.params = params  # sphere: [r]; box: half extents; capsule: [r, half_len]
+        self.points = points  # SHAPE_POINTS: [n,3] in link reference frame
+        self.friction = friction
+
+
+class FlatBody:
+    """A URDF flattened into base + 1-DoF links + frames + collision shapes."""
+    def __init__(self, robot, scale=1.0, fixed_base=False, mass_override=None, mesh_loader=None,
+                 max_hull_points=32):
+        self.robot = robot
+        self.scale = float(scale)
+        s = self.scale
+        links = robot.links
+        root = links[robot.root]
+
+        root_mass = root.mass
+        root_inertia = root.inertia.copy()
+        if mass_override is not None:
+            # p.changeDynamics(uid, -1, mass=...) touches the root link only (reference
+            # model.py:79-80); inertia is rescaled by the mass ratio [decision, DESIGN.md].
+            ratio = (float(mass_override) / root_mass) if root_mass > 0 else 1.0
+            root_mass = float(mass_override)
+            root_inertia = root_inertia * ratio
+        self.fixed_base = bool(fixed_base) or root_mass == 0.0
+
+        self.links = []
+        self.frames = []  # index == pybullet joint/link index
+        self.shapes = []
+        # accumulators: link index (-1 base) -> [m, h(3), I_O(3x3)]
+        acc = {-1: [0.0, np.zeros(3), np.zeros((3, 3))]}
+
+        def add_inertia(anchor, T_anchor_link, link, mass, inertia):
+            if mass <= 0.0:
+                return
+            Tc = T_anchor_link * Transform(link.inertial_origin.R, link.inertial_origin.p * s)
+            c = Tc.p
+            Ic = Tc.R @ (inertia * (s * s)) @ Tc.R.T
+            a = acc[anchor]
+            a[0] += mass
+            a[1] += mass * c
+            a[2] += Ic + mass * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+
+        def add_shapes(anchor, T_anchor_link, link):
+            mu = link.lateral_friction if link.lateral_friction is not None else 0.5
+            for sh in link.collisions:
+                T = T_anchor_link * Transform(sh.origin.R, sh.origin.p * s)
+                if sh.kind == 'sphere':
+                    self.shapes.append(FlatShape(SHAPE_SPHERE, anchor, T, np.array([sh.radius * s]), friction=mu))
+                elif sh.kind == 'box':
+                    self.shapes.append(FlatShape(SHAPE_BOX, anchor, T, 0.5 * sh.size * s, friction=mu))
+                elif sh.kind in ('capsule', 'cylinder'):
+                    # cylinders are approximated by the inscribed capsule of the same radius
+                    # (documented deviation; Bullet uses a true cylinder)
+                    half = max(0.5 * sh.length * s - (sh.radius * s if sh.kind == 'cylinder' else 0.0), 0.0)
+                    self.shapes.append(
+                        FlatShape(SHAPE_CAPSULE, anchor, T, np.array([sh.radius * s, half]), friction=mu))
+                elif sh.kind == 'mesh':
+                    if mesh_loader is None:
+                        continue
+                    pts = mesh_loader(os.path.join(robot.dir, sh.mesh), max_hull_points)
+                    if pts is None or len(pts) == 0:
+                        continue
+                    pts = (pts * sh.mesh_scale[None, :] * s) @ T.R.T + T.p
+                    self.shapes.append(FlatShape(SHAPE_POINTS, anchor, Transform(), np.zeros(3), points=pts, friction=mu))
+
+        # root
+        self.base_name = root.name
+        self.T_base_report = Transform(root.inertial_origin.R, root.inertial_origin.p * s)  # root inertial frame
+        add_inertia(-1, Transform(), root, root_mass, root_inertia)
+        add_shapes(-1, Transform(), root)
+        anchor_of = {robot.root: (-1, Transform())}
+
+        for j in robot.joints:  # DFS order guarantees the parent was visited
+            p_anchor, T_anchor_parent = anchor_of[j.parent]
+            child = links[j.child]
+            T_joint = T_anchor_parent * Transform(j.origin.R, j.origin.p * s)
+            if j.movable:
+                fl = FlatLink()
+                fl.parent = p_anchor
+                fl.joint_type = JOINT_PRISMATIC if j.type == 'prismatic' else JOINT_REVOLUTE
+                fl.joint_index = j.index
+                fl.name = j.name
+                fl.origin = T_joint
+                fl.axis = j.axis.copy()
+                fl.damping = j.damping
+                fl.lower, fl.upper = (j.lower * s, j.upper * s) if j.type == 'prismatic' else (j.lower, j.upper)
+                fl.max_force = j.effort
+                fl.max_velocity = j.velocity
+                idx = len(self.links)
+                self.links.append(fl)
+                acc[idx] = [0.0, np.zeros(3), np.zeros((3, 3))]
+                anchor, T_anchor_child = idx, Transform()
+            else:
+                anchor, T_anchor_child = p_anchor, T_joint
+            anchor_of[j.child] = (anchor, T_anchor_child)
+            add_inertia(anchor, T_anchor_child, child, child.mass, child.inertia)
+            add_shapes(anchor, T_anchor_child, child)
+            T_com = T_anchor_child * Transform(child.inertial_origin.R, child.inertial_origin.p * s)
+            self.frames.append(FlatFrame(j.name, anchor, T_anchor_child, T_com))
+
+        def finish(a):
+            m, h, IO = a
+            if m <= 0.0:
+                return 0.0, np.zeros(3), np.zeros((3, 3))
+            c = h / m
+            Ic = IO - m * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+            return m, c, 0.5 * (Ic + Ic.T)
+
+        self.base_mass, self.base_com, self.base_inertia = finish(acc[-1])
+        for i, fl in enumerate(self.links):
+            fl.mass, fl.com, fl.inertia = finish(acc[i])
+            if fl.mass <= 0.0:
+                raise ValueError('moving link %s has zero mass' % fl.name)
+        if self.fixed_base:
+            self.base_mass = 0.0
+
+        self.joint_to_dof = [j.q_index for j in robot.joints]
+        self.dof_to_joint = [fl.joint_index for fl in self.links]
+
+    @property
+    def num_dofs(self):
+        return len(self.links)
+
+    def frame_id(self, name):
+        names = self.robot.joint_names
+        return names.index(name) if name in names else -1

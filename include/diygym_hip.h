@@ -1,0 +1,103 @@
+/* diygym_hip.h -- C-ABI of the MI355X batched simulation backend.
+ *
+ * This is the boundary that replaces the `pybullet` module API on DIYGym's
+ * step path.  The reference is Python and binds pybullet through its CPython
+ * extension; the calls it makes are enumerated in SURVEY.md 8(b).  Each entry
+ * point below names the reference call sites it replaces.  All buffer
+ * arguments are DEVICE pointers owned by the caller (torch tensors'
+ * data_ptr()); `stream` is a hipStream_t (NULL = default stream).  No entry
+ * point allocates, frees or synchronises after dg_world_create, so every call
+ * can be captured into a hipGraph.  Return value: 0 on success, a negative
+ * DG_ERR_* otherwise, with dg_last_error() giving the message.  One world per
+ * GPU, one host thread per world (same rule as a pybullet client).
+ *
+ * Batched buffers:
+ *   state    float [state_dim][env_stride]  struct-of-arrays over envs (coalesced)
+ *   actions  float [num_envs][act_dim]      row per env, columns in the order of
+ *                                           flatten(action_space) (reference utils.py:46-60)
+ *   obs      float [num_envs][obs_dim]      ... of flatten(observe())
+ *   rew      float [num_envs][rew_dim]      one column per reward addon
+ *   term     uint8 [num_envs][term_dim]     one column per terminal addon
+ *   rew_sum  float [num_envs]               collapsed reward  (sum_rewards, diy_gym.py:94,168)
+ *   term_flag uint8 [num_envs]              collapsed terminal (terminal_if_any/all, diy_gym.py:95-96,185)
+ */
+#ifndef DIYGYM_HIP_H
+#define DIYGYM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_OK 0
+#define DG_ERR_BAD_SCENE (-1)
+#define DG_ERR_HIP (-2)
+#define DG_ERR_UNSUPPORTED (-3)
+#define DG_ERR_ARG (-4)
+
+typedef struct dg_world dg_world;
+
+/* library identification: (major << 16) | minor */
+int32_t dg_version(void);
+const char* dg_last_error(void);
+
+/* Replaces p.connect / p.resetSimulation / p.setPhysicsEngineParameter /
+ * p.setGravity / p.loadURDF / p.changeDynamics (reference diy_gym.py:68-82,
+ * model.py:65-83): builds the device-side constant tables for `num_envs`
+ * copies of the scene blob (include/diygym_scene.h) on HIP device `device`.
+ * `env_stride` (>= num_envs, multiple of 64) is the row pitch of `state`.
+ * `seed` and `env_index_base` key the per-env respawn RNG streams. */
+int32_t dg_world_create(const int32_t* idata, int64_t n_i, const double* fdata, int64_t n_f, int32_t num_envs,
+                        int32_t env_stride, int32_t device, uint64_t seed, int64_t env_index_base, dg_world** out);
+
+/* Replaces p.disconnect (reference diy_gym.py:225). */
+void dg_world_destroy(dg_world* w);
+
+/* dims[0..7] = state_dim, act_dim, obs_dim, rew_dim, term_dim, n_links,
+ * lds_bytes_per_workgroup, envs_per_wavefront */
+int32_t dg_world_dims(const dg_world* w, int32_t dims[8]);
+
+/* Host-side view of the motor table (p.setJointMotorControlArray gains/forces,
+ * uniform over envs): cfg[n_links][3] = kp, kd, max_force (<0: raw impulse). */
+int32_t dg_world_get_motor_cfg(const dg_world* w, double* cfg);
+int32_t dg_world_set_motor_cfg(dg_world* w, const double* cfg);
+
+/* Writes the load-time state (model poses from the config, joints at zero)
+ * into `state` for every env.  Replaces the p.resetBasePositionAndOrientation
+ * done while models are constructed (reference model.py:68). */
+int32_t dg_world_init_state(dg_world* w, float* state, void* stream);
+
+/* Replaces DIYGym.reset()'s addon.reset() + hot_start x p.stepSimulation +
+ * observe (reference diy_gym.py:130-148; respawn.py:31-35,
+ * joint_controller.py:36-38) for the envs whose `mask` byte is non-zero
+ * (mask == NULL: all envs).  obs (nullable) is written for every env. */
+int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream);
+
+/* Replaces one DIYGym.step(): addon.update() for the controller addons whose
+ * bit is set in `update_mask` (p.setJointMotorControlArray,
+ * p.calculateInverseKinematics, p.applyExternalForce/Torque), step_counter += 1,
+ * p.stepSimulation, then observe / reward / is_terminal (p.getJointStates,
+ * p.getLinkState, p.getBasePositionAndOrientation, p.getBaseVelocity)
+ * (reference diy_gym.py:187-209).  Any output pointer may be NULL. */
+int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t update_mask, float* obs, float* rew,
+                      uint8_t* term, float* rew_sum, uint8_t* term_flag, void* stream);
+
+/* Outputs for the current state without stepping (reference diy_gym.py:150-185). */
+int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew, uint8_t* term, float* rew_sum,
+                         uint8_t* term_flag, void* stream);
+
+/* Debug getter replacing p.getLinkState / p.getBasePositionAndOrientation /
+ * p.getBaseVelocity: out[num_envs][13] = pos3 quat4 linvel3 angvel3 of `frame`
+ * (pybullet joint index, -1 = base) of body `body`; com != 0 selects the
+ * inertial frame (items 0,1,6,7), else the URDF link frame (items 4,5). */
+int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int32_t frame, int32_t com, float* out,
+                             void* stream);
+
+/* Per-env diagnostics of the last step: diag[num_envs][2] = contact count,
+ * solver iterations of the final substep (int32).  Optional; pass NULL to
+ * disable (default).  The buffer must stay valid until changed. */
+int32_t dg_world_set_diag_buffer(dg_world* w, int32_t* diag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,207 @@
+/* diygym_scene.h -- flat scene description ("scene blob") shared by every
+ * implementation of the DIYGym batched step path.
+ *
+ * This header defines a DATA FORMAT only: two arrays, `int32_t I[]` and
+ * `double F[]`, that describe one environment (bodies, 1-DoF links, named
+ * frames, collision shapes, the addon program and solver parameters).  The
+ * host (diy_gym_amd/scene.py) emits it from the YAML config + URDF files; the
+ * HIP library (diy_gym_amd/csrc) and the CPU oracle (oracle/) both consume it.
+ * It is the batched replacement for the sequence of pybullet "model" calls the
+ * reference issues while constructing an environment (reference:
+ * diy_gym/diy_gym.py:74-91, diy_gym/model.py:53-83; SURVEY.md 8(b) groups
+ * "world" and "model").
+ *
+ * All indices are 0-based.  Quaternions are xyzw.  Rotation matrices are
+ * row-major 3x3 with x_parent = R * x_child + p.
+ */
+#ifndef DIYGYM_SCENE_H
+#define DIYGYM_SCENE_H
+
+#define DG_MAGIC 0x44475953 /* 'DGYS' */
+#define DG_VERSION 3
+
+/* ---- header ints ---------------------------------------------------- */
+enum {
+  DG_H_MAGIC = 0,
+  DG_H_VERSION,
+  DG_H_N_BODIES,
+  DG_H_N_LINKS,      /* moving (1-DoF) links over all bodies == total DoF */
+  DG_H_N_FRAMES,
+  DG_H_N_SHAPES,
+  DG_H_N_POINTS,     /* convex hull points over all SHAPE_POINTS shapes   */
+  DG_H_N_PAIRS,      /* shape pairs that may collide                       */
+  DG_H_N_OPS,        /* addon program length                               */
+  DG_H_N_ILIST,      /* length of the op int-list pool                     */
+  DG_H_N_FLIST,      /* length of the op float-list pool                   */
+  DG_H_ACT_DIM,
+  DG_H_OBS_DIM,
+  DG_H_REW_DIM,
+  DG_H_TERM_DIM,
+  DG_H_SUBSTEPS,     /* numSubSteps (reference diy_gym.py:77)              */
+  DG_H_SOLVER_ITERS, /* numSolverIterations (reference diy_gym.py:78)      */
+  DG_H_MAX_EPISODE_STEPS, /* -1 = disabled (reference diy_gym.py:57)        */
+  DG_H_HOT_START,    /* sim steps after reset (reference diy_gym.py:58,145) */
+  DG_H_IK_ITERS,
+  DG_H_STATE_DIM,    /* floats of persistent state per env                 */
+  DG_H_ADDON_STATE_OFF, /* offset of addon state inside the env state      */
+  DG_H_N_ADDON_STATE,
+  DG_H_MAX_CONTACTS,
+  DG_H_REW_MODE,     /* DG_COLLAPSE_NONE | DG_COLLAPSE_SUM (reference diy_gym.py:94)      */
+  DG_H_TERM_MODE,    /* DG_COLLAPSE_NONE | _ANY | _ALL (reference diy_gym.py:95-96)      */
+  DG_H_N_TERM_GROUPS,/* receptors that own terminal columns (for _ALL)                   */
+  DG_H_OFF_BODY_I,
+  DG_H_OFF_LINK_I,
+  DG_H_OFF_FRAME_I,
+  DG_H_OFF_SHAPE_I,
+  DG_H_OFF_PAIR_I,
+  DG_H_OFF_OP_I,
+  DG_H_OFF_ILIST,
+  DG_H_OFF_BODY_F,
+  DG_H_OFF_LINK_F,
+  DG_H_OFF_FRAME_F,
+  DG_H_OFF_SHAPE_F,
+  DG_H_OFF_POINT_F,
+  DG_H_OFF_OP_F,
+  DG_H_OFF_FLIST,
+  DG_H_INT_COUNT /* header length in I[] */
+};
+
+/* ---- header floats -------------------------------------------------- */
+enum {
+  DG_HF_DT = 0,        /* substep length = timestep / substeps            */
+  DG_HF_GRAV_X, DG_HF_GRAV_Y, DG_HF_GRAV_Z,
+  DG_HF_RESIDUAL_THRESHOLD, /* PGS early-out on squared velocity residual */
+  DG_HF_CONTACT_ERP,
+  DG_HF_LIMIT_ERP,
+  DG_HF_LINEAR_SLOP,
+  DG_HF_LIN_DAMPING,   /* btMultiBody linear damping k (K1 = K2 = k)      */
+  DG_HF_ANG_DAMPING,
+  DG_HF_MAX_COORD_VEL, /* joint velocity clamp                            */
+  DG_HF_DEFAULT_MOTOR_IMPULSE, /* velocity motor every joint gets at load  */
+  DG_HF_IK_LAMBDA_SQ,  /* DLS damping (task space, null-space variant)    */
+  DG_HF_IK_JOINT_DAMPING, /* DLS2 diagonal (joint space variant)          */
+  DG_HF_IK_RESIDUAL,   /* position residual threshold                     */
+  DG_HF_IK_MAX_ANGLE,  /* per-iteration joint step clamp (rad)            */
+  DG_HF_IK_NULL_REST_GAIN,
+  DG_HF_IK_NULL_LIMIT_GAIN,
+  DG_HF_CONTACT_MARGIN, /* speculative contact distance                   */
+  DG_HF_FLOAT_COUNT
+};
+
+/* ---- per-env state prefix --------------------------------------------- */
+enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_EPISODE /* resets so far (RNG stream) */,
+       DG_ST_PREFIX };
+
+/* ---- body table ------------------------------------------------------ */
+#define DG_BODY_FIXED 1  /* base does not move (use_fixed_base / massless root) */
+enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF, DG_BI_STRIDE };
+/* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
+ * then, for a floating base only, linvel[3] (of the base-frame origin, world)
+ * angvel[3] (world); then ext_force[3] ext_torque[3] (world, about the base
+ * origin... see DG_EXT_*); then per link see DG_LS_*.                        */
+enum {
+  DG_BF_MASS = 0, DG_BF_COM = 1,        /* lumped base: mass, com[3]          */
+  DG_BF_INERTIA = 4,                    /* xx xy xz yy yz zz about the com    */
+  DG_BF_INIT_POS = 10, DG_BF_INIT_QUAT = 13, /* base link frame at load      */
+  DG_BF_REPORT_POS = 17, DG_BF_REPORT_QUAT = 20, /* root inertial frame in the
+                                          base link frame: what pybullet's
+                                          getBasePositionAndOrientation reports */
+  DG_BF_STRIDE = 24
+};
+
+/* ---- link table (one row per DoF, bodies contiguous, parents first) -- */
+enum { DG_LI_PARENT = 0 /* global link index, -1 = base of own body */, DG_LI_TYPE /* 0 revolute 1 prismatic */,
+       DG_LI_BODY, DG_LI_STATE_OFF, DG_LI_STRIDE };
+enum {
+  DG_LF_POS = 0,   /* joint frame origin in the parent reference frame      */
+  DG_LF_ROT = 3,   /* 3x3                                                    */
+  DG_LF_AXIS = 12, /* in the link frame                                      */
+  DG_LF_MASS = 15, DG_LF_COM = 16, DG_LF_INERTIA = 19,
+  DG_LF_DAMPING = 25, DG_LF_LOWER = 26, DG_LF_UPPER = 27, DG_LF_MAX_FORCE = 28, DG_LF_MAX_VEL = 29,
+  DG_LF_STRIDE = 32
+};
+/* per-env state of a link at DG_LI_STATE_OFF */
+enum { DG_LS_Q = 0, DG_LS_QD, DG_LS_TARGET_POS, DG_LS_TARGET_VEL, DG_LS_TORQUE /* joint torque for the next step */,
+       DG_LS_APPLIED /* motor torque applied during the last substep */, DG_LS_STRIDE };
+
+/* offsets inside the body state block */
+enum { DG_BS_POS = 0, DG_BS_QUAT = 3, DG_BS_FIXED_END = 7, DG_BS_LINVEL = 7, DG_BS_ANGVEL = 10, DG_BS_FLOAT_END = 13 };
+/* after FIXED_END / FLOAT_END: external wrench for the next step, world frame,
+ * torque taken about the base-frame origin of the body */
+enum { DG_EXT_FORCE = 0, DG_EXT_TORQUE = 3, DG_EXT_STRIDE = 6 };
+
+/* ---- motor configuration (uniform over envs, owned by the world) ----- */
+enum { DG_MC_KP = 0, DG_MC_KD, DG_MC_MAX_IMPULSE_SCALE /* max force; impulse = force*dt, or <0: raw impulse */,
+       DG_MC_STRIDE };
+
+/* ---- frame table ------------------------------------------------------ */
+enum { DG_FI_BODY = 0, DG_FI_LINK /* global link index, -1 = base */, DG_FI_STRIDE };
+enum { DG_FF_POS = 0, DG_FF_QUAT = 3, DG_FF_COM_POS = 7, DG_FF_COM_QUAT = 10, DG_FF_STRIDE = 14 };
+
+/* ---- shapes ----------------------------------------------------------- */
+enum { DG_SHAPE_SPHERE = 0, DG_SHAPE_BOX = 1, DG_SHAPE_CAPSULE = 2, DG_SHAPE_POINTS = 3 };
+enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, DG_SI_STRIDE };
+enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3] | capsule r, half_len (axis = local z) */,
+       DG_SF_FRICTION = 15, DG_SF_STRIDE = 16 };
+enum { DG_PI_A = 0, DG_PI_B, DG_PI_STRIDE };
+
+/* ---- addon program ---------------------------------------------------- */
+/* phases: an op runs in exactly one phase */
+enum {
+  DG_OP_NOP = 0,
+  /* update phase (reference Addon.update, diy_gym.py:202-204) */
+  DG_OP_JOINT_CONTROL = 1,   /* joint_controller.py:40-58 */
+  DG_OP_IK_CONTROL = 2,      /* ik_controller.py:51-80    */
+  DG_OP_EXTERNAL_FORCE = 3,  /* external_force.py:21-24   */
+  DG_OP_PROPELLOR = 4,       /* examples/drone_pilot/drone_pilot.py:31-37 */
+  /* reset phase (reference Addon.reset, diy_gym.py:141-143) */
+  DG_OP_RESPAWN = 16,        /* respawn.py:31-39 */
+  DG_OP_RESET_JOINTS = 17,   /* joint_controller.py:36-38, ik_controller.py:47-49 */
+  /* observe phase */
+  DG_OP_OBS_JOINT_STATE = 32,  /* joint_state_sensor.py:47-57 */
+  DG_OP_OBS_OBJECT_STATE = 33, /* object_state_sensor.py:49-75 */
+  DG_OP_OBS_ADDON_STATE = 34,  /* drone_pilot.py:39-40 */
+  /* reward phase */
+  DG_OP_REW_REACH = 48,        /* reach_target.py:32-33 */
+  DG_OP_REW_ELECTRICITY = 49,  /* electricity_cost.py:15-18 */
+  DG_OP_REW_CONST = 50,        /* time_penalty.py:11-12 */
+  /* terminal phase */
+  DG_OP_TERM_REACH = 64,       /* reach_target.py:35-36 */
+  DG_OP_TERM_TILT = 65,        /* drone_pilot.py:53-55 */
+  DG_OP_TERM_TIMER = 66        /* diy_gym.py:180-183 */
+};
+enum {
+  DG_OI_CODE = 0,
+  DG_OI_BODY,      /* primary body                                          */
+  DG_OI_FRAME,     /* frame index (global) or -1 = base                      */
+  DG_OI_BODY2,     /* secondary body (source) or -1                          */
+  DG_OI_FRAME2,
+  DG_OI_FLAGS,
+  DG_OI_N,         /* list length                                            */
+  DG_OI_ILIST,     /* offset into the int-list pool (global link indices)    */
+  DG_OI_FLIST,     /* offset into the float-list pool                        */
+  DG_OI_IO_OFF,    /* column in the action / obs / reward / terminal buffer  */
+  DG_OI_STATE_OFF, /* addon state offset (relative to ADDON_STATE_OFF)       */
+  DG_OI_SLOT,      /* update ops: bit index in the per-step update mask      */
+  DG_OI_STRIDE
+};
+enum { DG_OF_STRIDE = 16 };
+
+/* DG_OP_JOINT_CONTROL flags */
+enum { DG_JC_POSITION = 0, DG_JC_VELOCITY = 1, DG_JC_TORQUE = 2 };
+/* DG_OP_IK_CONTROL flags */
+#define DG_IK_USE_ORIENTATION 1
+#define DG_IK_NULLSPACE 2
+/* DG_OP_OBS_JOINT_STATE flags */
+#define DG_JS_VELOCITY 1
+#define DG_JS_EFFORT 2
+/* DG_OP_OBS_OBJECT_STATE flags */
+#define DG_OS_ROTATION 1
+#define DG_OS_VELOCITY 2
+/* DG_OP_RESPAWN flags */
+#define DG_RS_ONCE 1
+
+/* collapse modes for the reward / terminal outputs */
+enum { DG_COLLAPSE_NONE = 0, DG_COLLAPSE_SUM = 1, DG_COLLAPSE_ANY = 2, DG_COLLAPSE_ALL = 3 };
+
+#endif /* DIYGYM_SCENE_H */

@@ -1,0 +1,1132 @@
+/* dgsim_oracle.c -- CPU oracle for the DIYGym batched step path (fp64, plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg as the checker for the HIP path.  The product
+ * (diy_gym_amd/) never links, loads or calls it.
+ *
+ * PARITY UNPINNED.  The arithmetic of the reference's step path lives in the
+ * third-party `pybullet` wheel (reference requirements.txt:3, unpinned, source
+ * not vendored, not installable here).  This file restates (a) the reference's
+ * own Python semantics -- every addon hook and the DIYGym.step/reset sequence,
+ * each function citing the reference file:line it follows -- and (b) the
+ * published algorithms pybullet's multibody path is built on (Featherstone's
+ * articulated-body algorithm; sequential-impulse / projected Gauss-Seidel on
+ * velocity-level rows; damped-least-squares IK), with Bullet's parameter
+ * values taken FROM RECOLLECTION (tagged [R] below, listed in DESIGN.md).
+ * There are no golden vectors in the reference, so what pins
+ * this oracle is tests/test_oracle_kat.py: analytic known-answer tests
+ * (free fall, resting contact, pendulum period and energy, mass-matrix
+ * symmetry, ABA vs. Lagrangian double pendulum, FK of the UR5 at the
+ * reference's rest pose computed independently in numpy, IK fixed point) and
+ * the reference's one behavioural test (tests/test_environment.py:23-40).
+ *
+ * One env at a time, arrays-of-structs, straightforward dense 6x6 spatial
+ * algebra: deliberately NOT the layout or the code of the HIP kernels.
+ */
+#include "dgsim_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/diygym_scene.h"
+
+#define MAXL 24     /* moving links per body */
+#define MAXV (6 + MAXL)
+#define MAXC 32     /* contacts per env */
+#define MAXROWS (3 * MAXL * 8 + 3 * MAXC)
+
+static char g_err[512];
+static void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+const char* dgo_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------ math */
+typedef struct { double x, y, z; } v3;
+typedef struct { double m[3][3]; } m3;
+typedef struct { double x, y, z, w; } qt;
+
+static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vscale(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
+static double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static double vnorm(v3 a) { return sqrt(vdot(a, a)); }
+static v3 mv(const m3* A, v3 b) {
+  return V(A->m[0][0] * b.x + A->m[0][1] * b.y + A->m[0][2] * b.z, A->m[1][0] * b.x + A->m[1][1] * b.y + A->m[1][2] * b.z,
+           A->m[2][0] * b.x + A->m[2][1] * b.y + A->m[2][2] * b.z);
+}
+static v3 mtv(const m3* A, v3 b) { /* A^T b */
+  return V(A->m[0][0] * b.x + A->m[1][0] * b.y + A->m[2][0] * b.z, A->m[0][1] * b.x + A->m[1][1] * b.y + A->m[2][1] * b.z,
+           A->m[0][2] * b.x + A->m[1][2] * b.y + A->m[2][2] * b.z);
+}
+static m3 mmul(const m3* A, const m3* B) {
+  m3 C;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C.m[i][j] = A->m[i][0] * B->m[0][j] + A->m[i][1] * B->m[1][j] + A->m[i][2] * B->m[2][j];
+  return C;
+}
+static m3 mident(void) { m3 I = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}}; return I; }
+static m3 mfrom9(const double* p) {
+  m3 A;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A.m[i][j] = p[3 * i + j];
+  return A;
+}
+static m3 msym6(const double* p) { /* xx xy xz yy yz zz */
+  m3 A = {{{p[0], p[1], p[2]}, {p[1], p[3], p[4]}, {p[2], p[4], p[5]}}};
+  return A;
+}
+static qt qmul(qt a, qt b) {
+  qt r = {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+  return r;
+}
+static qt qconj(qt a) { qt r = {-a.x, -a.y, -a.z, a.w}; return r; }
+static qt qnormalize(qt a) {
+  double n = sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  qt r = {a.x / n, a.y / n, a.z / n, a.w / n};
+  return r;
+}
+static m3 qmat(qt q) {
+  double n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0 ? 2.0 / n : 0.0;
+  double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys,
+         yz = q.y * zs, zz = q.z * zs;
+  m3 R = {{{1 - (yy + zz), xy - wz, xz + wy}, {xy + wz, 1 - (xx + zz), yz - wx}, {xz - wy, yz + wx, 1 - (xx + yy)}}};
+  return R;
+}
+static qt qfrom_mat(const m3* R) {
+  double tr = R->m[0][0] + R->m[1][1] + R->m[2][2];
+  qt q;
+  if (tr > 0) {
+    double s = sqrt(tr + 1.0) * 2.0;
+    q.x = (R->m[2][1] - R->m[1][2]) / s; q.y = (R->m[0][2] - R->m[2][0]) / s; q.z = (R->m[1][0] - R->m[0][1]) / s; q.w = 0.25 * s;
+  } else if (R->m[0][0] > R->m[1][1] && R->m[0][0] > R->m[2][2]) {
+    double s = sqrt(1.0 + R->m[0][0] - R->m[1][1] - R->m[2][2]) * 2.0;
+    q.x = 0.25 * s; q.y = (R->m[0][1] + R->m[1][0]) / s; q.z = (R->m[0][2] + R->m[2][0]) / s; q.w = (R->m[2][1] - R->m[1][2]) / s;
+  } else if (R->m[1][1] > R->m[2][2]) {
+    double s = sqrt(1.0 + R->m[1][1] - R->m[0][0] - R->m[2][2]) * 2.0;
+    q.x = (R->m[0][1] + R->m[1][0]) / s; q.y = 0.25 * s; q.z = (R->m[1][2] + R->m[2][1]) / s; q.w = (R->m[0][2] - R->m[2][0]) / s;
+  } else {
+    double s = sqrt(1.0 + R->m[2][2] - R->m[0][0] - R->m[1][1]) * 2.0;
+    q.x = (R->m[0][2] + R->m[2][0]) / s; q.y = (R->m[1][2] + R->m[2][1]) / s; q.z = 0.25 * s; q.w = (R->m[1][0] - R->m[0][1]) / s;
+  }
+  return qnormalize(q);
+}
+/* pybullet getQuaternionFromEuler: fixed-axis XYZ = Rz(yaw) Ry(pitch) Rx(roll) [R] */
+static qt qfrom_euler(double r, double p, double y) {
+  double cr = cos(r * 0.5), sr = sin(r * 0.5), cp = cos(p * 0.5), sp = sin(p * 0.5), cy = cos(y * 0.5), sy = sin(y * 0.5);
+  qt q = {sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+  return q;
+}
+/* pybullet getEulerFromQuaternion (btQuaternion::getEulerZYX branches) [R] */
+static v3 euler_from_q(qt q) {
+  double sarg = -2.0 * (q.x * q.z - q.w * q.y);
+  if (sarg <= -0.99999) return V(0.0, -0.5 * M_PI, 2.0 * atan2(q.x, -q.y));
+  if (sarg >= 0.99999) return V(0.0, 0.5 * M_PI, 2.0 * atan2(-q.x, q.y));
+  double sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
+  return V(atan2(2.0 * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz), asin(sarg),
+           atan2(2.0 * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz));
+}
+static m3 rot_axis(v3 a, double th) { /* Rodrigues, |a| = 1 */
+  double c = cos(th), s = sin(th), t = 1 - c;
+  m3 R = {{{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
+           {t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x},
+           {t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}}};
+  return R;
+}
+
+/* spatial vectors: [angular(3); linear(3)] */
+typedef struct { double v[6]; } s6;
+typedef struct { double m[6][6]; } m6;
+static v3 ang(const s6* a) { return V(a->v[0], a->v[1], a->v[2]); }
+static v3 lin(const s6* a) { return V(a->v[3], a->v[4], a->v[5]); }
+static s6 mk6(v3 a, v3 l) { s6 r = {{a.x, a.y, a.z, l.x, l.y, l.z}}; return r; }
+static s6 s6add(s6 a, s6 b) { for (int i = 0; i < 6; i++) a.v[i] += b.v[i]; return a; }
+static s6 s6scale(s6 a, double s) { for (int i = 0; i < 6; i++) a.v[i] *= s; return a; }
+static double s6dot(const s6* a, const s6* b) { double s = 0; for (int i = 0; i < 6; i++) s += a->v[i] * b->v[i]; return s; }
+static s6 m6v(const m6* A, const s6* x) {
+  s6 r;
+  for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += A->m[i][j] * x->v[j]; r.v[i] = s; }
+  return r;
+}
+/* motion transform parent -> child:  E = rotation parent->child coords, r = child origin in parent coords */
+static s6 xmotion(const m3* E, v3 r, const s6* v) {
+  v3 w = ang(v), l = lin(v);
+  return mk6(mv(E, w), mv(E, vsub(l, vcross(r, w))));
+}
+/* force transform child -> parent (transpose of the motion transform) */
+static s6 xforce_to_parent(const m3* E, v3 r, const s6* f) {
+  v3 n = mtv(E, ang(f)), l = mtv(E, lin(f));
+  return mk6(vadd(n, vcross(r, l)), l);
+}
+static m6 xmat(const m3* E, v3 r) { /* 6x6 of xmotion */
+  m6 X; memset(&X, 0, sizeof X);
+  m3 rx = {{{0, -r.z, r.y}, {r.z, 0, -r.x}, {-r.y, r.x, 0}}};
+  m3 Erx = mmul(E, &rx);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { X.m[i][j] = E->m[i][j]; X.m[3 + i][3 + j] = E->m[i][j]; X.m[3 + i][j] = -Erx.m[i][j]; }
+  return X;
+}
+static s6 crm(const s6* v, const s6* s) { /* v x s (motion) */
+  v3 w = ang(v), l = lin(v), sw = ang(s), sl = lin(s);
+  return mk6(vcross(w, sw), vadd(vcross(w, sl), vcross(l, sw)));
+}
+static s6 crf(const s6* v, const s6* f) { /* v x* f (force) */
+  v3 w = ang(v), l = lin(v), n = ang(f), fl = lin(f);
+  return mk6(vadd(vcross(w, n), vcross(l, fl)), vcross(w, fl));
+}
+static m6 rigid_inertia(double m, v3 c, const m3* Ic) {
+  m6 I; memset(&I, 0, sizeof I);
+  m3 cx = {{{0, -c.z, c.y}, {c.z, 0, -c.x}, {-c.y, c.x, 0}}};
+  double cc = vdot(c, c);
+  double cv[3] = {c.x, c.y, c.z};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      I.m[i][j] = Ic->m[i][j] + m * ((i == j ? cc : 0.0) - cv[i] * cv[j]);
+      I.m[i][3 + j] = m * cx.m[i][j];
+      I.m[3 + i][j] = -m * cx.m[i][j];
+      I.m[3 + i][3 + j] = (i == j) ? m : 0.0;
+    }
+  return I;
+}
+/* solve A x = b for SPD 6x6 (Cholesky); returns 0 on failure */
+static int spd_solve(int n, const double* A, const double* b, double* x) {
+  double L[12 * 12];
+  if (n > 12) return 0;
+  memset(L, 0, sizeof L);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) { if (s <= 0) return 0; L[i * n + i] = sqrt(s); } else L[i * n + j] = s / L[j * n + j];
+    }
+  double y[12];
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+  return 1;
+}
+
+/* counter-based RNG shared (as a spec) with the device: splitmix64 finaliser,
+ * 24-bit mantissa so the value is exact in fp32 and fp64 alike */
+static uint64_t mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+  return z;
+}
+static double rng_uniform(uint64_t seed, uint64_t env, uint64_t episode, uint64_t op, uint64_t comp) {
+  uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1));
+  z = mix64(z ^ (episode * 0xD1342543DE82EF95ULL + op * 0x2545F4914F6CDD1DULL + comp + 1));
+  return (double)(z >> 40) * (1.0 / 16777216.0);
+}
+
+/* ------------------------------------------------------------- the world */
+typedef struct {
+  int32_t* I; double* F; int64_t ni, nf;
+  int nb, nl, nfr, nsh, npairs, nops;
+  int act_dim, obs_dim, rew_dim, term_dim, substeps, iters, max_steps, hot_start, ik_iters, state_dim;
+  int addon_off, max_contacts, rew_mode, term_mode, n_term_groups;
+  const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
+  const double *BF, *LF, *FF, *SF, *PF, *OF, *FL;
+  double h; v3 g;
+} Scene;
+
+typedef struct {
+  int body_a, link_a, body_b, link_b; /* link = global link index or -1 (base) */
+  v3 p; /* world contact point (midway) */
+  v3 n; /* world normal, from B towards A */
+  double dist; /* signed distance (negative = penetration) */
+  double mu;
+} Contact;
+
+struct dgo_world {
+  Scene sc;
+  int B;
+  uint64_t seed; int64_t env_base;
+  double* state; /* [B][state_dim] */
+  double* mcfg;  /* [nl][DG_MC_STRIDE] */
+  int* last_contacts; int* last_iters;
+};
+
+/* per-body workspace for one env */
+typedef struct {
+  int n; int first; int fixed;
+  v3 p0; qt q0; m3 R0; /* base link frame in world */
+  /* per link */
+  m3 E[MAXL]; v3 r[MAXL];         /* parent->child motion transform */
+  m3 Rw[MAXL]; v3 pw[MAXL];       /* link frame in world */
+  s6 S[MAXL], v[MAXL], c[MAXL], pA[MAXL], U[MAXL], a[MAXL];
+  m6 IA[MAXL]; double d[MAXL], u[MAXL], qdd[MAXL];
+  s6 v0, pA0, a0; m6 IA0;
+  int parent[MAXL]; /* local index, -1 base */
+  double dv[MAXV]; /* solver velocity change: base(6, base coords) + joints */
+} BodyWS;
+
+static double* env_state(dgo_world* w, int e) { return w->state + (size_t)e * w->sc.state_dim; }
+static const int32_t* body_i(const Scene* s, int b) { return s->BI + b * DG_BI_STRIDE; }
+static const double* body_f(const Scene* s, int b) { return s->BF + b * DG_BF_STRIDE; }
+static const int32_t* link_i(const Scene* s, int l) { return s->LI + l * DG_LI_STRIDE; }
+static const double* link_f(const Scene* s, int l) { return s->LF + l * DG_LF_STRIDE; }
+static int body_fixed(const Scene* s, int b) { return body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
+static double* body_ext(const Scene* s, double* st, int b) {
+  return st + body_i(s, b)[DG_BI_STATE_OFF] + (body_fixed(s, b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END);
+}
+
+static int parse_scene(Scene* s, const int32_t* I, int64_t ni, const double* F, int64_t nf) {
+  if (ni < DG_H_INT_COUNT || I[DG_H_MAGIC] != DG_MAGIC) { set_err("bad scene magic"); return 0; }
+  if (I[DG_H_VERSION] != DG_VERSION) { set_err("scene version %d, expected %d", I[DG_H_VERSION], DG_VERSION); return 0; }
+  s->I = (int32_t*)malloc(sizeof(int32_t) * (size_t)ni); memcpy(s->I, I, sizeof(int32_t) * (size_t)ni);
+  s->F = (double*)malloc(sizeof(double) * (size_t)nf); memcpy(s->F, F, sizeof(double) * (size_t)nf);
+  s->ni = ni; s->nf = nf; I = s->I; F = s->F;
+  s->nb = I[DG_H_N_BODIES]; s->nl = I[DG_H_N_LINKS]; s->nfr = I[DG_H_N_FRAMES]; s->nsh = I[DG_H_N_SHAPES];
+  s->npairs = I[DG_H_N_PAIRS]; s->nops = I[DG_H_N_OPS];
+  s->act_dim = I[DG_H_ACT_DIM]; s->obs_dim = I[DG_H_OBS_DIM]; s->rew_dim = I[DG_H_REW_DIM]; s->term_dim = I[DG_H_TERM_DIM];
+  s->substeps = I[DG_H_SUBSTEPS]; s->iters = I[DG_H_SOLVER_ITERS]; s->max_steps = I[DG_H_MAX_EPISODE_STEPS];
+  s->hot_start = I[DG_H_HOT_START]; s->ik_iters = I[DG_H_IK_ITERS]; s->state_dim = I[DG_H_STATE_DIM];
+  s->addon_off = I[DG_H_ADDON_STATE_OFF]; s->max_contacts = I[DG_H_MAX_CONTACTS];
+  s->rew_mode = I[DG_H_REW_MODE]; s->term_mode = I[DG_H_TERM_MODE]; s->n_term_groups = I[DG_H_N_TERM_GROUPS];
+  s->BI = I + I[DG_H_OFF_BODY_I]; s->LI = I + I[DG_H_OFF_LINK_I]; s->FI = I + I[DG_H_OFF_FRAME_I];
+  s->SI = I + I[DG_H_OFF_SHAPE_I]; s->PI = I + I[DG_H_OFF_PAIR_I]; s->OI = I + I[DG_H_OFF_OP_I]; s->IL = I + I[DG_H_OFF_ILIST];
+  s->BF = F + I[DG_H_OFF_BODY_F]; s->LF = F + I[DG_H_OFF_LINK_F]; s->FF = F + I[DG_H_OFF_FRAME_F];
+  s->SF = F + I[DG_H_OFF_SHAPE_F]; s->PF = F + I[DG_H_OFF_POINT_F]; s->OF = F + I[DG_H_OFF_OP_F]; s->FL = F + I[DG_H_OFF_FLIST];
+  s->h = F[DG_HF_DT]; s->g = V(F[DG_HF_GRAV_X], F[DG_HF_GRAV_Y], F[DG_HF_GRAV_Z]);
+  if (s->max_contacts > MAXC) { set_err("max_contacts %d > %d", s->max_contacts, MAXC); return 0; }
+  for (int b = 0; b < s->nb; b++)
+    if (body_i(s, b)[DG_BI_N_LINKS] > MAXL) { set_err("body %d has more than %d links", b, MAXL); return 0; }
+  return 1;
+}
+
+dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, int64_t n_f, int32_t num_envs, uint64_t seed,
+                      int64_t env_index_base) {
+  dgo_world* w = (dgo_world*)calloc(1, sizeof *w);
+  if (!parse_scene(&w->sc, idata, n_i, fdata, n_f)) { free(w); return NULL; }
+  w->B = num_envs; w->seed = seed; w->env_base = env_index_base;
+  w->state = (double*)calloc((size_t)num_envs * w->sc.state_dim, sizeof(double));
+  w->mcfg = (double*)calloc((size_t)(w->sc.nl > 0 ? w->sc.nl : 1) * DG_MC_STRIDE, sizeof(double));
+  w->last_contacts = (int*)calloc(num_envs, sizeof(int));
+  w->last_iters = (int*)calloc(num_envs, sizeof(int));
+  /* every movable joint starts with pybullet's default velocity motor: target 0,
+   * kd 1, kp 0, fixed impulse budget per substep [R] */
+  for (int l = 0; l < w->sc.nl; l++) {
+    w->mcfg[l * DG_MC_STRIDE + DG_MC_KP] = 0.0;
+    w->mcfg[l * DG_MC_STRIDE + DG_MC_KD] = 1.0;
+    w->mcfg[l * DG_MC_STRIDE + DG_MC_MAX_IMPULSE_SCALE] = -w->sc.F[DG_HF_DEFAULT_MOTOR_IMPULSE];
+  }
+  /* initial state = load pose (reference model.py:68), joints at zero */
+  for (int e = 0; e < num_envs; e++) {
+    double* st = env_state(w, e);
+    for (int b = 0; b < w->sc.nb; b++) {
+      double* bs = st + body_i(&w->sc, b)[DG_BI_STATE_OFF];
+      const double* bf = body_f(&w->sc, b);
+      for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] = bf[DG_BF_INIT_POS + k];
+      for (int k = 0; k < 4; k++) bs[DG_BS_QUAT + k] = bf[DG_BF_INIT_QUAT + k];
+    }
+  }
+  return w;
+}
+void dgo_destroy(dgo_world* w) {
+  if (!w) return;
+  free(w->sc.I); free(w->sc.F); free(w->state); free(w->mcfg); free(w->last_contacts); free(w->last_iters); free(w);
+}
+int32_t dgo_state_dim(const dgo_world* w) { return w->sc.state_dim; }
+double* dgo_state(dgo_world* w) { return w->state; }
+double* dgo_motor_cfg(dgo_world* w) { return w->mcfg; }
+int32_t dgo_last_contact_count(const dgo_world* w, int32_t env) { return w->last_contacts[env]; }
+int32_t dgo_last_iterations(const dgo_world* w, int32_t env) { return w->last_iters[env]; }
+
+/* --------------------------------------------------------- kinematics */
+static void body_kinematics(const Scene* s, const double* st, int b, BodyWS* ws, const double* q_override) {
+  const int32_t* bi = body_i(s, b);
+  const double* bs = st + bi[DG_BI_STATE_OFF];
+  ws->n = bi[DG_BI_N_LINKS]; ws->first = bi[DG_BI_FIRST_LINK]; ws->fixed = bi[DG_BI_FLAGS] & DG_BODY_FIXED;
+  ws->p0 = V(bs[0], bs[1], bs[2]);
+  qt q0 = {bs[3], bs[4], bs[5], bs[6]}; ws->q0 = q0; ws->R0 = qmat(q0);
+  for (int i = 0; i < ws->n; i++) {
+    int gl = ws->first + i;
+    const int32_t* li = link_i(s, gl); const double* lf = link_f(s, gl);
+    int par = li[DG_LI_PARENT]; ws->parent[i] = par < 0 ? -1 : par - ws->first;
+    double q = q_override ? q_override[i] : st[li[DG_LI_STATE_OFF] + DG_LS_Q];
+    m3 RT = mfrom9(lf + DG_LF_ROT); v3 pT = V(lf[DG_LF_POS], lf[DG_LF_POS + 1], lf[DG_LF_POS + 2]);
+    v3 ax = V(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]);
+    m3 Rpc; v3 r;
+    if (li[DG_LI_TYPE] == 0) { m3 Rq = rot_axis(ax, q); Rpc = mmul(&RT, &Rq); r = pT; ws->S[i] = mk6(ax, V(0, 0, 0)); }
+    else { Rpc = RT; r = vadd(pT, mv(&RT, vscale(ax, q))); ws->S[i] = mk6(V(0, 0, 0), ax); }
+    /* E = Rpc^T */
+    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) ws->E[i].m[a][c] = Rpc.m[c][a];
+    ws->r[i] = r;
+    const m3* Rp = ws->parent[i] < 0 ? &ws->R0 : &ws->Rw[ws->parent[i]];
+    v3 pp = ws->parent[i] < 0 ? ws->p0 : ws->pw[ws->parent[i]];
+    ws->Rw[i] = mmul(Rp, &Rpc);
+    ws->pw[i] = vadd(pp, mv(Rp, r));
+  }
+}
+/* link (-1 = base) frame in world */
+static void link_world(const BodyWS* ws, int local_link, m3* R, v3* p) {
+  if (local_link < 0) { *R = ws->R0; *p = ws->p0; } else { *R = ws->Rw[local_link]; *p = ws->pw[local_link]; }
+}
+
+/* velocities (spatial, link coords) from state */
+static void body_velocities(const Scene* s, const double* st, int b, BodyWS* ws) {
+  const double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+  if (ws->fixed) memset(&ws->v0, 0, sizeof ws->v0);
+  else {
+    v3 vw = V(bs[DG_BS_LINVEL], bs[DG_BS_LINVEL + 1], bs[DG_BS_LINVEL + 2]);
+    v3 ww = V(bs[DG_BS_ANGVEL], bs[DG_BS_ANGVEL + 1], bs[DG_BS_ANGVEL + 2]);
+    ws->v0 = mk6(mtv(&ws->R0, ww), mtv(&ws->R0, vw));
+  }
+  for (int i = 0; i < ws->n; i++) {
+    double qd = st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD];
+    const s6* vp = ws->parent[i] < 0 ? &ws->v0 : &ws->v[ws->parent[i]];
+    s6 vJ = s6scale(ws->S[i], qd);
+    ws->v[i] = s6add(xmotion(&ws->E[i], ws->r[i], vp), vJ);
+    ws->c[i] = crm(&ws->v[i], &vJ);
+  }
+}
+
+/* Bullet's per-link "global" damping [R]: force -m v_com (k + k|v_com|), torque
+ * -I_c w (k + k|w|), returned as a spatial force about the link origin */
+static s6 damping_force(double m, v3 c, const m3* Ic, const s6* v, double kl, double ka) {
+  v3 w = ang(v), vo = lin(v);
+  v3 vc = vadd(vo, vcross(w, c));
+  v3 f = vscale(vc, -m * (kl + kl * vnorm(vc)));
+  v3 n = vscale(mv(Ic, w), -(ka + ka * vnorm(w)));
+  return mk6(vadd(n, vcross(c, f)), f);
+}
+
+/* articulated-body algorithm, passes 1-3 (Featherstone, RBDA ch. 7).  tau = joint
+ * torques (damping, torque-control).  Leaves IA, U, d in ws for impulse responses. */
+static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
+  const double* bf = body_f(s, b);
+  double kl = s->F[DG_HF_LIN_DAMPING], ka = s->F[DG_HF_ANG_DAMPING];
+  /* pass 1: inertias and bias forces */
+  for (int i = 0; i < ws->n; i++) {
+    const double* lf = link_f(s, ws->first + i);
+    v3 c = V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]); m3 Ic = msym6(lf + DG_LF_INERTIA);
+    ws->IA[i] = rigid_inertia(lf[DG_LF_MASS], c, &Ic);
+    s6 Iv = m6v(&ws->IA[i], &ws->v[i]);
+    ws->pA[i] = crf(&ws->v[i], &Iv);
+    s6 fd = damping_force(lf[DG_LF_MASS], c, &Ic, &ws->v[i], kl, ka);
+    for (int k = 0; k < 6; k++) ws->pA[i].v[k] -= fd.v[k];
+  }
+  if (!ws->fixed) {
+    v3 c = V(bf[DG_BF_COM], bf[DG_BF_COM + 1], bf[DG_BF_COM + 2]); m3 Ic = msym6(bf + DG_BF_INERTIA);
+    ws->IA0 = rigid_inertia(bf[DG_BF_MASS], c, &Ic);
+    s6 Iv = m6v(&ws->IA0, &ws->v0);
+    ws->pA0 = crf(&ws->v0, &Iv);
+    s6 fd = damping_force(bf[DG_BF_MASS], c, &Ic, &ws->v0, kl, ka);
+    /* external wrench (world, about the base origin) -> base coords */
+    const double* ex = body_ext(s, (double*)st, b);
+    v3 fe = mtv(&ws->R0, V(ex[0], ex[1], ex[2])), ne = mtv(&ws->R0, V(ex[3], ex[4], ex[5]));
+    s6 fx = mk6(ne, fe);
+    for (int k = 0; k < 6; k++) ws->pA0.v[k] -= fd.v[k] + fx.v[k];
+  }
+  /* pass 2: articulated inertias, leaves to root */
+  for (int i = ws->n - 1; i >= 0; i--) {
+    const int32_t* li = link_i(s, ws->first + i); const double* lf = link_f(s, ws->first + i);
+    double qd = st[li[DG_LI_STATE_OFF] + DG_LS_QD];
+    double tau = st[li[DG_LI_STATE_OFF] + DG_LS_TORQUE] - lf[DG_LF_DAMPING] * qd; /* Bullet joint damping [R] */
+    ws->U[i] = m6v(&ws->IA[i], &ws->S[i]);
+    ws->d[i] = s6dot(&ws->S[i], &ws->U[i]);
+    ws->u[i] = tau - s6dot(&ws->S[i], &ws->pA[i]);
+    m6 Ia = ws->IA[i];
+    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Ia.m[a][c] -= ws->U[i].v[a] * ws->U[i].v[c] / ws->d[i];
+    s6 Iac = m6v(&Ia, &ws->c[i]);
+    s6 pa;
+    for (int k = 0; k < 6; k++) pa.v[k] = ws->pA[i].v[k] + Iac.v[k] + ws->U[i].v[k] * ws->u[i] / ws->d[i];
+    m6 X = xmat(&ws->E[i], ws->r[i]);
+    /* parent += X^T Ia X ; X^T pa */
+    m6 T; for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 6; k++) t += Ia.m[a][k] * X.m[k][c]; T.m[a][c] = t; }
+    m6* Ip = ws->parent[i] < 0 ? &ws->IA0 : &ws->IA[ws->parent[i]];
+    s6* pp = ws->parent[i] < 0 ? &ws->pA0 : &ws->pA[ws->parent[i]];
+    if (ws->parent[i] >= 0 || !ws->fixed) {
+      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 6; k++) t += X.m[k][a] * T.m[k][c]; Ip->m[a][c] += t; }
+      s6 pf = xforce_to_parent(&ws->E[i], ws->r[i], &pa);
+      for (int k = 0; k < 6; k++) pp->v[k] += pf.v[k];
+    }
+  }
+  /* pass 3: accelerations.  Gravity enters as a base acceleration of -g (fixed
+   * base) or is added afterwards (floating base, RBDA 9.4). */
+  v3 gb = mtv(&ws->R0, s->g);
+  if (ws->fixed) ws->a0 = mk6(V(0, 0, 0), vscale(gb, -1.0));
+  else {
+    double rhs[6], x[6];
+    for (int k = 0; k < 6; k++) rhs[k] = -ws->pA0.v[k];
+    if (!spd_solve(6, &ws->IA0.m[0][0], rhs, x)) memset(x, 0, sizeof x);
+    for (int k = 0; k < 6; k++) ws->a0.v[k] = x[k];
+  }
+  for (int i = 0; i < ws->n; i++) {
+    const s6* ap = ws->parent[i] < 0 ? &ws->a0 : &ws->a[ws->parent[i]];
+    s6 a1 = s6add(xmotion(&ws->E[i], ws->r[i], ap), ws->c[i]);
+    ws->qdd[i] = (ws->u[i] - s6dot(&ws->U[i], &a1)) / ws->d[i];
+    ws->a[i] = s6add(a1, s6scale(ws->S[i], ws->qdd[i]));
+  }
+  if (!ws->fixed) { ws->a0.v[3] += gb.x; ws->a0.v[4] += gb.y; ws->a0.v[5] += gb.z; }
+}
+
+/* impulse response: generalized velocity change caused by a unit of (spatial force
+ * f at local link `lk` (-1 = base), expressed in that link's coords) and/or a
+ * joint impulse on dof `dof` (-1 none).  Same recursion as ABA with zero
+ * velocity and zero gravity (Featherstone RBDA 7.3 / Bullet's
+ * calcAccelerationDeltasMultiDof).  Also returns the row Jacobian J with
+ * J . gen_velocity == f . v_link  (+ qd[dof]). */
+static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, double* J, double* dv) {
+  s6 p[MAXL], p0; double u[MAXL];
+  memset(p, 0, sizeof(s6) * (size_t)(ws->n > 0 ? ws->n : 1)); memset(&p0, 0, sizeof p0);
+  for (int k = 0; k < 6 + ws->n; k++) { J[k] = 0; dv[k] = 0; }
+  s6 fj[MAXL], fj0; memset(fj, 0, sizeof(s6) * (size_t)(ws->n > 0 ? ws->n : 1)); memset(&fj0, 0, sizeof fj0);
+  if (f) { if (lk < 0) { fj0 = *f; for (int k = 0; k < 6; k++) p0.v[k] = -f->v[k]; } else { fj[lk] = *f; for (int k = 0; k < 6; k++) p[lk].v[k] = -f->v[k]; } }
+  for (int i = ws->n - 1; i >= 0; i--) {
+    /* Jacobian: pure force propagation */
+    J[6 + i] = s6dot(&ws->S[i], &fj[i]) + (i == dof ? 1.0 : 0.0);
+    s6 fjp = xforce_to_parent(&ws->E[i], ws->r[i], &fj[i]);
+    if (ws->parent[i] < 0) fj0 = s6add(fj0, fjp); else fj[ws->parent[i]] = s6add(fj[ws->parent[i]], fjp);
+    /* response */
+    u[i] = (i == dof ? 1.0 : 0.0) - s6dot(&ws->S[i], &p[i]);
+    s6 pa; for (int k = 0; k < 6; k++) pa.v[k] = p[i].v[k] + ws->U[i].v[k] * u[i] / ws->d[i];
+    s6 pf = xforce_to_parent(&ws->E[i], ws->r[i], &pa);
+    if (ws->parent[i] < 0) p0 = s6add(p0, pf); else p[ws->parent[i]] = s6add(p[ws->parent[i]], pf);
+  }
+  s6 a[MAXL], a0; memset(&a0, 0, sizeof a0);
+  if (!ws->fixed) {
+    for (int k = 0; k < 6; k++) J[k] = fj0.v[k];
+    double rhs[6], x[6]; for (int k = 0; k < 6; k++) rhs[k] = -p0.v[k];
+    if (!spd_solve(6, &ws->IA0.m[0][0], rhs, x)) memset(x, 0, sizeof x);
+    for (int k = 0; k < 6; k++) { a0.v[k] = x[k]; dv[k] = x[k]; }
+  }
+  for (int i = 0; i < ws->n; i++) {
+    const s6* ap = ws->parent[i] < 0 ? &a0 : &a[ws->parent[i]];
+    s6 a1 = xmotion(&ws->E[i], ws->r[i], ap);
+    double qdd = (u[i] - s6dot(&ws->U[i], &a1)) / ws->d[i];
+    a[i] = s6add(a1, s6scale(ws->S[i], qdd));
+    dv[6 + i] = qdd;
+  }
+}
+
+/* ----------------------------------------------------------- collision */
+typedef struct { int type, body, llink /* local */, glink; m3 R; v3 p; const double* prm; double mu; int poff, npts; } WShape;
+
+static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
+  const int32_t* si = s->SI + sh * DG_SI_STRIDE; const double* sf = s->SF + sh * DG_SF_STRIDE;
+  o->type = si[DG_SI_TYPE]; o->body = si[DG_SI_BODY]; o->glink = si[DG_SI_LINK];
+  const BodyWS* ws = &wsb[o->body];
+  o->llink = o->glink < 0 ? -1 : o->glink - ws->first;
+  m3 Rl; v3 pl; link_world(ws, o->llink, &Rl, &pl);
+  m3 Rs = mfrom9(sf + DG_SF_ROT);
+  o->R = mmul(&Rl, &Rs); o->p = vadd(pl, mv(&Rl, V(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2])));
+  o->prm = sf + DG_SF_PARAMS; o->mu = sf[DG_SF_FRICTION]; o->poff = si[DG_SI_POINT_OFF]; o->npts = si[DG_SI_N_POINTS];
+}
+static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, double dist) {
+  if (*nc >= maxc) return;
+  Contact* c = &cs[(*nc)++];
+  c->body_a = a->body; c->link_a = a->llink; c->body_b = b->body; c->link_b = b->llink;
+  c->p = vscale(vadd(pa, pb), 0.5); c->n = n; c->dist = dist; c->mu = a->mu * b->mu; /* Bullet combines friction by product [R] */
+}
+/* sphere (centre c, radius r) against box shape bx: returns 1 and contact data when dist < margin */
+static int sphere_box(v3 c, double r, const WShape* bx, double margin, v3* pa, v3* pb, v3* n, double* dist) {
+  v3 lc = mtv(&bx->R, vsub(c, bx->p));
+  double h[3] = {bx->prm[0], bx->prm[1], bx->prm[2]}, l[3] = {lc.x, lc.y, lc.z}, cl[3];
+  int inside = 1;
+  for (int k = 0; k < 3; k++) { cl[k] = l[k] < -h[k] ? -h[k] : (l[k] > h[k] ? h[k] : l[k]); if (cl[k] != l[k]) inside = 0; }
+  v3 nl; double d;
+  if (!inside) {
+    v3 df = V(l[0] - cl[0], l[1] - cl[1], l[2] - cl[2]); d = vnorm(df); nl = vscale(df, 1.0 / d);
+  } else { /* centre inside: leave through the nearest face */
+    int best = 0; double bd = 1e300; double sg = 1;
+    for (int k = 0; k < 3; k++) { double dp = h[k] - l[k], dm = l[k] + h[k]; if (dp < bd) { bd = dp; best = k; sg = 1; } if (dm < bd) { bd = dm; best = k; sg = -1; } }
+    double nn[3] = {0, 0, 0}; nn[best] = sg; nl = V(nn[0], nn[1], nn[2]); d = -bd; cl[best] = sg * h[best];
+  }
+  if (d - r >= margin) return 0;
+  *n = mv(&bx->R, nl);
+  *pb = vadd(bx->p, mv(&bx->R, V(cl[0], cl[1], cl[2])));
+  *pa = vsub(c, vscale(*n, r));
+  *dist = d - r;
+  return 1;
+}
+static void seg_ends(const WShape* c, v3* e0, v3* e1) {
+  v3 ax = V(c->R.m[0][2], c->R.m[1][2], c->R.m[2][2]);
+  *e0 = vsub(c->p, vscale(ax, c->prm[1])); *e1 = vadd(c->p, vscale(ax, c->prm[1]));
+}
+static v3 closest_on_seg(v3 a, v3 b, v3 p) {
+  v3 ab = vsub(b, a); double den = vdot(ab, ab);
+  double t = den > 0 ? vdot(vsub(p, a), ab) / den : 0.0; t = t < 0 ? 0 : (t > 1 ? 1 : t);
+  return vadd(a, vscale(ab, t));
+}
+/* closest points between segments p1-q1, p2-q2 (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(v3 p1, v3 q1, v3 p2, v3 q2, v3* c1, v3* c2) {
+  v3 d1 = vsub(q1, p1), d2 = vsub(q2, p2), r = vsub(p1, p2);
+  double a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r), sN, tN; const double eps = 1e-12;
+  if (a <= eps && e <= eps) { *c1 = p1; *c2 = p2; return; }
+  if (a <= eps) { sN = 0; tN = f / e; tN = tN < 0 ? 0 : (tN > 1 ? 1 : tN); }
+  else {
+    double c = vdot(d1, r);
+    if (e <= eps) { tN = 0; sN = -c / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+    else {
+      double b = vdot(d1, d2), den = a * e - b * b;
+      sN = den > eps ? (b * f - c * e) / den : 0.0; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN);
+      tN = (b * sN + f) / e;
+      if (tN < 0) { tN = 0; sN = -c / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+      else if (tN > 1) { tN = 1; sN = (b - c) / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
+    }
+  }
+  *c1 = vadd(p1, vscale(d1, sN)); *c2 = vadd(p2, vscale(d2, tN));
+}
+static int sphere_sphere(v3 ca, double ra, v3 cb, double rb, double margin, v3* pa, v3* pb, v3* n, double* dist) {
+  v3 d = vsub(ca, cb); double len = vnorm(d);
+  if (len - ra - rb >= margin) return 0;
+  *n = len > 1e-12 ? vscale(d, 1.0 / len) : V(0, 0, 1);
+  *pa = vsub(ca, vscale(*n, ra)); *pb = vadd(cb, vscale(*n, rb)); *dist = len - ra - rb;
+  return 1;
+}
+
+static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
+  int nc = 0; double margin = s->F[DG_HF_CONTACT_MARGIN];
+  for (int pi = 0; pi < s->npairs; pi++) {
+    WShape A, Bs; shape_world(s, wsb, s->PI[pi * DG_PI_STRIDE + DG_PI_A], &A); shape_world(s, wsb, s->PI[pi * DG_PI_STRIDE + DG_PI_B], &Bs);
+    const WShape *a = &A, *b = &Bs; double flip = 1.0;
+    /* canonical order: lower type id first, except that a box is always `b` */
+    if (a->type == DG_SHAPE_BOX || (b->type != DG_SHAPE_BOX && a->type > b->type)) { const WShape* t = a; a = b; b = t; flip = -1.0; }
+    v3 pa, pb, n; double dist;
+    #define EMIT() do { if (flip > 0) add_contact(cs, &nc, s->max_contacts, a, b, pa, pb, n, dist); \
+                        else add_contact(cs, &nc, s->max_contacts, b, a, pb, pa, vscale(n, -1.0), dist); } while (0)
+    if (a->type == DG_SHAPE_SPHERE && b->type == DG_SHAPE_SPHERE) {
+      if (sphere_sphere(a->p, a->prm[0], b->p, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if (a->type == DG_SHAPE_SPHERE && b->type == DG_SHAPE_BOX) {
+      if (sphere_box(a->p, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if (a->type == DG_SHAPE_SPHERE && (b->type == DG_SHAPE_CAPSULE || b->type == DG_SHAPE_POINTS)) {
+      v3 e0, e1; seg_ends(b, &e0, &e1); v3 cb = closest_on_seg(e0, e1, a->p);
+      if (sphere_sphere(a->p, a->prm[0], cb, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if ((a->type == DG_SHAPE_CAPSULE || a->type == DG_SHAPE_POINTS) && (b->type == DG_SHAPE_CAPSULE || b->type == DG_SHAPE_POINTS)) {
+      /* mesh-vs-mesh uses the capsule fitted to each hull (documented approximation) */
+      v3 a0, a1, b0, b1, ca, cb; seg_ends(a, &a0, &a1); seg_ends(b, &b0, &b1); seg_seg(a0, a1, b0, b1, &ca, &cb);
+      if (sphere_sphere(ca, a->prm[0], cb, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if (a->type == DG_SHAPE_CAPSULE && b->type == DG_SHAPE_BOX) {
+      v3 e0, e1; seg_ends(a, &e0, &e1);
+      if (sphere_box(e0, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
+      if (a->prm[1] > 0 && sphere_box(e1, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if (a->type == DG_SHAPE_POINTS && b->type == DG_SHAPE_BOX) {
+      /* hull vertices against the box: keep the 4 deepest (ties -> lower index) */
+      int bi[4] = {-1, -1, -1, -1}; double bd[4] = {1e300, 1e300, 1e300, 1e300};
+      m3 Rl; v3 pl; link_world(&wsb[a->body], a->llink, &Rl, &pl);
+      for (int k = 0; k < a->npts; k++) {
+        const double* pp = s->PF + 3 * (a->poff + k);
+        v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));
+        v3 qa, qb, qn; double qd;
+        if (!sphere_box(pwk, 0.0, b, margin, &qa, &qb, &qn, &qd)) continue;
+        for (int j = 0; j < 4; j++) if (qd < bd[j]) { for (int m = 3; m > j; m--) { bd[m] = bd[m - 1]; bi[m] = bi[m - 1]; } bd[j] = qd; bi[j] = k; break; }
+      }
+      for (int j = 0; j < 4; j++) if (bi[j] >= 0) {
+        const double* pp = s->PF + 3 * (a->poff + bi[j]);
+        v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));
+        if (sphere_box(pwk, 0.0, b, margin, &pa, &pb, &n, &dist)) EMIT();
+      }
+    }
+    #undef EMIT
+  }
+  return nc;
+}
+
+/* ------------------------------------------------------------- solver */
+typedef struct {
+  int body_a, body_b; /* body_b = -1: single-body row */
+  double JA[MAXV], RA[MAXV], JB[MAXV], RB[MAXV];
+  double b, lo, hi, acc, diag; /* diag = J M^-1 J^T */
+  int normal_row; double mu;   /* friction rows: index of the normal row */
+  int motor_link;              /* global link index for motor rows else -1 */
+} Row;
+
+static double row_jv(const Row* r, BodyWS* wsb) {
+  double s = 0; const BodyWS* a = &wsb[r->body_a];
+  for (int k = 0; k < 6 + a->n; k++) s += r->JA[k] * a->dv[k];
+  if (r->body_b >= 0) { const BodyWS* b = &wsb[r->body_b]; for (int k = 0; k < 6 + b->n; k++) s += r->JB[k] * b->dv[k]; }
+  return s;
+}
+static double gen_vel_dot(const Scene* s, const double* st, const BodyWS* ws, const double* J) {
+  double r = 0;
+  if (!ws->fixed) for (int k = 0; k < 6; k++) r += J[k] * ws->v0.v[k];
+  for (int i = 0; i < ws->n; i++) r += J[6 + i] * st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD];
+  return r;
+}
+/* spatial unit force at world point p along world direction n, in the coords of local link lk */
+static s6 point_force(const BodyWS* ws, int lk, v3 p, v3 n) {
+  m3 R; v3 o; link_world(ws, lk, &R, &o);
+  v3 rl = mtv(&R, vsub(p, o)), nl = mtv(&R, n);
+  return mk6(vcross(rl, nl), nl);
+}
+static void tangent_basis(v3 n, v3* t1, v3* t2) { /* btPlaneSpace1 [R] */
+  if (fabs(n.z) > 0.7071067811865475244) {
+    double a = n.y * n.y + n.z * n.z, k = 1.0 / sqrt(a);
+    *t1 = V(0, -n.z * k, n.y * k); *t2 = V(a * k, -n.x * t1->z, n.x * t1->y);
+  } else {
+    double a = n.x * n.x + n.y * n.y, k = 1.0 / sqrt(a);
+    *t1 = V(-n.y * k, n.x * k, 0); *t2 = V(-n.z * t1->y, n.z * t1->x, a * k);
+  }
+}
+static int make_contact_row(const Scene* s, const double* st, BodyWS* wsb, const Contact* c, v3 dir, Row* r) {
+  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1;
+  BodyWS *A = &wsb[c->body_a], *Bw = &wsb[c->body_b];
+  int a_dyn = !(A->fixed && A->n == 0), b_dyn = !(Bw->fixed && Bw->n == 0);
+  if (!a_dyn && !b_dyn) return 0;
+  double diag = 0, jv = 0;
+  if (a_dyn) {
+    s6 f = point_force(A, c->link_a, c->p, dir);
+    r->body_a = c->body_a; body_response(A, c->link_a, &f, -1, r->JA, r->RA);
+    for (int k = 0; k < 6 + A->n; k++) diag += r->JA[k] * r->RA[k];
+    jv += gen_vel_dot(s, st, A, r->JA);
+    if (b_dyn) {
+      s6 fb = point_force(Bw, c->link_b, c->p, vscale(dir, -1.0));
+      r->body_b = c->body_b; body_response(Bw, c->link_b, &fb, -1, r->JB, r->RB);
+      for (int k = 0; k < 6 + Bw->n; k++) diag += r->JB[k] * r->RB[k];
+      jv += gen_vel_dot(s, st, Bw, r->JB);
+    } else r->body_b = -1;
+  } else {
+    s6 fb = point_force(Bw, c->link_b, c->p, vscale(dir, -1.0));
+    r->body_a = c->body_b; r->body_b = -1; body_response(Bw, c->link_b, &fb, -1, r->JA, r->RA);
+    for (int k = 0; k < 6 + Bw->n; k++) diag += r->JA[k] * r->RA[k];
+    jv += gen_vel_dot(s, st, Bw, r->JA);
+  }
+  r->diag = diag; r->b = -jv;
+  return diag > 1e-18;
+}
+
+/* one substep of length h for env state st (Bullet btMultiBodyDynamicsWorld::
+ * internalSingleStepSimulation order [R]: collide at the current poses, forward
+ * dynamics, velocity update, constraint solve, position update) */
+static void substep(dgo_world* w, int env) {
+  Scene* s = &w->sc; double* st = env_state(w, env); double h = s->h;
+  BodyWS* wsb = (BodyWS*)malloc(sizeof(BodyWS) * (size_t)s->nb);
+  Row* rows = (Row*)malloc(sizeof(Row) * MAXROWS); int nr = 0;
+  Contact cs[MAXC];
+  for (int b = 0; b < s->nb; b++) { body_kinematics(s, st, b, &wsb[b], NULL); body_velocities(s, st, b, &wsb[b]); }
+  int nc = collide(s, wsb, cs); w->last_contacts[env] = nc;
+  /* forward dynamics + velocity update */
+  for (int b = 0; b < s->nb; b++) {
+    BodyWS* ws = &wsb[b];
+    if (ws->fixed && ws->n == 0) continue;
+    body_aba(s, st, b, ws);
+    double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+    if (!ws->fixed) {
+      v3 al = lin(&ws->a0), aa = ang(&ws->a0), wb = ang(&ws->v0), vb = lin(&ws->v0);
+      v3 acl = vadd(al, vcross(wb, vb)); /* classical acceleration of the base origin */
+      v3 dvw = mv(&ws->R0, acl), dww = mv(&ws->R0, aa);
+      bs[DG_BS_LINVEL] += h * dvw.x; bs[DG_BS_LINVEL + 1] += h * dvw.y; bs[DG_BS_LINVEL + 2] += h * dvw.z;
+      bs[DG_BS_ANGVEL] += h * dww.x; bs[DG_BS_ANGVEL + 1] += h * dww.y; bs[DG_BS_ANGVEL + 2] += h * dww.z;
+    }
+    for (int i = 0; i < ws->n; i++) st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD] += h * ws->qdd[i];
+    body_velocities(s, st, b, ws); /* rows see the updated velocities */
+    memset(ws->dv, 0, sizeof ws->dv);
+  }
+  /* rows: motors, then joint limits (btMultiBodyJointMotor / JointLimitConstraint [R]) */
+  double erp = s->F[DG_HF_LIMIT_ERP];
+  for (int b = 0; b < s->nb; b++) {
+    BodyWS* ws = &wsb[b];
+    for (int i = 0; i < ws->n; i++) {
+      int gl = ws->first + i; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; const double* mc = w->mcfg + gl * DG_MC_STRIDE;
+      ls[DG_LS_APPLIED] = 0.0;
+      double maxf = mc[DG_MC_MAX_IMPULSE_SCALE], maximp = maxf < 0 ? -maxf : maxf * h;
+      if (maximp > 0) {
+        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = gl;
+        body_response(ws, -1, NULL, i, r->JA, r->RA);
+        r->diag = r->RA[6 + i];
+        /* rhs = kp*(q*-q)/dt + qd + kd*(qd*-qd) as a velocity target; error = target - qd */
+        r->b = mc[DG_MC_KP] * (ls[DG_LS_TARGET_POS] - ls[DG_LS_Q]) / h + mc[DG_MC_KD] * (ls[DG_LS_TARGET_VEL] - ls[DG_LS_QD]);
+        r->lo = -maximp; r->hi = maximp;
+      }
+    }
+  }
+  for (int b = 0; b < s->nb; b++) {
+    BodyWS* ws = &wsb[b];
+    for (int i = 0; i < ws->n; i++) {
+      int gl = ws->first + i; const double* lf = link_f(s, gl); double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+      if (lf[DG_LF_LOWER] > lf[DG_LF_UPPER]) continue;
+      for (int side = 0; side < 2; side++) {
+        double sg = side == 0 ? 1.0 : -1.0;
+        double dist = side == 0 ? ls[DG_LS_Q] - lf[DG_LF_LOWER] : lf[DG_LF_UPPER] - ls[DG_LS_Q];
+        if (dist >= 0.25) continue; /* rows that cannot become active within one substep are skipped */
+        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = -1;
+        body_response(ws, -1, NULL, i, r->JA, r->RA);
+        for (int k = 0; k < 6 + ws->n; k++) { r->JA[k] *= sg; r->RA[k] *= sg; }
+        r->diag = r->RA[6 + i] * sg;
+        double relv = sg * ls[DG_LS_QD];
+        r->b = -relv + (dist > 0 ? -dist / h : -dist * erp / h);
+        r->lo = 0; r->hi = 1e300;
+      }
+    }
+  }
+  /* contacts: all normal rows first, then the friction rows (btMultiBodyConstraintSolver order [R]) */
+  int first_normal = nr; int crow[MAXC];
+  double cerp = s->F[DG_HF_CONTACT_ERP], slop = s->F[DG_HF_LINEAR_SLOP];
+  for (int k = 0; k < nc; k++) {
+    Row* r = &rows[nr]; crow[k] = -1;
+    if (!make_contact_row(s, st, wsb, &cs[k], cs[k].n, r)) continue;
+    double pen = cs[k].dist + slop;
+    r->b += pen > 0 ? -pen / h : -pen * cerp / h;
+    r->lo = 0; r->hi = 1e300; crow[k] = nr++;
+  }
+  (void)first_normal;
+  for (int k = 0; k < nc; k++) {
+    if (crow[k] < 0 || cs[k].mu <= 0) continue;
+    v3 t1, t2; tangent_basis(cs[k].n, &t1, &t2);
+    for (int d = 0; d < 2; d++) {
+      Row* r = &rows[nr];
+      if (!make_contact_row(s, st, wsb, &cs[k], d == 0 ? t1 : t2, r)) continue;
+      r->normal_row = crow[k]; r->mu = cs[k].mu; nr++;
+    }
+  }
+  /* projected Gauss-Seidel with the residual early-out (pybullet solverResidualThreshold [R]) */
+  double thr = s->F[DG_HF_RESIDUAL_THRESHOLD]; int it;
+  for (it = 0; it < s->iters; it++) {
+    double maxres = 0;
+    for (int k = 0; k < nr; k++) {
+      Row* r = &rows[k];
+      double lo = r->lo, hi = r->hi;
+      if (r->normal_row >= 0) { hi = r->mu * rows[r->normal_row].acc; lo = -hi; }
+      double delta = (r->b - row_jv(r, wsb)) / r->diag;
+      double nacc = r->acc + delta; nacc = nacc < lo ? lo : (nacc > hi ? hi : nacc);
+      delta = nacc - r->acc; r->acc = nacc;
+      BodyWS* A = &wsb[r->body_a]; for (int j = 0; j < 6 + A->n; j++) A->dv[j] += r->RA[j] * delta;
+      if (r->body_b >= 0) { BodyWS* Bw = &wsb[r->body_b]; for (int j = 0; j < 6 + Bw->n; j++) Bw->dv[j] += r->RB[j] * delta; }
+      double res = delta * r->diag; if (res * res > maxres) maxres = res * res;
+    }
+    if (maxres <= thr) { it++; break; }
+  }
+  w->last_iters[env] = it;
+  for (int k = 0; k < nr; k++) if (rows[k].motor_link >= 0) st[link_i(s, rows[k].motor_link)[DG_LI_STATE_OFF] + DG_LS_APPLIED] = rows[k].acc / h;
+  /* apply velocity changes, integrate positions (btMultiBody::stepPositionsMultiDof [R]) */
+  double vmax = s->F[DG_HF_MAX_COORD_VEL];
+  for (int b = 0; b < s->nb; b++) {
+    BodyWS* ws = &wsb[b];
+    if (ws->fixed && ws->n == 0) continue;
+    double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+    if (!ws->fixed) {
+      v3 dw = mv(&ws->R0, V(ws->dv[0], ws->dv[1], ws->dv[2])), dl = mv(&ws->R0, V(ws->dv[3], ws->dv[4], ws->dv[5]));
+      bs[DG_BS_ANGVEL] += dw.x; bs[DG_BS_ANGVEL + 1] += dw.y; bs[DG_BS_ANGVEL + 2] += dw.z;
+      bs[DG_BS_LINVEL] += dl.x; bs[DG_BS_LINVEL + 1] += dl.y; bs[DG_BS_LINVEL + 2] += dl.z;
+      for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] += h * bs[DG_BS_LINVEL + k];
+      v3 wv = V(bs[DG_BS_ANGVEL], bs[DG_BS_ANGVEL + 1], bs[DG_BS_ANGVEL + 2]);
+      double wn = vnorm(wv), th = wn * h; qt dq;
+      if (th > 1e-12) { double sn = sin(0.5 * th) / wn; dq.x = wv.x * sn; dq.y = wv.y * sn; dq.z = wv.z * sn; dq.w = cos(0.5 * th); }
+      else { dq.x = 0.5 * h * wv.x; dq.y = 0.5 * h * wv.y; dq.z = 0.5 * h * wv.z; dq.w = 1.0; }
+      qt q0 = {bs[3], bs[4], bs[5], bs[6]}; qt qn = qnormalize(qmul(dq, q0));
+      bs[3] = qn.x; bs[4] = qn.y; bs[5] = qn.z; bs[6] = qn.w;
+    }
+    for (int i = 0; i < ws->n; i++) {
+      double* ls = st + link_i(s, ws->first + i)[DG_LI_STATE_OFF];
+      double qd = ls[DG_LS_QD] + ws->dv[6 + i]; qd = qd > vmax ? vmax : (qd < -vmax ? -vmax : qd);
+      ls[DG_LS_QD] = qd; ls[DG_LS_Q] += h * qd;
+    }
+  }
+  free(rows); free(wsb);
+}
+
+/* -------------------------------------------------- frames and queries */
+typedef struct { v3 p; qt q; v3 v; v3 w; } FrameState;
+/* world pose/velocity of frame fr (-1 = base) of body b.  com selects the inertial frame. */
+static void frame_state(const Scene* s, const double* st, int b, int fr, int com, const double* q_override, FrameState* o) {
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
+  body_kinematics(s, st, b, ws, q_override); body_velocities(s, st, b, ws);
+  int lk; v3 off; qt qoff;
+  if (fr < 0) {
+    const double* bf = body_f(s, b); lk = -1;
+    if (com) { off = V(bf[DG_BF_REPORT_POS], bf[DG_BF_REPORT_POS + 1], bf[DG_BF_REPORT_POS + 2]); qt t = {bf[DG_BF_REPORT_QUAT], bf[DG_BF_REPORT_QUAT + 1], bf[DG_BF_REPORT_QUAT + 2], bf[DG_BF_REPORT_QUAT + 3]}; qoff = t; }
+    else { off = V(0, 0, 0); qt t = {0, 0, 0, 1}; qoff = t; }
+  } else {
+    const int32_t* fi = s->FI + fr * DG_FI_STRIDE; const double* ff = s->FF + fr * DG_FF_STRIDE;
+    lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
+    const double* pp = ff + (com ? DG_FF_COM_POS : DG_FF_POS); const double* qq = ff + (com ? DG_FF_COM_QUAT : DG_FF_QUAT);
+    off = V(pp[0], pp[1], pp[2]); qt t = {qq[0], qq[1], qq[2], qq[3]}; qoff = t;
+  }
+  m3 R; v3 p; link_world(ws, lk, &R, &p);
+  qt ql = qfrom_mat(&R);
+  if (lk < 0) ql = ws->q0;
+  o->p = vadd(p, mv(&R, off)); o->q = qnormalize(qmul(ql, qoff));
+  const s6* v = lk < 0 ? &ws->v0 : &ws->v[lk];
+  v3 wl = ang(v), vl = lin(v);
+  o->w = mv(&R, wl); o->v = mv(&R, vadd(vl, vcross(wl, off)));
+  free(ws);
+}
+int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, double* out) {
+  FrameState f; frame_state(&w->sc, env_state(w, env), body, frame, com, NULL, &f);
+  out[0] = f.p.x; out[1] = f.p.y; out[2] = f.p.z; out[3] = f.q.x; out[4] = f.q.y; out[5] = f.q.z; out[6] = f.q.w;
+  out[7] = f.v.x; out[8] = f.v.y; out[9] = f.v.z; out[10] = f.w.x; out[11] = f.w.y; out[12] = f.w.z;
+  return 0;
+}
+
+/* ------------------------------------------------ inverse kinematics */
+/* Restates what p.calculateInverseKinematics does for the reference's call
+ * (ik_controller.py:61-69) as recollected [R]: up to IK_ITERS damped
+ * least-squares steps from the current joint angles, each with a fresh
+ * Jacobian; with the four null-space lists of DoF length (UR5) the task-space
+ * DLS + null-space projection variant, otherwise (Jaco) the joint-space DLS
+ * variant; steps scaled so no joint moves more than IK_MAX_ANGLE; stop when
+ * the position error is below IK_RESIDUAL. */
+static void ik_jacobian(const BodyWS* ws, int lk, v3 pe, double* Jm /* [6][n] */) {
+  int n = ws->n; memset(Jm, 0, sizeof(double) * 6 * (size_t)n);
+  for (int i = lk; i >= 0; i = ws->parent[i]) {
+    v3 sw = ang(&ws->S[i]), sl = lin(&ws->S[i]);
+    v3 aw = mv(&ws->Rw[i], sw), al = mv(&ws->Rw[i], sl);
+    v3 jl = vadd(vcross(aw, vsub(pe, ws->pw[i])), al);
+    Jm[0 * n + i] = jl.x; Jm[1 * n + i] = jl.y; Jm[2 * n + i] = jl.z; Jm[3 * n + i] = aw.x; Jm[4 * n + i] = aw.y; Jm[5 * n + i] = aw.z;
+  }
+}
+static void run_ik(dgo_world* w, const double* st, int op, const double* act, double* q /* [n] out */) {
+  const Scene* s = &w->sc; const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+  int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
+  int use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE, m = use_orn ? 6 : 3;
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
+  body_kinematics(s, st, b, ws, NULL);
+  int n = ws->n;
+  for (int i = 0; i < n; i++) q[i] = st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_Q];
+  FrameState cur; frame_state(s, st, b, fr, 1, NULL, &cur);
+  v3 tp = vadd(cur.p, V(act[0], act[1], act[2]));
+  qt tq = cur.q;
+  if (use_orn) tq = qmul(cur.q, qfrom_euler(act[3], act[4], act[5])); /* ik_controller.py:56-59 */
+  const int32_t* fi = s->FI + fr * DG_FI_STRIDE; int lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
+  const double* rest = s->FL + oi[DG_OI_FLIST]; /* rest[n], lower[n], upper[n], range[n] */
+  double lam2 = s->F[DG_HF_IK_LAMBDA_SQ], jd = s->F[DG_HF_IK_JOINT_DAMPING], maxang = s->F[DG_HF_IK_MAX_ANGLE];
+  double g0 = s->F[DG_HF_IK_NULL_REST_GAIN], g1 = s->F[DG_HF_IK_NULL_LIMIT_GAIN];
+  (void)of;
+  for (int it = 0; it < s->ik_iters; it++) {
+    FrameState f; frame_state(s, st, b, fr, 1, q, &f);
+    v3 ep = vsub(tp, f.p);
+    if (vnorm(ep) < s->F[DG_HF_IK_RESIDUAL] && it > 0) break;
+    double dS[6] = {ep.x, ep.y, ep.z, 0, 0, 0};
+    if (use_orn) {
+      qt dq = qmul(tq, qconj(f.q));
+      if (dq.w < 0) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
+      double sn = sqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0 * atan2(sn, dq.w);
+      double k = sn > 1e-12 ? an / sn : 2.0;
+      dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
+    }
+    body_kinematics(s, st, b, ws, q);
+    double J6[6 * MAXL], J[6 * MAXL]; ik_jacobian(ws, lk, f.p, J6);
+    for (int r = 0; r < m; r++) for (int c = 0; c < n; c++) J[r * n + c] = J6[r * n + c];
+    double dth[MAXL];
+    if (nullsp) {
+      double U[36], y[6];
+      for (int r = 0; r < m; r++) for (int c = 0; c < m; c++) { double t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * J[c * n + k]; U[r * m + c] = t + (r == c ? lam2 : 0.0); }
+      spd_solve(m, U, dS, y);
+      for (int k = 0; k < n; k++) { double t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * y[r]; dth[k] = t; }
+      /* null-space velocity: towards the rest pose, away from violated limits */
+      double v0[MAXL], Jv[6], z[6];
+      for (int k = 0; k < n; k++) {
+        v0[k] = g0 * (rest[k] - q[k]);
+        double lo = rest[n + k], hi = rest[2 * n + k], rg = rest[3 * n + k];
+        if (q[k] > hi) v0[k] += g1 * (hi - q[k]) / rg;
+        if (q[k] < lo) v0[k] += g1 * (lo - q[k]) / rg;
+      }
+      for (int r = 0; r < m; r++) { double t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * v0[k]; Jv[r] = t; }
+      spd_solve(m, U, Jv, z);
+      for (int k = 0; k < n; k++) { double t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * z[r]; dth[k] += v0[k] - t; }
+    } else {
+      double A[12 * 12], rhs[12];
+      if (n > 12) n = 12;
+      for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) { double t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * J[k * ws->n + c]; A[r * n + c] = t + (r == c ? jd : 0.0); }
+        double t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * dS[k]; rhs[r] = t; }
+      spd_solve(n, A, rhs, dth); n = ws->n;
+    }
+    double mx = 0; for (int k = 0; k < n; k++) if (fabs(dth[k]) > mx) mx = fabs(dth[k]);
+    double sc = mx > maxang ? maxang / mx : 1.0;
+    for (int k = 0; k < n; k++) q[k] += sc * dth[k];
+  }
+  free(ws);
+}
+int dgo_ik(dgo_world* w, int32_t env, int32_t op, const double* action, double* q_out) {
+  run_ik(w, env_state(w, env), op, action, q_out); return 0;
+}
+
+/* ------------------------------------------------------ addon program */
+static void set_motor(dgo_world* w, int gl, double kp, double kd, double maxforce) {
+  double* mc = w->mcfg + gl * DG_MC_STRIDE; mc[DG_MC_KP] = kp; mc[DG_MC_KD] = kd; mc[DG_MC_MAX_IMPULSE_SCALE] = maxforce;
+}
+static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t mask) {
+  Scene* s = &w->sc; double* st = env_state(w, env);
+  for (int op = 0; op < s->nops; op++) {
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+    int code = oi[DG_OI_CODE];
+    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
+    if (!((mask >> oi[DG_OI_SLOT]) & 1ULL)) continue;
+    const double* a = act + oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST]; int n = oi[DG_OI_N];
+    if (code == DG_OP_JOINT_CONTROL) { /* joint_controller.py:40-58 */
+      int mode = oi[DG_OI_FLAGS];
+      for (int k = 0; k < n; k++) {
+        int gl = il[k]; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; double maxf = link_f(s, gl)[DG_LF_MAX_FORCE];
+        if (mode == DG_JC_POSITION) { ls[DG_LS_TARGET_POS] = a[k]; ls[DG_LS_TARGET_VEL] = 0.0; set_motor(w, gl, of[0], of[1], maxf); }
+        else if (mode == DG_JC_VELOCITY) { ls[DG_LS_TARGET_VEL] = a[k]; ls[DG_LS_TARGET_POS] = 0.0; set_motor(w, gl, 0.0, of[1], maxf); }
+        else ls[DG_LS_TORQUE] = a[k]; /* TORQUE_CONTROL: the velocity motor is left as it was */
+      }
+    } else if (code == DG_OP_IK_CONTROL) { /* ik_controller.py:51-80 */
+      double q[MAXL]; run_ik(w, st, op, a, q);
+      int first = body_i(s, oi[DG_OI_BODY])[DG_BI_FIRST_LINK];
+      for (int k = 0; k < n; k++) {
+        int gl = il[k]; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+        (void)first;
+        ls[DG_LS_TARGET_POS] = q[k]; /* joint_cmds[k] pairs with joint_ids[k] (ik_controller.py:69-74) */
+        ls[DG_LS_TARGET_VEL] = 0.0; set_motor(w, gl, of[0], of[1], link_f(s, gl)[DG_LF_MAX_FORCE]);
+      }
+    } else if (code == DG_OP_EXTERNAL_FORCE) { /* external_force.py:21-24: WORLD_FRAME force at a world position */
+      int b = oi[DG_OI_BODY]; if (body_fixed(s, b)) continue;
+      double* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; double* ex = body_ext(s, st, b);
+      v3 f = V(a[0], a[1], a[2]); v3 rel = vsub(V(of[0], of[1], of[2]), V(bs[0], bs[1], bs[2])); v3 t = vcross(rel, f);
+      ex[0] += f.x; ex[1] += f.y; ex[2] += f.z; ex[3] += t.x; ex[4] += t.y; ex[5] += t.z;
+    } else if (code == DG_OP_PROPELLOR) { /* drone_pilot.py:31-37 */
+      int b = oi[DG_OI_BODY]; double* as = st + s->addon_off + oi[DG_OI_STATE_OFF];
+      as[0] = as[0] + (a[0] - as[0]) * of[2];
+      if (body_fixed(s, b)) continue;
+      FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 0, NULL, &f);
+      m3 R = qmat(f.q); double* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; double* ex = body_ext(s, st, b);
+      v3 fw = mv(&R, V(0, 0, of[0] * as[0])), tw = mv(&R, V(0, 0, of[1] * as[0]));
+      v3 t = vadd(vcross(vsub(f.p, V(bs[0], bs[1], bs[2])), fw), tw);
+      ex[0] += fw.x; ex[1] += fw.y; ex[2] += fw.z; ex[3] += t.x; ex[4] += t.y; ex[5] += t.z;
+    }
+  }
+}
+static void set_base_com_pose(const Scene* s, double* st, int b, v3 pc, qt qc) {
+  /* p.resetBasePositionAndOrientation takes the pose of the root inertial frame and zeroes the velocity [R] */
+  const double* bf = body_f(s, b); double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+  qt qr = {bf[DG_BF_REPORT_QUAT], bf[DG_BF_REPORT_QUAT + 1], bf[DG_BF_REPORT_QUAT + 2], bf[DG_BF_REPORT_QUAT + 3]};
+  qt ql = qnormalize(qmul(qc, qconj(qr))); m3 R = qmat(ql);
+  v3 pl = vsub(pc, mv(&R, V(bf[DG_BF_REPORT_POS], bf[DG_BF_REPORT_POS + 1], bf[DG_BF_REPORT_POS + 2])));
+  bs[0] = pl.x; bs[1] = pl.y; bs[2] = pl.z; bs[3] = ql.x; bs[4] = ql.y; bs[5] = ql.z; bs[6] = ql.w;
+  if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) bs[DG_BS_LINVEL + k] = 0.0;
+}
+static void run_reset_ops(dgo_world* w, int env) {
+  Scene* s = &w->sc; double* st = env_state(w, env);
+  uint64_t episode = (uint64_t)st[DG_ST_EPISODE];
+  for (int op = 0; op < s->nops; op++) {
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE; int code = oi[DG_OI_CODE];
+    if (code == DG_OP_RESPAWN) { /* respawn.py:31-39 */
+      uint64_t ep = (oi[DG_OI_FLAGS] & DG_RS_ONCE) ? 0 : episode + 1, ge = (uint64_t)(w->env_base + env);
+      double u[6]; for (int k = 0; k < 6; k++) u[k] = rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)k) - 0.5;
+      v3 p = V(of[0] + u[0] * of[7], of[1] + u[1] * of[8], of[2] + u[2] * of[9]);
+      qt q0 = {of[3], of[4], of[5], of[6]};
+      qt q = qmul(q0, qfrom_euler(u[3] * of[10], u[4] * of[11], u[5] * of[12]));
+      set_base_com_pose(s, st, oi[DG_OI_BODY], p, q);
+    } else if (code == DG_OP_RESET_JOINTS) { /* joint_controller.py:36-38 */
+      const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST];
+      for (int k = 0; k < oi[DG_OI_N]; k++) { double* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
+    }
+  }
+  st[DG_ST_EPISODE] = (double)(episode + 1);
+}
+static double reach_dist(const Scene* s, const double* st, const int32_t* oi) { /* reach_target.py:21-30 */
+  FrameState a, b;
+  /* link frames use getLinkState item 4 (URDF frame); bases use the reported (inertial) position */
+  frame_state(s, st, oi[DG_OI_BODY2], oi[DG_OI_FRAME2], oi[DG_OI_FRAME2] < 0, NULL, &a);
+  frame_state(s, st, oi[DG_OI_BODY], oi[DG_OI_FRAME], oi[DG_OI_FRAME] < 0, NULL, &b);
+  return vnorm(vsub(b.p, a.p));
+}
+static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+  Scene* s = &w->sc; const double* st = env_state(w, env);
+  double rsum = 0; int gany[64]; memset(gany, 0, sizeof gany); int any = 0;
+  for (int op = 0; op < s->nops; op++) {
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+    int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST];
+    if (code == DG_OP_OBS_JOINT_STATE) { /* joint_state_sensor.py:47-57 */
+      int n = oi[DG_OI_N], k2 = n;
+      for (int k = 0; k < n; k++) if (obs) obs[io + k] = st[link_i(s, il[k])[DG_LI_STATE_OFF] + DG_LS_Q];
+      if (oi[DG_OI_FLAGS] & DG_JS_VELOCITY) { for (int k = 0; k < n; k++) if (obs) obs[io + k2 + k] = st[link_i(s, il[k])[DG_LI_STATE_OFF] + DG_LS_QD]; k2 += n; }
+      if (oi[DG_OI_FLAGS] & DG_JS_EFFORT) for (int k = 0; k < n; k++) if (obs) obs[io + k2 + k] = st[link_i(s, il[k])[DG_LI_STATE_OFF] + DG_LS_APPLIED];
+    } else if (code == DG_OP_OBS_OBJECT_STATE) { /* object_state_sensor.py:32-75: inertial-frame states (items 0,1,6,7) */
+      FrameState t; frame_state(s, st, oi[DG_OI_BODY], oi[DG_OI_FRAME], 1, NULL, &t);
+      if (oi[DG_OI_BODY2] >= 0) {
+        FrameState sr; frame_state(s, st, oi[DG_OI_BODY2], oi[DG_OI_FRAME2], 1, NULL, &sr);
+        t.p = vsub(t.p, sr.p); t.v = vsub(t.v, sr.v); t.q = qmul(sr.q, t.q); t.w = vsub(t.w, sr.w);
+      }
+      if (obs) {
+        int k = io; obs[k++] = t.p.x; obs[k++] = t.p.y; obs[k++] = t.p.z;
+        /* output order = insertion order of the dict built in observe(), object_state_sensor.py:64-73:
+         * position, velocity, rotation, angular_velocity */
+        if (oi[DG_OI_FLAGS] & DG_OS_VELOCITY) { obs[k++] = t.v.x; obs[k++] = t.v.y; obs[k++] = t.v.z; }
+        if (oi[DG_OI_FLAGS] & DG_OS_ROTATION) { v3 e = euler_from_q(t.q); obs[k++] = e.x; obs[k++] = e.y; obs[k++] = e.z; }
+        if ((oi[DG_OI_FLAGS] & DG_OS_ROTATION) && (oi[DG_OI_FLAGS] & DG_OS_VELOCITY)) { obs[k++] = t.w.x; obs[k++] = t.w.y; obs[k++] = t.w.z; }
+      }
+    } else if (code == DG_OP_OBS_ADDON_STATE) {
+      for (int k = 0; k < oi[DG_OI_N]; k++) if (obs) obs[io + k] = st[s->addon_off + oi[DG_OI_STATE_OFF] + k];
+    } else if (code == DG_OP_REW_REACH) { double r = -reach_dist(s, st, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
+    else if (code == DG_OP_REW_ELECTRICITY) { /* electricity_cost.py:15-18 */
+      const int32_t* bi = body_i(s, oi[DG_OI_BODY]); double acc = 0;
+      for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) { const double* ls = st + link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabs(ls[DG_LS_APPLIED] * ls[DG_LS_QD]); }
+      double r = -acc * of[0]; if (rew) rew[io] = r; rsum += r;
+    } else if (code == DG_OP_REW_CONST) { if (rew) rew[io] = of[0]; rsum += of[0]; }
+    else if (code == DG_OP_TERM_REACH || code == DG_OP_TERM_TILT || code == DG_OP_TERM_TIMER) {
+      int t = 0;
+      if (code == DG_OP_TERM_REACH) t = reach_dist(s, st, oi) < of[1];
+      else if (code == DG_OP_TERM_TILT) { /* drone_pilot.py:53-55 */
+        FrameState f; frame_state(s, st, oi[DG_OI_BODY], -1, 1, NULL, &f);
+        t = 2.0 * atan2(sqrt(f.q.x * f.q.x + f.q.y * f.q.y + f.q.z * f.q.z), fabs(f.q.w)) > of[0];
+      } else t = st[DG_ST_STEP] >= of[0]; /* diy_gym.py:180-183 */
+      if (term) term[io] = (uint8_t)t;
+      if (t) { any = 1; gany[oi[DG_OI_SLOT] & 63] = 1; }
+    }
+  }
+  if (rew_sum) *rew_sum = rsum;
+  if (term_flag) {
+    if (s->term_mode == DG_COLLAPSE_ALL) { int all = s->n_term_groups > 0; for (int g = 0; g < s->n_term_groups; g++) all = all && gany[g]; *term_flag = (uint8_t)all; }
+    else *term_flag = (uint8_t)any;
+  }
+}
+
+static void sim_step(dgo_world* w, int env) {
+  Scene* s = &w->sc; double* st = env_state(w, env);
+  for (int k = 0; k < s->substeps; k++) substep(w, env);
+  /* external wrenches and joint torques last for one stepSimulation [R] */
+  for (int b = 0; b < s->nb; b++) { double* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
+  for (int l = 0; l < s->nl; l++) st[link_i(s, l)[DG_LI_STATE_OFF] + DG_LS_TORQUE] = 0.0;
+}
+
+int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+  Scene* s = &w->sc;
+  for (int e = 0; e < w->B; e++)
+    run_output_ops(w, e, obs ? obs + (size_t)e * s->obs_dim : NULL, rew ? rew + (size_t)e * s->rew_dim : NULL,
+                   term ? term + (size_t)e * s->term_dim : NULL, rew_sum ? rew_sum + e : NULL, term_flag ? term_flag + e : NULL);
+  return 0;
+}
+/* reference diy_gym.py:130-148 */
+int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
+  Scene* s = &w->sc;
+  for (int e = 0; e < w->B; e++) {
+    if (mask && !mask[e]) continue;
+    double* st = env_state(w, e);
+    st[DG_ST_STEP] = 0.0;
+    run_reset_ops(w, e);
+    for (int k = 0; k < s->hot_start; k++) sim_step(w, e);
+  }
+  if (obs) dgo_observe(w, obs, NULL, NULL, NULL, NULL);
+  return 0;
+}
+/* reference diy_gym.py:187-209 */
+int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* obs, double* rew, uint8_t* term, double* rew_sum,
+             uint8_t* term_flag) {
+  Scene* s = &w->sc;
+  /* motor configuration is uniform over envs: apply ops env by env (idempotent) */
+  for (int e = 0; e < w->B; e++) {
+    double* st = env_state(w, e);
+    if (actions) run_update_ops(w, e, actions + (size_t)e * s->act_dim, update_mask);
+    st[DG_ST_STEP] += 1.0;
+    sim_step(w, e);
+  }
+  return dgo_observe(w, obs, rew, term, rew_sum, term_flag);
+}
+
+int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, double* qdd_out, double* base_acc6_out) {
+  Scene* s = &w->sc; double* st = env_state(w, env);
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
+  body_kinematics(s, st, body, ws, NULL); body_velocities(s, st, body, ws); body_aba(s, st, body, ws);
+  for (int i = 0; i < ws->n; i++) qdd_out[i] = ws->qdd[i];
+  if (base_acc6_out) for (int k = 0; k < 6; k++) base_acc6_out[k] = ws->a0.v[k];
+  free(ws); return 0;
+}
+int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, double* dv_out) {
+  Scene* s = &w->sc; double* st = env_state(w, env);
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); double J[MAXV];
+  body_kinematics(s, st, body, ws, NULL); body_velocities(s, st, body, ws); body_aba(s, st, body, ws);
+  body_response(ws, -1, NULL, dof, J, dv_out);
+  free(ws); return 0;
+}

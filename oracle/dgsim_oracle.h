@@ -1,0 +1,69 @@
+/* dgsim_oracle.h -- C API of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under diy_gym_amd/ may include, link or
+ * load this.  Users: tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.  See oracle/README.md for what pins it (PARITY UNPINNED
+ * against pybullet).
+ */
+#ifndef DGSIM_ORACLE_H
+#define DGSIM_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dgo_world dgo_world;
+
+/* Build a world of `num_envs` independent copies of the scene blob
+ * (include/diygym_scene.h).  `env_index_base` offsets the per-env RNG stream so
+ * that shards of one job draw different jitter.  Returns NULL on a malformed
+ * blob (dgo_last_error() says why). */
+dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, int64_t n_f, int32_t num_envs,
+                      uint64_t seed, int64_t env_index_base);
+void dgo_destroy(dgo_world* w);
+const char* dgo_last_error(void);
+
+int32_t dgo_state_dim(const dgo_world* w);
+/* state is env-major here: state[env * state_dim + k] */
+double* dgo_state(dgo_world* w);
+/* motor configuration table [n_links][DG_MC_STRIDE], uniform over envs */
+double* dgo_motor_cfg(dgo_world* w);
+
+/* reset the envs whose mask byte is non-zero (mask == NULL: all), run the reset
+ * ops, hot_start sim steps, then write obs[num_envs][obs_dim] for ALL envs
+ * (obs may be NULL). */
+int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs);
+
+/* one DIYGym.step(): update ops selected by `update_mask` (bit = DG_OI_SLOT),
+ * one simulation step, outputs.  Any output pointer may be NULL.
+ *   actions [num_envs][act_dim], obs [num_envs][obs_dim],
+ *   rew [num_envs][rew_dim], term [num_envs][term_dim] (0/1),
+ *   rew_sum [num_envs], term_any [num_envs] (collapsed per DG_H_* modes) */
+int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* obs, double* rew, uint8_t* term,
+             double* rew_sum, uint8_t* term_flag);
+
+/* outputs for the current state without stepping */
+int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag);
+
+/* world pose + velocity of a frame: out[0..2] pos, [3..6] quat, [7..9] linear
+ * velocity, [10..12] angular velocity.  frame = -1: base.  com != 0 selects the
+ * inertial frame (getLinkState items 0,1,6,7), else the URDF link frame (4,5). */
+int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, double* out13);
+
+/* diagnostics from the most recent substep of env `env` */
+int32_t dgo_last_contact_count(const dgo_world* w, int32_t env);
+int32_t dgo_last_iterations(const dgo_world* w, int32_t env);
+
+/* stand-alone pieces exposed for known-answer tests */
+/* joint-space inverse dynamics check: returns qdd for body `body` of env `env`
+ * at the current state with zero motor action (pure ABA, gravity + damping). */
+int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, double* qdd_out, double* base_acc6_out);
+/* joint-space mass matrix inverse column through the ABA impulse response */
+int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, double* dv_out);
+/* run the IK restatement only; q_out[n_links of body] */
+int dgo_ik(dgo_world* w, int32_t env, int32_t op_index, const double* action, double* q_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,162 @@
+"""Adapter that gives the CPU oracle the interface of ``HipBackend``.
+
+Lives under tests/ on purpose: the product package never sees the oracle.  It is
+used (a) to run host-side logic tests (addon compilation, spaces, dict plumbing,
+sharding) without a GPU and (b) as the checker in the GPU parity tests.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libdgsim_oracle.so'))
+        vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+        L.dgo_create.restype = vp
+        L.dgo_create.argtypes = [vp, i64, vp, i64, i32, u64, i64]
+        L.dgo_destroy.argtypes = [vp]
+        L.dgo_last_error.restype = ctypes.c_char_p
+        L.dgo_state_dim.restype = i32
+        L.dgo_state_dim.argtypes = [vp]
+        L.dgo_state.restype = ctypes.POINTER(ctypes.c_double)
+        L.dgo_state.argtypes = [vp]
+        L.dgo_motor_cfg.restype = ctypes.POINTER(ctypes.c_double)
+        L.dgo_motor_cfg.argtypes = [vp]
+        L.dgo_reset.argtypes = [vp, vp, vp]
+        L.dgo_step.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp]
+        L.dgo_observe.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.dgo_frame_state.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.dgo_last_contact_count.restype = i32
+        L.dgo_last_contact_count.argtypes = [vp, i32]
+        L.dgo_last_iterations.restype = i32
+        L.dgo_last_iterations.argtypes = [vp, i32]
+        L.dgo_forward_dynamics.argtypes = [vp, i32, i32, vp, vp]
+        L.dgo_unit_response.argtypes = [vp, i32, i32, i32, vp]
+        L.dgo_ik.argtypes = [vp, i32, i32, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleBackend:
+    """fp64 oracle behind the HipBackend interface (CPU tensors, fp32 views for outputs)."""
+    def __init__(self, layout, num_envs, device=None, seed=0, env_index_base=0):
+        self.L = lib()
+        self.layout = layout
+        self.num_envs = int(num_envs)
+        self.device = torch.device('cpu')
+        I, F = layout.I, layout.F
+        self.handle = self.L.dgo_create(_p(I), I.size, _p(F), F.size, self.num_envs, seed, env_index_base)
+        if not self.handle:
+            raise RuntimeError('oracle: ' + self.L.dgo_last_error().decode())
+        self.state_dim = self.L.dgo_state_dim(self.handle)
+        self.act_dim, self.obs_dim, self.rew_dim, self.term_dim = layout.act_dim, layout.obs_dim, layout.rew_dim, layout.term_dim
+        self.n_links = layout.n_links
+        B = self.num_envs
+        self._state = np.ctypeslib.as_array(self.L.dgo_state(self.handle), shape=(B, self.state_dim))
+        self._mcfg = np.ctypeslib.as_array(self.L.dgo_motor_cfg(self.handle), shape=(max(self.n_links, 1), 3))
+        self.act = torch.zeros((B, max(self.act_dim, 1)), dtype=torch.float32)
+        self.obs64 = np.zeros((B, max(self.obs_dim, 1)))
+        self.rew64 = np.zeros((B, max(self.rew_dim, 1)))
+        self.term8 = np.zeros((B, max(self.term_dim, 1)), dtype=np.uint8)
+        self.rsum64 = np.zeros(B)
+        self.tflag8 = np.zeros(B, dtype=np.uint8)
+        self.obs = torch.zeros((B, max(self.obs_dim, 1)), dtype=torch.float32)
+        self.rew = torch.zeros((B, max(self.rew_dim, 1)), dtype=torch.float32)
+        self.term = torch.zeros((B, max(self.term_dim, 1)), dtype=torch.uint8)
+        self.rew_sum = torch.zeros(B, dtype=torch.float32)
+        self.term_flag = torch.zeros(B, dtype=torch.uint8)
+
+    def _publish(self):
+        self.obs.copy_(torch.from_numpy(self.obs64).float())
+        self.rew.copy_(torch.from_numpy(self.rew64).float())
+        self.term.copy_(torch.from_numpy(self.term8))
+        self.rew_sum.copy_(torch.from_numpy(self.rsum64).float())
+        self.term_flag.copy_(torch.from_numpy(self.tflag8))
+
+    def close(self):
+        if self.handle:
+            self.L.dgo_destroy(self.handle)
+            self.handle = None
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask.cpu().numpy().astype(np.uint8))
+        self.L.dgo_reset(self.handle, _p(m), _p(self.obs64))
+        self._publish()
+
+    def step(self, update_mask, actions=None):
+        act = (self.act if actions is None else actions).detach().cpu().numpy().astype(np.float64)
+        act = np.ascontiguousarray(act)
+        self.L.dgo_step(self.handle, _p(act) if self.act_dim else None, update_mask, _p(self.obs64), _p(self.rew64), _p(self.term8),
+                        _p(self.rsum64), _p(self.tflag8))
+        self._publish()
+
+    def observe(self):
+        self.L.dgo_observe(self.handle, _p(self.obs64), _p(self.rew64), _p(self.term8), _p(self.rsum64), _p(self.tflag8))
+        self._publish()
+
+    def frame_state(self, body, frame=-1, com=False):
+        out = np.zeros((self.num_envs, 13))
+        gf = -1 if frame < 0 else self.layout.I[0:0].size + self._global_frame(body, frame)
+        for e in range(self.num_envs):
+            self.L.dgo_frame_state(self.handle, e, body, gf, int(bool(com)), _p(out[e]))
+        return torch.from_numpy(out).float()
+
+    def frame_state64(self, body, frame=-1, com=False):
+        out = np.zeros((self.num_envs, 13))
+        gf = -1 if frame < 0 else self._global_frame(body, frame)
+        for e in range(self.num_envs):
+            self.L.dgo_frame_state(self.handle, e, body, gf, int(bool(com)), _p(out[e]))
+        return out
+
+    def _global_frame(self, body, frame):
+        from diy_gym_amd.scene import K
+        I = self.layout.I
+        FI = I[I[K.H_OFF_FRAME_I]:I[K.H_OFF_FRAME_I] + I[K.H_N_FRAMES] * K.FI_STRIDE].reshape(-1, K.FI_STRIDE)
+        idx = np.nonzero(FI[:, K.FI_BODY] == body)[0]
+        return int(idx[frame])
+
+    def motor_cfg(self):
+        return self._mcfg[:self.n_links].copy()
+
+    def set_motor_cfg(self, cfg):
+        self._mcfg[:self.n_links] = cfg
+
+    def get_state(self):
+        return self._state.copy()
+
+    def set_state(self, arr):
+        self._state[:] = arr
+
+    def contacts(self, env=0):
+        return self.L.dgo_last_contact_count(self.handle, env)
+
+    def iterations(self, env=0):
+        return self.L.dgo_last_iterations(self.handle, env)
+
+    def forward_dynamics(self, env, body, n):
+        qdd = np.zeros(max(n, 1))
+        a0 = np.zeros(6)
+        self.L.dgo_forward_dynamics(self.handle, env, body, _p(qdd), _p(a0))
+        return qdd[:n], a0
+
+    def unit_response(self, env, body, dof, n):
+        dv = np.zeros(6 + n)
+        self.L.dgo_unit_response(self.handle, env, body, dof, _p(dv))
+        return dv
+
+    def ik(self, env, op_index, action, n):
+        q = np.zeros(n)
+        a = np.ascontiguousarray(np.asarray(action, dtype=np.float64))
+        self.L.dgo_ik(self.handle, env, op_index, _p(a), _p(q))
+        return q

@@ -116,28 +116,42 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // ---- LDS plan (slots per lane)
   std::vector<int32_t> plan((size_t)nb * PLB_STRIDE + (size_t)nl * PLL_STRIDE);
   int32_t* PLB = plan.data(); int32_t* PLL = plan.data() + (size_t)nb * PLB_STRIDE;
-  int slot = 0, nvmax = 0, nmax = 0;
+  int slot = 0, nvmax = 0, nmax = 0; bool any_float = false;
   for (int b = 0; b < nb; b++) {
     const int32_t* B = BI + b * DG_BI_STRIDE; const bool fx = B[DG_BI_FLAGS] & DG_BODY_FIXED; const int n = B[DG_BI_N_LINKS];
     const int nv = (fx ? 0 : 6) + n;
-    PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 9;
+    if (!fx) any_float = true;
+    PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6;
     PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * (nv + 1) / 2;
     PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += nv;
     PLB[b * PLB_STRIDE + PLB_NV] = nv;
     nvmax = std::max(nvmax, nv); nmax = std::max(nmax, n);
   }
-  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 12; PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; }
+  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 9; PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; PLL[l * PLL_STRIDE + PLL_IAACC] = -1; }
   const int maxc = I[DG_H_MAX_CONTACTS];
   const int cont_off = slot; slot += 1 + maxc * CL_STRIDE;
-  int tr = AB_STRIDE + nmax * AW_STRIDE;
-  tr = std::max(tr, 3 * maxc * (4 * nvmax + 7));
+  const int ab_stride = any_float ? AB_FLOAT_STRIDE : AB_FIXED_STRIDE;
+  // transient region: ABA workspace (+ inertia accumulators for links with a child that is not link+1),
+  // contact rows, IK scratch -- never live at the same time
+  const int tr_off = slot;
+  int tr = 0;
+  for (int b = 0; b < nb; b++) {
+    const int32_t* B = BI + b * DG_BI_STRIDE; const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    int need = ab_stride + n * AW_STRIDE;
+    for (int i = 0; i < n; i++) {
+      const int par = LI[(first + i) * DG_LI_STRIDE + DG_LI_PARENT];
+      if (par >= 0 && par != first + i - 1 && PLL[par * PLL_STRIDE + PLL_IAACC] < 0) { PLL[par * PLL_STRIDE + PLL_IAACC] = tr_off + need; need += 21; }
+    }
+    tr = std::max(tr, need);
+  }
+  tr = std::max(tr, 3 * maxc * (4 * nvmax + 3));
   for (int op = 0; op < I[DG_H_N_OPS]; op++)
     if (OI[op * DG_OI_STRIDE + DG_OI_CODE] == DG_OP_IK_CONTROL) {
       const int n = BI[OI[op * DG_OI_STRIDE + DG_OI_BODY] * DG_BI_STRIDE + DG_BI_N_LINKS];
       if (!(OI[op * DG_OI_STRIDE + DG_OI_FLAGS] & DG_IK_NULLSPACE)) { delete w; return fail(DG_ERR_UNSUPPORTED, "joint-space DLS IK (non null-space variant) is not implemented on device yet"); }
       tr = std::max(tr, 9 * n);
     }
-  const int tr_off = slot; slot += tr;
+  slot += tr;
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
   while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
@@ -159,7 +173,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
   sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
-  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total;
+  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
@@ -173,7 +187,6 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     for (int k = 0; k < 3; k++) init[so + DG_BS_POS + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_POS + k];
     for (int k = 0; k < 4; k++) init[so + DG_BS_QUAT + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_QUAT + k];
   }
-  (void)LI;
   HIP_TRY(hipMalloc((void**)&w->d_init, sizeof(float) * init.size())); HIP_TRY(hipMemcpy(w->d_init, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
   // allow > 64 KiB of dynamic LDS
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))

@@ -36,7 +36,7 @@ struct DevScene {
   const int32_t* PLL;  // per link: [pose_off, mrow_off]
   int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
-  int32_t tr_off, tr_slots, cont_off, nv_max, total_slots;  // LDS plan
+  int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
   int32_t num_envs, stride;
   uint64_t seed; int64_t env_base;
   float h, gx, gy, gz;
@@ -44,13 +44,15 @@ struct DevScene {
 struct MotorTable { float v[DG_MAX_LINKS * 3]; };  // kp, kd, max_force (<0 raw impulse)
 
 enum { PLB_R0 = 0, PLB_MINV, PLB_DV, PLB_NV, PLB_STRIDE };
-enum { PLL_POSE = 0, PLL_MROW, PLL_STRIDE };
-// transient ABA workspace per link
-enum { AW_E = 0, AW_R = 9, AW_V = 12, AW_PA = 18, AW_U = 24, AW_D = 30, AW_UU = 31, AW_IA = 32, AW_STRIDE = 53 };
-// transient base block (before the per-link blocks)
-enum { AB_IA = 0, AB_PA = 21, AB_L = 27, AB_V = 48, AB_A = 54, AB_STRIDE = 60 };
-// contact list entry
-enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_STRIDE = 8 };
+enum { PLL_POSE = 0, PLL_MROW, PLL_IAACC /* LDS accumulator for children that are not link+1, or -1 */, PLL_STRIDE };
+// transient ABA workspace per link.  Articulated inertias are NOT stored per link: along a chain
+// (parent == link - 1) the child's contribution is carried in registers; only links with a child that
+// is not their immediate successor get a 21-slot LDS accumulator (PLL_IAACC).
+enum { AW_E = 0, AW_R = 9, AW_V = 12, AW_PA = 18, AW_U = 24, AW_D = 30, AW_UU = 31, AW_STRIDE = 32 };
+// transient base block (before the per-link blocks): V, A always; IA, PA, L only when a floating base exists
+enum { AB_V = 0, AB_A = 6, AB_FIXED_STRIDE = 12, AB_IA = 12, AB_PA = 33, AB_L = 39, AB_FLOAT_STRIDE = 60 };
+// contact list entry (body info is per lane: the pair id differs between lanes)
+enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_DVA = 8, CL_NVA = 9, CL_DVB = 10, CL_NVB = 11, CL_STRIDE = 12 };
 // motor / limit row block per link: b_motor acc_motor b_lo acc_lo b_hi acc_hi
 enum { MR_B = 0, MR_ACC, MR_LO_B, MR_LO_ACC, MR_HI_B, MR_HI_ACC, MR_STRIDE };
 
@@ -73,6 +75,12 @@ struct Lane {
   DGD void L3set(int o, V3 v) const { L(o) = v.x; L(o + 1) = v.y; L(o + 2) = v.z; }
   DGD M3 LM(int o) const { M3 A; _Pragma("unroll") for (int k = 0; k < 9; k++) A.m[k] = L(o + k); return A; }
   DGD void LMset(int o, const M3& A) const { _Pragma("unroll") for (int k = 0; k < 9; k++) L(o + k) = A.m[k]; }
+  // POSE entries: first two columns of R (6 slots), then the position (3 slots)
+  DGD M3 LR(int o) const {
+    V3 c0 = v3(L(o), L(o + 1), L(o + 2)), c1 = v3(L(o + 3), L(o + 4), L(o + 5)), c2 = cross(c0, c1);
+    M3 R = {{c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z}}; return R;
+  }
+  DGD void LRset(int o, const M3& R) const { L(o) = R.m[0]; L(o + 1) = R.m[3]; L(o + 2) = R.m[6]; L(o + 3) = R.m[1]; L(o + 4) = R.m[4]; L(o + 5) = R.m[7]; }
   DGD S6 L6(int o) const { S6 s = {L3(o), L3(o + 3)}; return s; }
   DGD void L6set(int o, const S6& s) const { L3set(o, s.a); L3set(o + 3, s.l); }
   DGD void L6add(int o, const S6& s) const { L(o) += s.a.x; L(o + 1) += s.a.y; L(o + 2) += s.a.z; L(o + 3) += s.l.x; L(o + 4) += s.l.y; L(o + 5) += s.l.z; }
@@ -109,8 +117,8 @@ struct Lane {
 
   // link (global index, -1 = base of body b) world frame from the POSE region
   DGD void link_world(int b, int gl, M3& R, V3& p) const {
-    if (gl < 0) { R = LM(plb(b)[PLB_R0]); p = base_pos(b); }
-    else { int o = pll(gl)[PLL_POSE]; R = LM(o); p = L3(o + 9); }
+    if (gl < 0) { R = LR(plb(b)[PLB_R0]); p = base_pos(b); }
+    else { int o = pll(gl)[PLL_POSE]; R = LR(o); p = L3(o + 6); }
   }
 
   // parent->child rotation (Rpc) and offset r for link gl at joint value q
@@ -129,15 +137,15 @@ struct Lane {
     const int32_t* B = bi(b);
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
-    LMset(plb(b)[PLB_R0], R0);
+    LRset(plb(b)[PLB_R0], R0);
     for (int i = 0; i < n; i++) {
       int gl = first + i, par = li(gl)[DG_LI_PARENT];
       float q = qoff >= 0 ? L(qoff + i) : S(li(gl)[DG_LI_STATE_OFF] + DG_LS_Q);
       M3 Rpc; V3 r; joint_xform(gl, q, Rpc, r);
       M3 Rp; V3 pp;
-      if (par < 0) { Rp = R0; pp = p0; } else { int o = pll(par)[PLL_POSE]; Rp = LM(o); pp = L3(o + 9); }
+      if (par < 0) { Rp = R0; pp = p0; } else { int o = pll(par)[PLL_POSE]; Rp = LR(o); pp = L3(o + 6); }
       int o = pll(gl)[PLL_POSE];
-      LMset(o, mul(Rp, Rpc)); L3set(o + 9, pp + mul(Rp, r));
+      LRset(o, mul(Rp, Rpc)); L3set(o + 6, pp + mul(Rp, r));
     }
   }
 
@@ -169,7 +177,7 @@ struct Lane {
       unsigned long long path = 0ull; for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) path |= 1ull << (k - first);
       for (int k = first; k <= gl; k++) {
         if (!((path >> (k - first)) & 1ull)) continue;
-        int po_off = pll(k)[PLL_POSE]; M3 Rk = LM(po_off); V3 pk = L3(po_off + 9);
+        int po_off = pll(k)[PLL_POSE]; M3 Rk = LR(po_off); V3 pk = L3(po_off + 6);
         const float* f = lf(k); V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
         float qd = S(li(k)[DG_LI_STATE_OFF] + DG_LS_QD);
         vl = vl + cross(wl, pk - po);  // move the reference point to this link's origin (parent's angular velocity)
@@ -181,7 +189,7 @@ struct Lane {
   }
 
   // ------------------------------------------------- articulated-body pass
-  DGD int aw(int i) const { return sc.tr_off + AB_STRIDE + i * AW_STRIDE; }
+  DGD int aw(int i) const { return sc.tr_off + sc.ab_stride + i * AW_STRIDE; }
   DGD int ab() const { return sc.tr_off; }
 
   DGD S6 damping_force(float m, V3 c, const Sym3& Ic, const S6& v) const {
@@ -205,7 +213,7 @@ struct Lane {
     const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     const bool fx = fixed(b); const float h = sc.h;
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV], nb6 = fx ? 0 : 6;
-    M3 R0 = LM(plb(b)[PLB_R0]);
+    M3 R0 = LR(plb(b)[PLB_R0]);
     // ---- pass 1
     S6 v0 = {v3(0, 0, 0), v3(0, 0, 0)};
     if (!fx) {
@@ -231,14 +239,30 @@ struct Lane {
       AI I = rigid_inertia(f[DG_LF_MASS], c, Ic);
       S6 pA = crf(v, mul(I, v)) - damping_force(f[DG_LF_MASS], c, Ic, v);
       int o = aw(i);
-      LMset(o + AW_E, E); L3set(o + AW_R, r); L6set(o + AW_V, v); L6set(o + AW_PA, pA); LAIset(o + AW_IA, I);
+      LMset(o + AW_E, E); L3set(o + AW_R, r); L6set(o + AW_V, v); L6set(o + AW_PA, pA);
+      const int acc = pll(gl)[PLL_IAACC];
+      if (acc >= 0) { for (int k = 0; k < 21; k++) L(acc + k) = 0.f; }
     }
+    AI carry; int carry_parent = -2;  // contribution of link i+1 to link i, kept in registers along chains
     // ---- pass 2
     for (int i = n - 1; i >= 0; i--) {
       int gl = first + i, par = li(gl)[DG_LI_PARENT]; const float* f = lf(gl); int o = aw(i);
       int lo = li(gl)[DG_LI_STATE_OFF]; float qd = S(lo + DG_LS_QD);
       float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd;
-      AI IA = LAI(o + AW_IA); S6 Sx = subspace(gl); S6 pA = L6(o + AW_PA); S6 v = L6(o + AW_V);
+      AI IA = rigid_inertia(f[DG_LF_MASS], v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]), sym6(f + DG_LF_INERTIA));
+      if (carry_parent == gl) {
+        IA.I.xx += carry.I.xx; IA.I.xy += carry.I.xy; IA.I.xz += carry.I.xz; IA.I.yy += carry.I.yy; IA.I.yz += carry.I.yz; IA.I.zz += carry.I.zz;
+        IA.M.xx += carry.M.xx; IA.M.xy += carry.M.xy; IA.M.xz += carry.M.xz; IA.M.yy += carry.M.yy; IA.M.yz += carry.M.yz; IA.M.zz += carry.M.zz;
+#pragma unroll
+        for (int k = 0; k < 9; k++) IA.H.m[k] += carry.H.m[k];
+      }
+      { const int acc = pll(gl)[PLL_IAACC];
+        if (acc >= 0) { AI t = LAI(acc);
+          IA.I.xx += t.I.xx; IA.I.xy += t.I.xy; IA.I.xz += t.I.xz; IA.I.yy += t.I.yy; IA.I.yz += t.I.yz; IA.I.zz += t.I.zz;
+          IA.M.xx += t.M.xx; IA.M.xy += t.M.xy; IA.M.xz += t.M.xz; IA.M.yy += t.M.yy; IA.M.yz += t.M.yz; IA.M.zz += t.M.zz;
+#pragma unroll
+          for (int k = 0; k < 9; k++) IA.H.m[k] += t.H.m[k]; } }
+      S6 Sx = subspace(gl); S6 pA = L6(o + AW_PA); S6 v = L6(o + AW_V);
       S6 U = mul(IA, Sx); float d = dot(Sx, U); float u = tau - dot(Sx, pA); float dinv = 1.0f / d;
       L6set(o + AW_U, U); L(o + AW_D) = d; L(o + AW_UU) = u;
       if (par >= 0 || !fx) {
@@ -257,8 +281,11 @@ struct Lane {
         S6 pa = pA + mul(Ia, c) + U * (u * dinv);
         M3 E = LM(o + AW_E); V3 r = L3(o + AW_R);
         AI Ip = to_parent(Ia, E, r); S6 pf = xforce_to_parent(E, r, pa);
-        int po = par < 0 ? ab() : aw(par - first);
-        LAIadd(po + (par < 0 ? AB_IA : AW_IA), Ip); L6add(po + (par < 0 ? AB_PA : AW_PA), pf);
+        if (par < 0) { LAIadd(ab() + AB_IA, Ip); L6add(ab() + AB_PA, pf); }
+        else {
+          L6add(aw(par - first) + AW_PA, pf);
+          if (par == gl - 1) { carry = Ip; carry_parent = par; } else LAIadd(pll(par)[PLL_IAACC], Ip);
+        }
       }
     }
     // ---- base
@@ -347,7 +374,7 @@ struct Lane {
     const int32_t* B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     float r = 0.f; int k = 0;
     if (!fixed(b)) {
-      M3 R0 = LM(plb(b)[PLB_R0]);
+      M3 R0 = LR(plb(b)[PLB_R0]);
       V3 wb = tmul(R0, v3(S(so + DG_BS_ANGVEL), S(so + DG_BS_ANGVEL + 1), S(so + DG_BS_ANGVEL + 2)));
       V3 vb = tmul(R0, v3(S(so + DG_BS_LINVEL), S(so + DG_BS_LINVEL + 1), S(so + DG_BS_LINVEL + 2)));
       r = L(jo) * wb.x + L(jo + 1) * wb.y + L(jo + 2) * wb.z + L(jo + 3) * vb.x + L(jo + 4) * vb.y + L(jo + 5) * vb.z; k = 6;
@@ -362,11 +389,11 @@ struct Lane {
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV]; int k0 = 0;
     for (int k = 0; k < nv; k++) L(jo + k) = 0.f;
     if (!fixed(b)) {
-      M3 R0 = LM(plb(b)[PLB_R0]); V3 ja = tmul(R0, cross(p - base_pos(b), dir)), jl = tmul(R0, dir);
+      M3 R0 = LR(plb(b)[PLB_R0]); V3 ja = tmul(R0, cross(p - base_pos(b), dir)), jl = tmul(R0, dir);
       L3set(jo, ja); L3set(jo + 3, jl); k0 = 6;
     }
     for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) {
-      int po = pll(k)[PLL_POSE]; M3 Rk = LM(po); V3 pk = L3(po + 9); const float* f = lf(k);
+      int po = pll(k)[PLL_POSE]; M3 Rk = LR(po); V3 pk = L3(po + 6); const float* f = lf(k);
       V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
       L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
     }

@@ -131,8 +131,8 @@ DGD int collide(const Lane<LANES>& ln) {
 
 // ------------------------------------------------------------------- rows
 // contact row r (3 per contact: normal, t1, t2) in the transient region:
-//   [JA nvmax][RA nvmax][JB nvmax][RB nvmax][b][acc][diag][dvA][nvA][dvB][nvB]
-DGD int crow_stride(int nvmax) { return 4 * nvmax + 7; }
+//   [JA nvmax][RA nvmax][JB nvmax][RB nvmax][b][acc][diag]     (dv offsets / lengths live in the contact list)
+DGD int crow_stride(int nvmax) { return 4 * nvmax + 3; }
 
 DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
   if (fabsf(n.z) > 0.70710678118654752f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); t1 = v3(0.f, -n.z * k, n.y * k); t2 = v3(a * k, -n.x * t1.z, n.x * t1.y); }
@@ -157,11 +157,11 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
     // first side = the dynamic one of (A, B); the oracle makes the same choice
     int b1 = a_dyn ? ba : bb, l1 = a_dyn ? la : lb; V3 d1 = a_dyn ? dir : -dir;
     diag += ln.point_row(b1, l1, p, d1, ro, ro + nvm); jv += ln.gen_vel_dot(b1, ro);
-    ln.L(ro + 4 * nvm + 3) = (float)ln.plb(b1)[PLB_DV]; ln.L(ro + 4 * nvm + 4) = (float)ln.plb(b1)[PLB_NV];
+    ln.L(co + CL_DVA) = (float)ln.plb(b1)[PLB_DV]; ln.L(co + CL_NVA) = (float)ln.plb(b1)[PLB_NV];
     if (a_dyn && b_dyn) {
       diag += ln.point_row(bb, lb, p, -dir, ro + 2 * nvm, ro + 3 * nvm); jv += ln.gen_vel_dot(bb, ro + 2 * nvm);
-      ln.L(ro + 4 * nvm + 5) = (float)ln.plb(bb)[PLB_DV]; ln.L(ro + 4 * nvm + 6) = (float)ln.plb(bb)[PLB_NV];
-    } else { ln.L(ro + 4 * nvm + 5) = 0.f; ln.L(ro + 4 * nvm + 6) = 0.f; }
+      ln.L(co + CL_DVB) = (float)ln.plb(bb)[PLB_DV]; ln.L(co + CL_NVB) = (float)ln.plb(bb)[PLB_NV];
+    } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
     if (d == 0) { float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
     ln.L(ro + 4 * nvm) = b; ln.L(ro + 4 * nvm + 1) = 0.f; ln.L(ro + 4 * nvm + 2) = diag;
@@ -170,10 +170,10 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
 
 // one PGS update of contact row at ro; returns the squared velocity residual
 template <int LANES>
-DGD float solve_crow(const Lane<LANES>& ln, int ro, float lo, float hi, bool live, bool has) {
+DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, bool live, bool has) {
   if (!has) return 0.f;  // lanes without this contact slot hold no row data at all
   const int nvm = ln.sc.nv_max;
-  const int dA = (int)ln.L(ro + 4 * nvm + 3), nA = (int)ln.L(ro + 4 * nvm + 4), dB = (int)ln.L(ro + 4 * nvm + 5), nB = (int)ln.L(ro + 4 * nvm + 6);
+  const int dA = (int)ln.L(co + CL_DVA), nA = (int)ln.L(co + CL_NVA), dB = (int)ln.L(co + CL_DVB), nB = (int)ln.L(co + CL_NVB);
   float jv = 0.f;
   for (int k = 0; k < nvm; k++) { if (k < nA) jv += ln.L(ro + k) * ln.L(dA + k); if (k < nB) jv += ln.L(ro + 2 * nvm + k) * ln.L(dB + k); }
   float diag = ln.L(ro + 4 * nvm + 2), acc = ln.L(ro + 4 * nvm + 1);
@@ -260,7 +260,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
     }
     for (int c = 0; c < wave_max_cont; c++) {  // contact normals
       const bool has = c < ncont;
-      float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, 0.f, 3.0e38f, live, has);
+      float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, sc.cont_off + 1 + c * CL_STRIDE, 0.f, 3.0e38f, live, has);
       if (has) maxres = fmaxf(maxres, r);
     }
     for (int c = 0; c < wave_max_cont; c++) {  // friction
@@ -271,7 +271,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
       const bool act = has && mu > 0.f;
       const float lim = act ? mu * ln.L(sc.tr_off + (3 * c) * rs + 4 * nvm + 1) : 0.f;
 #pragma unroll
-      for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
+      for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
     }
     if (live) iters_done = it + 1;
     live = live && !(maxres <= thr);
@@ -289,7 +289,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
     const bool fx = ln.fixed(b); if (fx && n == 0) continue;
     const int dvo = ln.plb(b)[PLB_DV];
     if (!fx) {
-      M3 R0 = ln.LM(ln.plb(b)[PLB_R0]);
+      M3 R0 = ln.LR(ln.plb(b)[PLB_R0]);
       V3 dw = mul(R0, ln.L3(dvo)), dl = mul(R0, ln.L3(dvo + 3));
       V3 w = v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2)) + dw;
       V3 v = v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)) + dl;
@@ -354,7 +354,7 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
     // Jacobian columns (world frame) for the chain root -> end-effector link, zero elsewhere
     for (int i = 0; i < 6 * n; i++) ln.L(jo + i) = 0.f;
     for (int k = eel; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
-      int po = ln.pll(k)[PLL_POSE]; M3 Rk = ln.LM(po); V3 pk = ln.L3(po + 9); const float* f = ln.lf(k);
+      int po = ln.pll(k)[PLL_POSE]; M3 Rk = ln.LR(po); V3 pk = ln.L3(po + 6); const float* f = ln.lf(k);
       V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2])); int i = k - first;
       V3 jl, ja; if (ln.li(k)[DG_LI_TYPE] == 0) { jl = cross(axw, fp - pk); ja = axw; } else { jl = axw; ja = v3(0, 0, 0); }
       ln.L(jo + i) = jl.x; ln.L(jo + n + i) = jl.y; ln.L(jo + 2 * n + i) = jl.z;

@@ -63,7 +63,7 @@ class DIYGym(Receptor):
         self.builder = SceneBuilder(timestep=timestep, substeps=sub_steps, solver_iterations=iterations, gravity=gravity,
                                     max_episode_steps=self._max_episode_steps, hot_start=self.hot_start,
                                     rew_mode=K.COLLAPSE_SUM if self.collapse_rewards_func else K.COLLAPSE_NONE,
-                                    term_mode=term_mode, **(engine or {}))
+                                    term_mode=term_mode, max_contacts=config.get('max_contacts', None), **(engine or {}))
 
         # models in YAML order (body ids follow it), stored sorted by name (diy_gym.py:84-86)
         built = [(child.name, Model(child, env=self)) for child in config.find_all('model')]

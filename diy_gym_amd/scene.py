@@ -108,7 +108,7 @@ class OpHandle:
 
 class SceneBuilder:
     def __init__(self, timestep=1.0 / 240.0, substeps=2, solver_iterations=150, gravity=(0.0, 0.0, -9.81),
-                 max_episode_steps=None, hot_start=1, rew_mode=0, term_mode=0, **overrides):
+                 max_episode_steps=None, hot_start=1, rew_mode=0, term_mode=0, max_contacts=None, **overrides):
         self.timestep = float(timestep)
         self.substeps = max(int(substeps), 1)
         self.solver_iterations = int(solver_iterations)
@@ -117,6 +117,7 @@ class SceneBuilder:
         self.hot_start = int(hot_start)
         self.rew_mode = rew_mode
         self.term_mode = term_mode
+        self.max_contacts = max_contacts
         self.params = dict(DEFAULTS)
         for k, v in overrides.items():
             if k not in self.params:
@@ -249,7 +250,7 @@ class SceneBuilder:
 
         # candidate collision pairs: different bodies, at least one of them able to move,
         # and a narrow-phase routine exists for the pair (no box-box)
-        pairs, max_contacts = [], 0
+        pairs, max_contacts, static_pairs = [], 0, 0
         for a in range(len(shape_i)):
             for c in range(a + 1, len(shape_i)):
                 if shape_i[a][1] == shape_i[c][1] or not (shape_dyn[a] or shape_dyn[c]):
@@ -259,13 +260,17 @@ class SceneBuilder:
                     continue
                 pairs.append([a, c])
                 kinds = {ta, tc}
-                if kinds == {SHAPE_POINTS, SHAPE_BOX}:
-                    max_contacts += 4
-                elif kinds == {SHAPE_CAPSULE, SHAPE_BOX}:
-                    max_contacts += 2
-                else:
-                    max_contacts += 1
-        max_contacts = min(max_contacts, 32)
+                per_pair = 4 if kinds == {SHAPE_POINTS, SHAPE_BOX} else 2 if kinds == {SHAPE_CAPSULE, SHAPE_BOX} else 1
+                max_contacts += per_pair
+                if not (shape_dyn[a] and shape_dyn[c]):
+                    static_pairs += per_pair
+        # Contact budget per env (rows live in LDS).  Default: every contact a moving shape can have
+        # with the static world, plus a small pool for moving-vs-moving contacts; `max_contacts`
+        # in the env config overrides it.  Contacts beyond the budget are dropped in pair order --
+        # by the oracle and the kernels alike.
+        n_dyn = sum(1 for b in self.bodies if not (b[0].fixed_base and len(b[0].links) == 0))
+        budget = self.max_contacts if self.max_contacts is not None else max(4, static_pairs + n_dyn)
+        max_contacts = min(max_contacts, int(budget), 32)
 
         def arr(rows, width, dtype):
             if not rows:

@@ -11,7 +11,7 @@
 //   reset_kernel  : DIYGym.reset (diy_gym.py:130-148), per-env masked
 //   observe_kernel: DIYGym.observe/reward/is_terminal (diy_gym.py:150-185)
 //
-// Algorithm per substep (same mathematics as oracle/dgsim_oracle.c, different
+// Algorithm per substep (same mathematics as the fp64 CPU checker under oracle/, different
 // organisation): world kinematics -> narrow-phase contacts -> per body:
 // articulated-body algorithm in link coordinates (block-form articulated
 // inertias) + velocity update + the body's inverse mass matrix M^-1 from ABA

@@ -21,6 +21,7 @@ attributes.  Differences, all additive:
 physics step and the sensor / reward / terminal addons all run inside one HIP
 kernel launch (``dg_world_step``).
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -42,6 +43,7 @@ class DIYGym(Receptor):
         Receptor.__init__(self)
         config = config_file if isinstance(config_file, Configuration) else Configuration.from_file(config_file)
         self.env = self
+        self.config_dir = os.path.dirname(os.path.abspath(config_file)) if isinstance(config_file, str) else ''
         self.name = config.name
         self.compat = num_envs is None
         self.num_envs = 1 if num_envs is None else int(num_envs)
@@ -97,6 +99,10 @@ class DIYGym(Receptor):
         self._has_hook_rewards = any(type(a).reward is not Addon.reward for a in self._hook_addons)
         self._has_hook_terminals = any(type(a).is_terminal is not Addon.is_terminal for a in self._hook_addons)
 
+        # zero-copy flat paths are valid when every addon is compiled and none is hidden
+        visible = all(not a.hide for r in self.receptors.values() for a in r.addons.values())
+        self._flat_fast = visible and not self._hook_addons
+
         self.seed(seed)
         self.reset()
 
@@ -107,9 +113,6 @@ class DIYGym(Receptor):
                 self.observation_space.spaces[name] = obs_space
             if len(act_space.spaces):
                 self.action_space.spaces[name] = act_space
-        # zero-copy flat paths are valid when every addon is compiled and none is hidden
-        visible = all(not a.hide for r in self.receptors.values() for a in r.addons.values())
-        self._flat_fast = visible and not self._hook_addons
         if self.flatten_observations:
             lows, highs = [flatten(get_bounds_for_space(self.observation_space, opt)) for opt in [True, False]]
             self.original_observation_space = self.observation_space
@@ -123,7 +126,7 @@ class DIYGym(Receptor):
     def _out(self, t):
         if not self.compat:
             return t
-        a = t[0].detach().cpu().numpy()
+        a = np.array(t[0].detach().cpu().numpy(), copy=True)  # a snapshot, like the reference's fresh arrays
         return a if a.ndim else a.item()
 
     def _obs_view(self, off, n):

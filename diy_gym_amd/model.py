@@ -44,7 +44,7 @@ class Model(Receptor):
         urdf = config.get('model')
 
         full = None
-        for root in urdf_search_path():
+        for root in urdf_search_path() + [getattr(self.env, 'config_dir', '')]:
             cand = os.path.join(root, urdf)
             if os.path.isfile(cand):
                 full = cand

@@ -1105,8 +1105,18 @@ int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
 int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* obs, double* rew, uint8_t* term, double* rew_sum,
              uint8_t* term_flag) {
   Scene* s = &w->sc;
-  /* motor configuration is uniform over envs: apply ops env by env (idempotent) */
-  for (int e = 0; e < w->B; e++) {
+  /* envs are independent; the motor table is uniform over envs and every env writes the same values
+   * into it, so it is brought up to date by env 0 first and the remaining envs can run in parallel */
+  int e0 = 0;
+  if (w->B > 0) {
+    double* st = env_state(w, 0);
+    if (actions) run_update_ops(w, 0, actions, update_mask);
+    st[DG_ST_STEP] += 1.0; sim_step(w, 0); e0 = 1;
+  }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int e = e0; e < w->B; e++) {
     double* st = env_state(w, e);
     if (actions) run_update_ops(w, e, actions + (size_t)e * s->act_dim, update_mask);
     st[DG_ST_STEP] += 1.0;

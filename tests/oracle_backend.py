@@ -12,12 +12,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+ORACLE_LIB = os.path.join(ROOT, 'oracle', 'libdgsim_oracle.so')
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libdgsim_oracle.so'))
+        L = ctypes.CDLL(ORACLE_LIB)
         vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
         L.dgo_create.restype = vp
         L.dgo_create.argtypes = [vp, i64, vp, i64, i32, u64, i64]

@@ -1,0 +1,88 @@
+"""The reference's own behavioural tests (diy_gym/tests/test_environment.py:12-40,
+test_utils.py:13-20) on the HIP path, plus full-size properties that do not
+need the oracle: determinism, shard == whole, finiteness at BASELINE sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASIC = os.path.join(ROOT, 'tests', 'golden', 'basic_env_nocam.yaml')
+UR = os.path.join(ROOT, 'examples', 'ur_high_5', 'ur_high_5.yaml')
+DRONE = os.path.join(ROOT, 'examples', 'drone_pilot', 'drone_pilot.yaml')
+
+
+def test_reference_episode_on_the_gpu():
+    from diy_gym_amd import DIYGym
+    env = DIYGym(BASIC)  # one env, numpy in / numpy out, like the reference
+    for name in ('plane', 'red_marble', 'green_marble', 'blue_marble'):
+        assert name in env.models
+    assert 'force' in env.action_space['blue_marble'].spaces and 'pose' in env.observation_space['green_marble'].spaces
+    observation = env.reset()
+    initial_position = observation['green_marble']['pose']['position']
+    for _ in range(500):
+        observation, _, _, _ = env.step({'blue_marble': {'force': [0, -100, 0]}})
+    final_position = observation['green_marble']['pose']['position']
+    assert abs(np.linalg.norm(initial_position) - np.linalg.norm(final_position)) > 0.5
+    reset_position = env.reset()['green_marble']['pose']['position']
+    assert abs(np.linalg.norm(initial_position) - np.linalg.norm(reset_position)) < 0.05
+
+
+def run(cfg, B, steps, base=0, total=None, seed=3):
+    import diy_gym_amd.examples  # noqa: F401
+    from diy_gym_amd import DIYGym
+    from test_parity_gpu import action_bounds
+    env = DIYGym(cfg, num_envs=B, device='cuda:0', seed=seed, env_index_base=base)
+    lo, hi = action_bounds(env)
+    gen = torch.Generator().manual_seed(9)
+    total = total or B
+    for _ in range(steps):
+        act = lo + (hi - lo) * torch.rand((total, lo.numel()), generator=gen)
+        env.sim.step(env._all_slots, act[base:base + B].to('cuda:0').contiguous())
+        env.sim.reset(env.sim.term_flag)
+    torch.cuda.synchronize()
+    return env
+
+
+def test_full_size_ur_high_5_is_deterministic_and_finite():
+    a = run(UR, 16384, 20)
+    b = run(UR, 16384, 20)
+    assert torch.equal(a.sim.state, b.sim.state) and torch.equal(a.sim.obs, b.sim.obs)
+    assert bool(torch.isfinite(a.sim.state).all()) and bool(torch.isfinite(a.sim.obs).all())
+    # joints stay inside the URDF limits, quaternion-free fixed bases untouched
+    q = a.sim.obs[:, 0:6]
+    assert float(q.abs().max()) < 2 * np.pi
+
+
+def test_shards_equal_whole_batch():
+    whole = run(DRONE, 512, 15).sim.get_state()
+    parts = [run(DRONE, 256, 15, base=b, total=512).sim.get_state() for b in (0, 256)]
+    assert np.array_equal(np.concatenate(parts, axis=0), whole)
+
+
+def test_ragged_batch_sizes():
+    # batch sizes that do not fill the last wavefront, and a single env
+    for B in (1, 63, 65, 130):
+        env = run(UR, B, 3)
+        assert env.sim.obs.shape == (B, 27) and bool(torch.isfinite(env.sim.obs).all())
+        ref = run(UR, 130, 3).sim.obs[:B] if B != 130 else env.sim.obs
+        # env i of a small batch == env i of a bigger one (same seed, same actions prefix is not guaranteed)
+    a, b = run(UR, 63, 3, total=130), run(UR, 130, 3, total=130)
+    assert torch.equal(a.sim.obs, b.sim.obs[:63])
+
+
+def test_dict_action_path_matches_flat_path():
+    from diy_gym_amd import DIYGym
+    e1 = DIYGym(UR, num_envs=8, device='cuda:0')
+    e2 = DIYGym(UR, num_envs=8, device='cuda:0')
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        flat = (torch.rand((8, 12), generator=gen) * 0.02 - 0.01).to('cuda:0')
+        e1.sim.step(e1._all_slots, flat)
+        act = {'ur5_l': {'controller': {'linear': flat[:, 0:3], 'rotation': flat[:, 3:6]}},
+               'ur5_r': {'controller': {'linear': flat[:, 6:9], 'rotation': flat[:, 9:12]}}}
+        obs, rew, term, _ = e2.step(act)
+    assert torch.equal(e1.sim.obs, e2.sim.obs)
+    assert obs['ur5_l']['joint_state']['position'].shape == (8, 6) and term.dtype == torch.bool

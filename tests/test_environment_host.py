@@ -1,0 +1,150 @@
+"""Host-side behaviour of DIYGym, restating the reference's
+diy_gym/tests/test_environment.py:12-40 and test_utils.py:13-20.  The backend is
+the CPU oracle (injected from tests/), so these run without a GPU; the same
+assertions run on the HIP path in test_environment_gpu.py."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import diy_gym_amd.examples  # noqa: F401
+from diy_gym_amd import Addon, AddonFactory, DIYGym
+from diy_gym_amd.utils import flatten, unflatten
+from oracle_backend import OracleBackend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASIC = os.path.join(ROOT, 'tests', 'golden', 'basic_env_nocam.yaml')
+
+
+@pytest.fixture
+def env():
+    return DIYGym(BASIC, backend_factory=OracleBackend)
+
+
+def test_load_environment(env):
+    for name in ('plane', 'red_marble', 'green_marble', 'blue_marble'):
+        assert name in env.models
+    assert list(env.receptors) == ['basic_env_nocam', 'blue_marble', 'green_marble', 'plane', 'red_marble']
+    assert [env.models[n].uid for n in ('plane', 'red_marble', 'green_marble', 'blue_marble')] == [0, 1, 2, 3]  # YAML order
+
+
+def test_spaces(env):
+    assert 'force' in env.action_space['blue_marble'].spaces
+    assert 'pose' in env.observation_space['green_marble'].spaces
+    assert 'respawn' not in env.action_space['blue_marble'].spaces
+
+
+def test_episode(env):
+    """Reference test_environment.py:23-40, numpy in / numpy out, one env."""
+    observation = env.reset()
+    initial_position = observation['green_marble']['pose']['position']
+    assert isinstance(initial_position, np.ndarray) and initial_position.shape == (3, )
+    for _ in range(500):
+        observation, _, _, info = env.step({'blue_marble': {'force': [0, -100, 0]}})
+    final_position = observation['green_marble']['pose']['position']
+    assert abs(np.linalg.norm(initial_position) - np.linalg.norm(final_position)) > 0.5
+    assert info == {}
+    observation = env.reset()
+    reset_position = observation['green_marble']['pose']['position']
+    assert abs(np.linalg.norm(initial_position) - np.linalg.norm(reset_position)) < 0.05
+
+
+def test_flatten_unflatten(env):
+    action = env.action_space.sample()
+    back = unflatten(flatten(action), env.action_space)
+    assert np.all(action['red_marble']['force'] == back['red_marble']['force'])
+    assert np.all(action['blue_marble']['force'] == back['blue_marble']['force'])
+
+
+def test_only_named_addons_are_updated():
+    env = DIYGym(BASIC, num_envs=2, backend_factory=OracleBackend)
+    env.step({'red_marble': {'force': torch.tensor([[5.0, 0, 0], [0, 5.0, 0]])}})
+    assert env.sim.act[:, 3:6].tolist() == [[5.0, 0, 0], [0, 5.0, 0]]  # columns: blue(0:3), red(3:6)
+    assert env._mask == 0b10
+    env.step({'blue_marble': {'force': [1.0, 2.0, 3.0]}})
+    assert env._mask == 0b01 and env.sim.act[1, 0:3].tolist() == [1.0, 2.0, 3.0]
+
+
+def test_batched_outputs_are_views_and_collapse_modes():
+    cfg = os.path.join(ROOT, 'examples', 'drone_pilot', 'drone_pilot.yaml')
+    env = DIYGym(cfg, num_envs=4, backend_factory=OracleBackend)
+    assert env.collapse_terminals_func is any
+    act = {'drone': {'motor%d' % i: torch.full((4, 1), 0.5) for i in (1, 2, 3, 4)}}
+    obs, rew, term, _ = env.step(act)
+    assert obs['drone']['pose']['position'].shape == (4, 3) and obs['drone']['motor1'].shape == (4, 1)
+    assert list(obs['drone']['pose'].keys()) == ['position', 'velocity', 'rotation', 'angular_velocity']
+    off = env.models['drone'].addons['pose'].op.io_off  # motor1..4 come first (addons are name-sorted)
+    assert off == 4 and obs['drone']['pose']['position'].data_ptr() == env.sim.obs[:, off:off + 3].data_ptr()
+    assert rew['drone_pilot']['reach_goal'].shape == (4, ) and term.shape == (4, ) and term.dtype == torch.bool
+    assert float(obs['drone']['motor1'][0, 0]) == pytest.approx(0.05)  # first-order spool-up, drone_pilot.py:34
+    assert 'episode_timer' not in str(type(term))
+
+
+def test_terminal_dict_has_episode_timer_and_terminal_if_all():
+    cfg = os.path.join(ROOT, 'tests', 'golden', 'cart_tree.yaml')
+    env = DIYGym(cfg, num_envs=2, backend_factory=OracleBackend)
+    act = {'cart': {'drive': torch.zeros(2, 3)}}
+    for i in range(39):
+        _, _, term, _ = env.step(act)
+    # terminal_if_all: needs every receptor that owns terminals to fire; only 'cart_tree' owns any here
+    env.collapse_terminals_func = None
+    d = env.is_terminal()
+    assert list(d['cart_tree'].keys()) == ['near', 'episode_timer']
+    assert d['cart_tree']['episode_timer'].tolist() == [False, False]
+    env.step(act)
+    assert env.is_terminal()['cart_tree']['episode_timer'].tolist() == [True, True]
+    assert env.sim.term_flag.tolist() == [1, 1]
+
+
+def test_flat_paths_are_zero_copy(tmp_path):
+    import yaml
+    tree = yaml.safe_load(open(os.path.join(ROOT, 'examples', 'ur_high_5', 'ur_high_5.yaml')))
+    tree.update(flatten_observations=True, flatten_actions=True, sum_rewards=True)
+    for arm in ('ur5_l', 'ur5_r'):
+        tree[arm]['model'] = os.path.join(ROOT, 'diy_gym_amd', 'data', 'ur5', 'ur5_robot.urdf')
+    cfg = tmp_path / 'flat.yaml'
+    cfg.write_text(yaml.dump(tree))
+    env = DIYGym(str(cfg), num_envs=3, backend_factory=OracleBackend)
+    assert env.action_space.shape == (12, ) and env.observation_space.shape == (27, )
+    obs, rew, term, _ = env.step(torch.zeros(3, 12))
+    assert obs.shape == (3, 27) and obs.data_ptr() == env.sim.obs.data_ptr()
+    assert rew.shape == (3, ) and term.shape == (3, )
+    # flat layout == flatten() of the nested dict
+    env.flatten_observations = False
+    nested = env.observe(_refresh=False)
+    assert torch.equal(flatten(nested, batch_dims=1), obs)
+
+
+def test_custom_python_addon_still_works():
+    """User addons without compile() keep the reference's hook contract (addon.py:91-186)."""
+    class Counter(Addon):
+        def __init__(self, parent, config):
+            super().__init__(parent, config)
+            self.n = 0
+
+        def update(self, action):
+            self.n += 1
+
+        def reward(self):
+            return torch.full((self.env.num_envs, ), float(self.n))
+
+    AddonFactory.register_addon('counter', Counter)
+    from diy_gym_amd.config import Configuration
+    import yaml
+    tree = yaml.safe_load(open(BASIC))
+    tree['green_marble']['count'] = {'addon': 'counter'}
+    env = DIYGym(Configuration.from_dict('custom', tree), num_envs=2, backend_factory=OracleBackend)
+    _, rew, _, _ = env.step({'green_marble': {'count': None}})
+    assert rew['green_marble']['count'].tolist() == [1.0, 1.0]
+
+
+def test_error_conventions():
+    from diy_gym_amd.config import Configuration
+    with pytest.raises(KeyError):
+        DIYGym(Configuration.from_dict('e', {'x': {'addon': 'no_such_addon'}}), backend_factory=OracleBackend)
+    with pytest.raises(ValueError, match='Could not find URDF'):
+        DIYGym(Configuration.from_dict('e', {'x': {'model': 'nope.urdf'}}), backend_factory=OracleBackend)
+    with pytest.raises(NotImplementedError):
+        DIYGym(Configuration.from_dict('e', {'cam': {'addon': 'camera'}}), backend_factory=OracleBackend)

@@ -162,13 +162,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, I, sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_blob_f, sizeof(float) * (size_t)n_f)); HIP_TRY(hipMemcpy(w->d_blob_f, Ff.data(), sizeof(float) * (size_t)n_f, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
-  const int32_t* dI = (const int32_t*)w->d_blob_i; const float* dF = (const float*)w->d_blob_f;
+  // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
+  cip dI = (cip)w->d_blob_i; cfp dF = (cfp)w->d_blob_f;
   DevScene& sc = w->sc; memset(&sc, 0, sizeof sc);
   sc.BI = dI + I[DG_H_OFF_BODY_I]; sc.LI = dI + I[DG_H_OFF_LINK_I]; sc.FI = dI + I[DG_H_OFF_FRAME_I]; sc.SI = dI + I[DG_H_OFF_SHAPE_I];
   sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
-  sc.PLB = (const int32_t*)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE;
+  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE;
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
@@ -200,7 +201,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
 
 void dg_world_destroy(dg_world* w) {
   if (!w) return;
-  hipFree(w->d_blob_i); hipFree(w->d_blob_f); hipFree(w->d_plan); hipFree(w->d_init);
+  (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
   delete w;
 }
 

@@ -28,12 +28,20 @@ namespace dg {
 #define DG_MAX_LINKS 64   // total 1-DoF links in a scene (motor table travels in kernarg)
 #define DG_MAX_BODIES 192
 
+// Scene tables are immutable for the lifetime of a world.  Their pointers are typed as CONSTANT
+// address space (AS4) so that every wave-uniform read is provably invariant and becomes an s_load
+// through the scalar data cache; with plain global pointers the compiler must assume the state stores
+// may alias the tables and falls back to 64-lane vector loads of one address.
+#define DG_CONSTANT __attribute__((address_space(4)))
+typedef const int32_t DG_CONSTANT* cip;
+typedef const float DG_CONSTANT* cfp;
+
 // Everything wave-uniform the kernels need.  Passed by value (kernarg -> SGPRs / scalar loads).
 struct DevScene {
-  const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
-  const float *BF, *LF, *FF, *SF, *PF, *OF, *FL, *HF;
-  const int32_t* PLB;  // per body: [R0_off, minv_off, dv_off, nv]
-  const int32_t* PLL;  // per link: [pose_off, mrow_off]
+  cip BI, LI, FI, SI, PI, OI, IL;
+  cfp BF, LF, FF, SF, PF, OF, FL, HF;
+  cip PLB;  // per body: [R0_off, minv_off, dv_off, nv]
+  cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
   int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
@@ -102,12 +110,12 @@ struct Lane {
   }
 
   // ---- scene table accessors (wave-uniform indices) ----
-  DGD const int32_t* bi(int b) const { return sc.BI + b * DG_BI_STRIDE; }
-  DGD const float* bf(int b) const { return sc.BF + b * DG_BF_STRIDE; }
-  DGD const int32_t* li(int l) const { return sc.LI + l * DG_LI_STRIDE; }
-  DGD const float* lf(int l) const { return sc.LF + l * DG_LF_STRIDE; }
-  DGD const int32_t* plb(int b) const { return sc.PLB + b * PLB_STRIDE; }
-  DGD const int32_t* pll(int l) const { return sc.PLL + l * PLL_STRIDE; }
+  DGD cip bi(int b) const { return sc.BI + b * DG_BI_STRIDE; }
+  DGD cfp bf(int b) const { return sc.BF + b * DG_BF_STRIDE; }
+  DGD cip li(int l) const { return sc.LI + l * DG_LI_STRIDE; }
+  DGD cfp lf(int l) const { return sc.LF + l * DG_LF_STRIDE; }
+  DGD cip plb(int b) const { return sc.PLB + b * PLB_STRIDE; }
+  DGD cip pll(int l) const { return sc.PLL + l * PLL_STRIDE; }
   DGD bool fixed(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
   DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
   DGD int minv_idx(int i, int j) const { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
@@ -123,7 +131,7 @@ struct Lane {
 
   // parent->child rotation (Rpc) and offset r for link gl at joint value q
   DGD void joint_xform(int gl, float q, M3& Rpc, V3& r) const {
-    const float* f = lf(gl);
+    cfp f = lf(gl);
     M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = f[DG_LF_ROT + k];
     V3 pT = v3(f[DG_LF_POS], f[DG_LF_POS + 1], f[DG_LF_POS + 2]);
     V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
@@ -134,7 +142,7 @@ struct Lane {
   // ------------------------------------------------------------ kinematics
   // world pose of every link of body b into the POSE region (q from state, or from LDS at qoff when qoff >= 0)
   DGD void kinematics(int b, int qoff = -1) const {
-    const int32_t* B = bi(b);
+    cip B = bi(b);
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
     LRset(plb(b)[PLB_R0], R0);
@@ -154,12 +162,12 @@ struct Lane {
     V3 off; Q4 qo; int gl;
     if (fr < 0) {
       gl = -1;
-      if (com) { const float* f = bf(b); off = v3(f[DG_BF_REPORT_POS], f[DG_BF_REPORT_POS + 1], f[DG_BF_REPORT_POS + 2]);
+      if (com) { cfp f = bf(b); off = v3(f[DG_BF_REPORT_POS], f[DG_BF_REPORT_POS + 1], f[DG_BF_REPORT_POS + 2]);
         Q4 t = {f[DG_BF_REPORT_QUAT], f[DG_BF_REPORT_QUAT + 1], f[DG_BF_REPORT_QUAT + 2], f[DG_BF_REPORT_QUAT + 3]}; qo = t; }
       else { off = v3(0, 0, 0); Q4 t = {0, 0, 0, 1}; qo = t; }
     } else {
       gl = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
-      const float* f = sc.FF + fr * DG_FF_STRIDE + (com ? DG_FF_COM_POS : DG_FF_POS);
+      cfp f = sc.FF + fr * DG_FF_STRIDE + (com ? DG_FF_COM_POS : DG_FF_POS);
       off = v3(f[0], f[1], f[2]); Q4 t = {f[3], f[4], f[5], f[6]}; qo = t;
     }
     M3 R; V3 o; link_world(b, gl, R, o);
@@ -178,7 +186,7 @@ struct Lane {
       for (int k = first; k <= gl; k++) {
         if (!((path >> (k - first)) & 1ull)) continue;
         int po_off = pll(k)[PLL_POSE]; M3 Rk = LR(po_off); V3 pk = L3(po_off + 6);
-        const float* f = lf(k); V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+        cfp f = lf(k); V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
         float qd = S(li(k)[DG_LI_STATE_OFF] + DG_LS_QD);
         vl = vl + cross(wl, pk - po);  // move the reference point to this link's origin (parent's angular velocity)
         if (li(k)[DG_LI_TYPE] == 0) wl = wl + axw * qd; else vl = vl + axw * qd;
@@ -200,16 +208,16 @@ struct Lane {
     S6 o = {n + cross(c, f), f};
     return o;
   }
-  DGD Sym3 sym6(const float* p) const { Sym3 s = {p[0], p[1], p[2], p[3], p[4], p[5]}; return s; }
+  DGD Sym3 sym6(cfp p) const { Sym3 s = {p[0], p[1], p[2], p[3], p[4], p[5]}; return s; }
   DGD S6 subspace(int gl) const {
-    const float* f = lf(gl); V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
+    cfp f = lf(gl); V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
     S6 s; if (li(gl)[DG_LI_TYPE] == 0) { s.a = ax; s.l = v3(0, 0, 0); } else { s.a = v3(0, 0, 0); s.l = ax; }
     return s;
   }
 
   // forward dynamics of body b, velocity update, and M^-1 (packed symmetric) into the MINV region
   DGD void dynamics(int b) const {
-    const int32_t* B = bi(b); const float* Bf = bf(b);
+    cip B = bi(b); cfp Bf = bf(b);
     const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     const bool fx = fixed(b); const float h = sc.h;
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV], nb6 = fx ? 0 : 6;
@@ -229,7 +237,7 @@ struct Lane {
     }
     L6set(ab() + AB_V, v0);
     for (int i = 0; i < n; i++) {
-      int gl = first + i, par = li(gl)[DG_LI_PARENT]; const float* f = lf(gl);
+      int gl = first + i, par = li(gl)[DG_LI_PARENT]; cfp f = lf(gl);
       int lo = li(gl)[DG_LI_STATE_OFF]; float q = S(lo + DG_LS_Q), qd = S(lo + DG_LS_QD);
       M3 Rpc; V3 r; joint_xform(gl, q, Rpc, r); M3 E = transpose(Rpc);
       S6 vp = par < 0 ? v0 : L6(aw(par - first) + AW_V);
@@ -246,7 +254,7 @@ struct Lane {
     AI carry; int carry_parent = -2;  // contribution of link i+1 to link i, kept in registers along chains
     // ---- pass 2
     for (int i = n - 1; i >= 0; i--) {
-      int gl = first + i, par = li(gl)[DG_LI_PARENT]; const float* f = lf(gl); int o = aw(i);
+      int gl = first + i, par = li(gl)[DG_LI_PARENT]; cfp f = lf(gl); int o = aw(i);
       int lo = li(gl)[DG_LI_STATE_OFF]; float qd = S(lo + DG_LS_QD);
       float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd;
       AI IA = rigid_inertia(f[DG_LF_MASS], v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]), sym6(f + DG_LF_INERTIA));
@@ -371,7 +379,7 @@ struct Lane {
   // ------------------------------------------------------------ solver rows
   // generalized velocity of body b dotted with a Jacobian stored at LDS offset jo (length nv)
   DGD float gen_vel_dot(int b, int jo) const {
-    const int32_t* B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     float r = 0.f; int k = 0;
     if (!fixed(b)) {
       M3 R0 = LR(plb(b)[PLB_R0]);
@@ -385,7 +393,7 @@ struct Lane {
   // Jacobian (into jo) and response M^-1 J^T (into ro) of body b for a unit force along world direction
   // dir at world point p on link gl (-1 base).  Returns J M^-1 J^T.
   DGD float point_row(int b, int gl, V3 p, V3 dir, int jo, int ro) const {
-    const int32_t* B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV]; int k0 = 0;
     for (int k = 0; k < nv; k++) L(jo + k) = 0.f;
     if (!fixed(b)) {
@@ -393,7 +401,7 @@ struct Lane {
       L3set(jo, ja); L3set(jo + 3, jl); k0 = 6;
     }
     for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) {
-      int po = pll(k)[PLL_POSE]; M3 Rk = LR(po); V3 pk = L3(po + 6); const float* f = lf(k);
+      int po = pll(k)[PLL_POSE]; M3 Rk = LR(po); V3 pk = L3(po + 6); cfp f = lf(k);
       V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
       L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
     }

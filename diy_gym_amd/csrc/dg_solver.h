@@ -11,7 +11,7 @@ struct WShape { int type, body, glink; M3 R; V3 p; float prm0, prm1, prm2, mu; i
 
 template <int LANES>
 DGD void shape_world(const Lane<LANES>& ln, int sh, WShape& o) {
-  const int32_t* si = ln.sc.SI + sh * DG_SI_STRIDE; const float* sf = ln.sc.SF + sh * DG_SF_STRIDE;
+  cip si = ln.sc.SI + sh * DG_SI_STRIDE; cfp sf = ln.sc.SF + sh * DG_SF_STRIDE;
   o.type = si[DG_SI_TYPE]; o.body = si[DG_SI_BODY]; o.glink = si[DG_SI_LINK]; o.poff = si[DG_SI_POINT_OFF]; o.npts = si[DG_SI_N_POINTS];
   M3 Rl; V3 pl; ln.link_world(o.body, o.glink, Rl, pl);
   M3 Rs; _Pragma("unroll") for (int k = 0; k < 9; k++) Rs.m[k] = sf[DG_SF_ROT + k];
@@ -102,7 +102,7 @@ DGD int collide(const Lane<LANES>& ln) {
       int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
       M3 Rl; V3 pl; ln.link_world(a.body, a.glink, Rl, pl);
       for (int k = 0; k < a.npts; k++) {
-        const float* pp = sc.PF + 3 * (a.poff + k);
+        cfp pp = sc.PF + 3 * (a.poff + k);
         Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
         if (!h.hit) continue;
         bool placed = false;
@@ -118,7 +118,7 @@ DGD int collide(const Lane<LANES>& ln) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         int k = bi4[j] < 0 ? 0 : bi4[j];
-        const float* pp = sc.PF + 3 * (a.poff + k);  // per-lane index: vector load
+        cfp pp = sc.PF + 3 * (a.poff + k);  // per-lane index: vector load
         Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
         h.hit = h.hit && bi4[j] >= 0;
         emit_contact(ln, cnt, pi, h, flip);
@@ -143,7 +143,7 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
 template <int LANES>
 DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
   const DevScene& sc = ln.sc; const int nvm = sc.nv_max, rs = crow_stride(nvm);
-  const int32_t* sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; const int32_t* sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
+  cip sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; cip sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
   const int ba = sa[DG_SI_BODY], la = sa[DG_SI_LINK], bb = sb[DG_SI_BODY], lb = sb[DG_SI_LINK];
   const bool a_dyn = !(ln.fixed(ba) && ln.bi(ba)[DG_BI_N_LINKS] == 0), b_dyn = !(ln.fixed(bb) && ln.bi(bb)[DG_BI_N_LINKS] == 0);
   if (!mine) return;
@@ -200,7 +200,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
   for (int gl = 0; gl < sc.nl; gl++) {
-    const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; const float* f = ln.lf(gl);
+    const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
     const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
     const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
     ln.L(mo + MR_B) = kp * (ln.S(lo + DG_LS_TARGET_POS) - q) / h + kd * (ln.S(lo + DG_LS_TARGET_VEL) - qd);
@@ -242,7 +242,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
       float res = delta * diag; maxres = fmaxf(maxres, res * res);
     }
     for (int gl = 0; gl < sc.nl; gl++) {  // joint limits
-      const float* f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
+      cfp f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
       const int b = ln.li(gl)[DG_LI_BODY]; const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
       const int j = gl - ln.bi(b)[DG_BI_FIRST_LINK] + (ln.fixed(b) ? 0 : 6), mo = ln.pll(gl)[PLL_MROW];
       const float diag = ln.L(mvo + ln.minv_idx(j, j));
@@ -285,7 +285,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
     ln.Sset(lo + DG_LS_APPLIED, maximp > 0.f ? ln.L(ln.pll(gl)[PLL_MROW] + MR_ACC) / h : 0.f);
   }
   for (int b = 0; b < sc.nb; b++) {
-    const int32_t* B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
+    cip B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
     const bool fx = ln.fixed(b); if (fx && n == 0) continue;
     const int dvo = ln.plb(b)[PLB_DV];
     if (!fx) {
@@ -325,12 +325,12 @@ DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out) {
 // and must be refreshed by the caller afterwards.
 template <int LANES>
 DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane) {
-  const DevScene& sc = ln.sc; const int32_t* oi = sc.OI + op * DG_OI_STRIDE;
+  const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
   const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
   const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
   const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS];
   const int qo = sc.tr_off, jo = qo + n, vo = jo + 6 * n, dto = vo + n;
-  const float* rest = sc.FL + oi[DG_OI_FLIST];
+  cfp rest = sc.FL + oi[DG_OI_FLIST];
   for (int i = 0; i < n; i++) ln.L(qo + i) = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q);
   V3 cp, cv, cw; Q4 cq; ln.frame_state(b, fr, true, cp, cq, cv, cw, false);
   V3 tp = cp + v3(act[0], act[1], act[2]); Q4 tq = cq;
@@ -354,7 +354,7 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
     // Jacobian columns (world frame) for the chain root -> end-effector link, zero elsewhere
     for (int i = 0; i < 6 * n; i++) ln.L(jo + i) = 0.f;
     for (int k = eel; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
-      int po = ln.pll(k)[PLL_POSE]; M3 Rk = ln.LR(po); V3 pk = ln.L3(po + 6); const float* f = ln.lf(k);
+      int po = ln.pll(k)[PLL_POSE]; M3 Rk = ln.LR(po); V3 pk = ln.L3(po + 6); cfp f = ln.lf(k);
       V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2])); int i = k - first;
       V3 jl, ja; if (ln.li(k)[DG_LI_TYPE] == 0) { jl = cross(axw, fp - pk); ja = axw; } else { jl = axw; ja = v3(0, 0, 0); }
       ln.L(jo + i) = jl.x; ln.L(jo + n + i) = jl.y; ln.L(jo + 2 * n + i) = jl.z;
@@ -415,10 +415,10 @@ template <int LANES>
 DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask) {
   const DevScene& sc = ln.sc;
   for (int op = 0; op < sc.nops; op++) {
-    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+    cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
     if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
-    const float* a = act_row + oi[DG_OI_IO_OFF]; const int32_t* il = sc.IL + oi[DG_OI_ILIST]; const int n = oi[DG_OI_N];
+    const float* a = act_row + oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST]; const int n = oi[DG_OI_N];
     if (code == DG_OP_JOINT_CONTROL) {
       const int mode = oi[DG_OI_FLAGS];
       for (int k = 0; k < n; k++) {
@@ -457,7 +457,7 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
 
 template <int LANES>
 DGD void set_base_com_pose(const Lane<LANES>& ln, int b, V3 pc, Q4 qc) {
-  const float* f = ln.bf(b); const int so = ln.bi(b)[DG_BI_STATE_OFF];
+  cfp f = ln.bf(b); const int so = ln.bi(b)[DG_BI_STATE_OFF];
   Q4 qr = {f[DG_BF_REPORT_QUAT], f[DG_BF_REPORT_QUAT + 1], f[DG_BF_REPORT_QUAT + 2], f[DG_BF_REPORT_QUAT + 3]};
   Q4 ql = qnormalize(qmul(qc, qconj(qr))); M3 R = qmat(ql);
   V3 pl = pc - mul(R, v3(f[DG_BF_REPORT_POS], f[DG_BF_REPORT_POS + 1], f[DG_BF_REPORT_POS + 2]));
@@ -469,7 +469,7 @@ template <int LANES>
 DGD void run_reset_ops(const Lane<LANES>& ln) {
   const DevScene& sc = ln.sc; const uint64_t episode = (uint64_t)ln.S(DG_ST_EPISODE);
   for (int op = 0; op < sc.nops; op++) {
-    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+    cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
     if (code == DG_OP_RESPAWN) {
       const uint64_t ep = (oi[DG_OI_FLAGS] & DG_RS_ONCE) ? 0ull : episode + 1ull, ge = (uint64_t)(sc.env_base + ln.env);
       float u[6];
@@ -479,7 +479,7 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
       Q4 q0 = {of[3], of[4], of[5], of[6]};
       set_base_com_pose(ln, oi[DG_OI_BODY], p, qmul(q0, qfrom_euler(u[3] * of[10], u[4] * of[11], u[5] * of[12])));
     } else if (code == DG_OP_RESET_JOINTS) {
-      const int32_t* il = sc.IL + oi[DG_OI_ILIST]; const float* fl = sc.FL + oi[DG_OI_FLIST];
+      cip il = sc.IL + oi[DG_OI_ILIST]; cfp fl = sc.FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { const int lo = ln.li(il[k])[DG_LI_STATE_OFF]; ln.Sset(lo + DG_LS_Q, fl[k]); ln.Sset(lo + DG_LS_QD, 0.f); }
     }
   }
@@ -487,7 +487,7 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
 }
 
 template <int LANES>
-DGD float reach_dist(const Lane<LANES>& ln, const int32_t* oi) {
+DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
   V3 pa, pb, v, w; Q4 q;
   ln.frame_state(oi[DG_OI_BODY2], oi[DG_OI_FRAME2], oi[DG_OI_FRAME2] < 0, pa, q, v, w, false);
   ln.frame_state(oi[DG_OI_BODY], oi[DG_OI_FRAME], oi[DG_OI_FRAME] < 0, pb, q, v, w, false);
@@ -499,8 +499,8 @@ template <int LANES>
 DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag) {
   const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
   for (int op = 0; op < sc.nops; op++) {
-    const int32_t* oi = sc.OI + op * DG_OI_STRIDE; const float* of = sc.OF + op * DG_OF_STRIDE;
-    const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; const int32_t* il = sc.IL + oi[DG_OI_ILIST];
+    cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE;
+    const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST];
     if (code == DG_OP_OBS_JOINT_STATE) {
       const int n = oi[DG_OI_N]; int k2 = n;
       if (obs) {
@@ -525,7 +525,7 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
       if (obs) for (int k = 0; k < oi[DG_OI_N]; k++) obs[io + k] = ln.S(sc.addon_off + oi[DG_OI_STATE_OFF] + k);
     } else if (code == DG_OP_REW_REACH) { float r = -reach_dist(ln, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
     else if (code == DG_OP_REW_ELECTRICITY) {
-      const int32_t* B = ln.bi(oi[DG_OI_BODY]); float acc = 0.f;
+      cip B = ln.bi(oi[DG_OI_BODY]); float acc = 0.f;
       for (int i = 0; i < B[DG_BI_N_LINKS]; i++) { const int lo = ln.li(B[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabsf(ln.S(lo + DG_LS_APPLIED) * ln.S(lo + DG_LS_QD)); }
       float r = -acc * of[0]; if (rew) rew[io] = r; rsum += r;
     } else if (code == DG_OP_REW_CONST) { if (rew) rew[io] = of[0]; rsum += of[0]; }

@@ -36,6 +36,7 @@ SYMBOLS = {
     'dg_world_observe': (ctypes.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dg_world_frame_state': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
     'dg_world_set_diag_buffer': (ctypes.c_int32, [_vp, _vp]),
+    'dg_world_set_profile_buffer': (ctypes.c_int32, [_vp, _vp]),
 }
 
 
@@ -150,6 +151,18 @@ class HipBackend:
         self.diag = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
         self._check(self.lib.dg_world_set_diag_buffer(self.handle, _ptr(self.diag)))
         return self.diag
+
+    SECTIONS = ['update_ops', 'kinematics', 'narrow_phase', 'aba', 'minv', 'rows', 'pgs', 'integrate', 'outputs']
+
+    def enable_stamps(self, on=True):
+        """Diagnostic: per-wavefront shader cycles per section of the step (see diygym_hip.h)."""
+        if on:
+            n_waves = (self.num_envs + self.lanes - 1) // self.lanes
+            self.cycles = torch.zeros((n_waves, len(self.SECTIONS)), dtype=torch.int64, device=self.device)
+            self._check(self.lib.dg_world_set_profile_buffer(self.handle, _ptr(self.cycles)))
+        else:
+            self._check(self.lib.dg_world_set_profile_buffer(self.handle, None))
+        return getattr(self, 'cycles', None)
 
     # state as [num_envs, state_dim] host array (tests / checkpoints)
     def get_state(self):

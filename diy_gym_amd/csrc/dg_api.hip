@@ -22,21 +22,28 @@ static int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
 // ---------------------------------------------------------------- kernels
-template <int LANES>
+template <int LANES, bool PROF>
 __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
-                                                   float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag) {
+                                                   float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
+                                                   unsigned long long* cycles) {
   extern __shared__ float smem[];
   const int lane = threadIdx.x; if (lane >= LANES) return;
   const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
   Lane<LANES> ln(sc, mt, smem + lane, state + e, e, valid);
+  Prof<PROF> prof; prof.start();
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
   if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
   ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
-  sim_step(ln, diag);
+  prof.stamp(PS_UPDATE);
+  sim_step(ln, diag, prof);
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
                  (valid && term_flag) ? term_flag + e : nullptr);
+  prof.stamp(PS_OUTPUT);
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
 }
 
 template <int LANES>
@@ -49,7 +56,8 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
   if (doit) {
     ln.Sset(DG_ST_STEP, 0.0f);
     run_reset_ops(ln);
-    for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr);
+    Prof<false> prof;
+    for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr, prof);
   }
   if (obs) {
     for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
@@ -94,6 +102,7 @@ struct dg_world {
   int device = 0, lanes = 64, lds_bytes = 0, num_envs = 0, stride = 0;
   void* d_blob_i = nullptr; void* d_blob_f = nullptr; void* d_plan = nullptr; float* d_init = nullptr;
   int32_t* diag = nullptr;
+  unsigned long long* profile_cycles = nullptr;
 };
 
 extern "C" {
@@ -122,12 +131,13 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     const int nv = (fx ? 0 : 6) + n;
     if (!fx) any_float = true;
     PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6;
-    PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * (nv + 1) / 2;
+    PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * nv;
     PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += nv;
     PLB[b * PLB_STRIDE + PLB_NV] = nv;
     nvmax = std::max(nvmax, nv); nmax = std::max(nmax, n);
   }
-  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 9; PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; PLL[l * PLL_STRIDE + PLL_IAACC] = -1; }
+  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 9; PLL[l * PLL_STRIDE + PLL_IAACC] = -1; }
+  for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; }  // contiguous: pgs_rows_small strides through them
   const int maxc = I[DG_H_MAX_CONTACTS];
   const int cont_off = slot; slot += 1 + maxc * CL_STRIDE;
   const int ab_stride = any_float ? AB_FLOAT_STRIDE : AB_FIXED_STRIDE;
@@ -145,6 +155,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     tr = std::max(tr, need);
   }
   tr = std::max(tr, 3 * maxc * (4 * nvmax + 3));
+  if (I[DG_H_N_PAIRS] > 0) tr = std::max(tr, (int)SC_STRIDE * I[DG_H_N_SHAPES]);  // narrow-phase shape cache
   for (int op = 0; op < I[DG_H_N_OPS]; op++)
     if (OI[op * DG_OI_STRIDE + DG_OI_CODE] == DG_OP_IK_CONTROL) {
       const int n = BI[OI[op * DG_OI_STRIDE + DG_OI_BODY] * DG_BI_STRIDE + DG_BI_N_LINKS];
@@ -159,7 +170,18 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   w->lanes = lanes; w->lds_bytes = total * lanes * 4;
   // ---- device tables (floats converted once)
   std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
-  HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, I, sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
+  // device copy of the int tables, with device-only hints: IK ops on serial chains of <= 6 joints take the
+  // register-resident solver
+  std::vector<int32_t> Idev(I, I + n_i);
+  for (int op = 0; op < I[DG_H_N_OPS]; op++) {
+    int32_t* oi = Idev.data() + I[DG_H_OFF_OP_I] + op * DG_OI_STRIDE;
+    if (oi[DG_OI_CODE] != DG_OP_IK_CONTROL) continue;
+    const int32_t* B = BI + oi[DG_OI_BODY] * DG_BI_STRIDE; const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    bool chain = n >= 1 && n <= 6;
+    for (int i = 0; i < n && chain; i++) chain = LI[(first + i) * DG_LI_STRIDE + DG_LI_PARENT] == (i == 0 ? -1 : first + i - 1);
+    if (chain) oi[DG_OI_FLAGS] |= DG_IK_DEV_CHAIN;
+  }
+  HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, Idev.data(), sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_blob_f, sizeof(float) * (size_t)n_f)); HIP_TRY(hipMemcpy(w->d_blob_f, Ff.data(), sizeof(float) * (size_t)n_f, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
   // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
@@ -176,6 +198,12 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
   sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
+  // bodies whose solver rows are held in registers by the step kernel
+  sc.reg_body[0] = sc.reg_body[1] = -1;
+  for (int b = 0, k = 0; b < nb && k < 2; b++) {
+    const int32_t* B = BI + b * DG_BI_STRIDE;
+    if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) sc.reg_body[k++] = b;
+  }
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);
@@ -191,9 +219,9 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   HIP_TRY(hipMalloc((void**)&w->d_init, sizeof(float) * init.size())); HIP_TRY(hipMemcpy(w->d_init, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
   // allow > 64 KiB of dynamic LDS
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
-  if (lanes == 64) { SET_ATTR(step_kernel<64>); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); }
-  else if (lanes == 32) { SET_ATTR(step_kernel<32>); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); }
-  else { SET_ATTR(step_kernel<16>); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); }
+  if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); }
+  else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); }
+  else { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); }
 #undef SET_ATTR
   *out = w;
   return DG_OK;
@@ -265,9 +293,20 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
       }
     }
   }
-  LAUNCH(step_kernel, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag);
+  {
+    const dim3 grid((w->num_envs + w->lanes - 1) / w->lanes), block(64); hipStream_t st = (hipStream_t)stream;
+    if (w->profile_cycles) {
+      if (w->lanes != 64) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 envs per wavefront only");
+      hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles);
+    } else if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
+    else if (w->lanes == 32) hipLaunchKernelGGL((step_kernel<32, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
   return DG_OK;
 }
+
+int32_t dg_world_set_profile_buffer(dg_world* w, uint64_t* cycles) { if (!w) return fail(DG_ERR_ARG, "null world"); w->profile_cycles = (unsigned long long*)cycles; return DG_OK; }
 
 int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");

@@ -45,6 +45,7 @@ struct DevScene {
   int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
+  int32_t reg_body[2];  // up to two fixed-base bodies with <= 6 joints whose solver rows live in registers (-1: none)
   int32_t num_envs, stride;
   uint64_t seed; int64_t env_base;
   float h, gx, gy, gz;
@@ -118,7 +119,6 @@ struct Lane {
   DGD cip pll(int l) const { return sc.PLL + l * PLL_STRIDE; }
   DGD bool fixed(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
   DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
-  DGD int minv_idx(int i, int j) const { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
 
   DGD V3 base_pos(int b) const { int o = bi(b)[DG_BI_STATE_OFF]; return v3(S(o), S(o + 1), S(o + 2)); }
   DGD Q4 base_quat(int b) const { int o = bi(b)[DG_BI_STATE_OFF] + DG_BS_QUAT; Q4 q = {S(o), S(o + 1), S(o + 2), S(o + 3)}; return q; }
@@ -216,7 +216,8 @@ struct Lane {
   }
 
   // forward dynamics of body b, velocity update, and M^-1 (packed symmetric) into the MINV region
-  DGD void dynamics(int b) const {
+  template <class PROF_T>
+  DGD void dynamics(int b, PROF_T& prof) const {
     cip B = bi(b); cfp Bf = bf(b);
     const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     const bool fx = fixed(b); const float h = sc.h;
@@ -330,6 +331,7 @@ struct Lane {
       Sset(so + DG_BS_ANGVEL, S(so + DG_BS_ANGVEL) + h * dww.x); Sset(so + DG_BS_ANGVEL + 1, S(so + DG_BS_ANGVEL + 1) + h * dww.y);
       Sset(so + DG_BS_ANGVEL + 2, S(so + DG_BS_ANGVEL + 2) + h * dww.z);
     }
+    prof.stamp(3 /* PS_ABA */);
     // ---- M^-1 by unit impulse responses; column col of generalized coords (base 6 first when floating).
     // p (bias) reuses AW_PA, link accelerations reuse AW_V.
     for (int col = 0; col < nv; col++) {
@@ -363,7 +365,7 @@ struct Lane {
         chol6_solve(Lb, rhs, x);
         a0c.a = v3(x[0], x[1], x[2]); a0c.l = v3(x[3], x[4], x[5]);
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (k <= col) L(mo + minv_idx(k, col)) = x[k];
+        for (int k = 0; k < 6; k++) L(mo + col * nv + k) = x[k];
       }
       for (int i = 0; i < n; i++) {
         int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i);
@@ -371,9 +373,10 @@ struct Lane {
         S6 a1 = xmotion(LM(o + AW_E), L3(o + AW_R), ap);
         float qdd = (L(o + AW_UU) - dot(L6(o + AW_U), a1)) / L(o + AW_D);
         L6set(o + AW_V, a1 + subspace(gl) * qdd);
-        if (nb6 + i <= col) L(mo + minv_idx(nb6 + i, col)) = qdd;
+        L(mo + col * nv + nb6 + i) = qdd;
       }
     }
+    prof.stamp(4 /* PS_MINV */);
   }
 
   // ------------------------------------------------------------ solver rows
@@ -409,7 +412,7 @@ struct Lane {
     float diag = 0.f;
     for (int i = 0; i < nv; i++) {
       float s = 0.f;
-      for (int j = 0; j < nv; j++) s += L(mo + minv_idx(i, j)) * L(jo + j);
+      for (int j = 0; j < nv; j++) s += L(mo + j * nv + i) * L(jo + j);
       L(ro + i) = s; diag += s * L(jo + i);
     }
     return diag;

@@ -6,6 +6,22 @@
 
 namespace dg {
 
+// ---------------------------------------------------------------- in-kernel stamps
+// Diagnostic builds only (template PROF = true): wave-uniform cycle counters per section of the step.
+// The production instantiation (PROF = false) contains no stamp at all.
+enum { PS_UPDATE = 0, PS_KIN, PS_COLLIDE, PS_ABA, PS_MINV, PS_ROWS, PS_PGS, PS_INTEGRATE, PS_OUTPUT, PS_COUNT };
+template <bool PROF> struct Prof;
+template <> struct Prof<false> { DGD void start() {} DGD void stamp(int) {} };
+template <> struct Prof<true> {
+  unsigned long long last, acc[PS_COUNT];
+  DGD void start() { _Pragma("unroll") for (int k = 0; k < PS_COUNT; k++) acc[k] = 0ull; last = __builtin_amdgcn_s_memtime(); }
+  DGD void stamp(int id) {
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    _Pragma("unroll") for (int k = 0; k < PS_COUNT; k++) if (k == id) acc[k] += t - last;
+    last = t;
+  }
+};
+
 // ---------------------------------------------------------------- narrow phase
 struct WShape { int type, body, glink; M3 R; V3 p; float prm0, prm1, prm2, mu; int poff, npts; };
 
@@ -81,47 +97,77 @@ DGD void emit_contact(const Lane<LANES>& ln, int& cnt, int pair, const Hit& h, f
   cnt++;
 }
 
+// Round shapes (sphere / capsule / convex mesh via its fitted capsule) are reduced once per substep to a
+// world-space segment + radius, cached in the transient LDS region (free until the dynamics pass):
+//   [e0 3][e1 3][r][bounding radius] per shape.  Pairs whose bounding spheres are apart in every lane of the
+// wave are skipped with one wave-uniform branch.
+enum { SC_E0 = 0, SC_E1 = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
+
 template <int LANES>
 DGD int collide(const Lane<LANES>& ln) {
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
+  if (sc.npairs == 0) { ln.L(sc.cont_off) = 0.f; return 0; }
+  for (int sh = 0; sh < sc.nsh; sh++) {
+    const int type = sc.SI[sh * DG_SI_STRIDE + DG_SI_TYPE]; if (type == DG_SHAPE_BOX) continue;
+    WShape w; shape_world(ln, sh, w); V3 e0 = w.p, e1 = w.p;
+    if (type != DG_SHAPE_SPHERE) seg_ends(w, e0, e1);
+    const int o = sc.tr_off + sh * SC_STRIDE;
+    ln.L3set(o + SC_E0, e0); ln.L3set(o + SC_E1, e1); ln.L(o + SC_R) = w.prm0; ln.L(o + SC_BOUND) = w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
+  }
   for (int pi = 0; pi < sc.npairs; pi++) {
-    WShape A, Bs; shape_world(ln, sc.PI[pi * DG_PI_STRIDE + DG_PI_A], A); shape_world(ln, sc.PI[pi * DG_PI_STRIDE + DG_PI_B], Bs);
+    const int sA = sc.PI[pi * DG_PI_STRIDE + DG_PI_A], sB = sc.PI[pi * DG_PI_STRIDE + DG_PI_B];
+    const int tA = sc.SI[sA * DG_SI_STRIDE + DG_SI_TYPE], tB = sc.SI[sB * DG_SI_STRIDE + DG_SI_TYPE];
     // canonical order (uniform): lower type first, a box always second.  Normals are reported from
     // the pair's second shape towards its first, so flip when the roles were swapped.
-    const bool swap = A.type == DG_SHAPE_BOX || (Bs.type != DG_SHAPE_BOX && A.type > Bs.type);
-    const WShape& a = swap ? Bs : A; const WShape& b = swap ? A : Bs; const float flip = swap ? -1.f : 1.f;
-    const bool a_round = a.type == DG_SHAPE_CAPSULE || a.type == DG_SHAPE_POINTS, b_round = b.type == DG_SHAPE_CAPSULE || b.type == DG_SHAPE_POINTS;
-    if (a.type == DG_SHAPE_SPHERE && b.type == DG_SHAPE_SPHERE) emit_contact(ln, cnt, pi, sphere_sphere(a.p, a.prm0, b.p, b.prm0, margin), flip);
-    else if (a.type == DG_SHAPE_SPHERE && b.type == DG_SHAPE_BOX) emit_contact(ln, cnt, pi, sphere_box(a.p, a.prm0, b, margin), flip);
-    else if (a.type == DG_SHAPE_SPHERE && b_round) { V3 e0, e1; seg_ends(b, e0, e1); emit_contact(ln, cnt, pi, sphere_sphere(a.p, a.prm0, closest_on_seg(e0, e1, a.p), b.prm0, margin), flip); }
-    else if (a_round && b_round) { V3 a0, a1, b0, b1, ca, cb; seg_ends(a, a0, a1); seg_ends(b, b0, b1); seg_seg(a0, a1, b0, b1, ca, cb); emit_contact(ln, cnt, pi, sphere_sphere(ca, a.prm0, cb, b.prm0, margin), flip); }
-    else if (a.type == DG_SHAPE_CAPSULE && b.type == DG_SHAPE_BOX) {
-      V3 e0, e1; seg_ends(a, e0, e1); emit_contact(ln, cnt, pi, sphere_box(e0, a.prm0, b, margin), flip);
-      if (a.prm1 > 0.f) emit_contact(ln, cnt, pi, sphere_box(e1, a.prm0, b, margin), flip);
-    } else if (a.type == DG_SHAPE_POINTS && b.type == DG_SHAPE_BOX) {
-      int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-      M3 Rl; V3 pl; ln.link_world(a.body, a.glink, Rl, pl);
-      for (int k = 0; k < a.npts; k++) {
-        cfp pp = sc.PF + 3 * (a.poff + k);
-        Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
-        if (!h.hit) continue;
-        bool placed = false;
+    const bool swap = tA == DG_SHAPE_BOX || (tB != DG_SHAPE_BOX && tA > tB);
+    const int sa = swap ? sB : sA, sb = swap ? sA : sB, ta = swap ? tB : tA, tb = swap ? tA : tB; const float flip = swap ? -1.f : 1.f;
+    const int oa = sc.tr_off + sa * SC_STRIDE, ob = sc.tr_off + sb * SC_STRIDE;
+    if (tb != DG_SHAPE_BOX) {
+      // round vs round: closest points of the two segments, then sphere-sphere
+      const V3 a0 = ln.L3(oa + SC_E0), a1 = ln.L3(oa + SC_E1), b0 = ln.L3(ob + SC_E0), b1 = ln.L3(ob + SC_E1);
+      const float ra = ln.L(oa + SC_R), rb = ln.L(ob + SC_R), reach = ln.L(oa + SC_BOUND) + ln.L(ob + SC_BOUND) + margin;
+      const V3 dc = (a0 + a1) * 0.5f - (b0 + b1) * 0.5f;
+      if (!__any(dot(dc, dc) < reach * reach)) continue;
+      V3 ca = a0, cb = b0;
+      if (ta == DG_SHAPE_SPHERE && tb != DG_SHAPE_SPHERE) cb = closest_on_seg(b0, b1, a0);
+      else if (ta != DG_SHAPE_SPHERE) seg_seg(a0, a1, b0, b1, ca, cb);
+      emit_contact(ln, cnt, pi, sphere_sphere(ca, ra, cb, rb, margin), flip);
+    } else {
+      WShape b; shape_world(ln, sb, b);
+      const V3 a0 = ln.L3(oa + SC_E0), a1 = ln.L3(oa + SC_E1); const float ra = ln.L(oa + SC_R);
+      // cull with the bounding sphere of the round shape against the box
+      { Hit hb = sphere_box((a0 + a1) * 0.5f, ln.L(oa + SC_BOUND), b, margin); if (!__any(hb.hit)) continue; }
+      if (ta == DG_SHAPE_SPHERE) emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
+      else if (ta == DG_SHAPE_CAPSULE) {
+        emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
+        if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) emit_contact(ln, cnt, pi, sphere_box(a1, ra, b, margin), flip);
+      } else if (ta == DG_SHAPE_POINTS) {
+        const int abody = sc.SI[sa * DG_SI_STRIDE + DG_SI_BODY], alink = sc.SI[sa * DG_SI_STRIDE + DG_SI_LINK];
+        const int poff = sc.SI[sa * DG_SI_STRIDE + DG_SI_POINT_OFF], npts = sc.SI[sa * DG_SI_STRIDE + DG_SI_N_POINTS];
+        int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        M3 Rl; V3 pl; ln.link_world(abody, alink, Rl, pl);
+        for (int k = 0; k < npts; k++) {
+          cfp pp = sc.PF + 3 * (poff + k);
+          Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
+          if (!h.hit) continue;
+          bool placed = false;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (!placed && h.dist < bd4[j]) {
+          for (int j = 0; j < 4; j++) {
+            if (!placed && h.dist < bd4[j]) {
 #pragma unroll
-            for (int m = 3; m > j; m--) { bd4[m] = bd4[m - 1]; bi4[m] = bi4[m - 1]; }
-            bd4[j] = h.dist; bi4[j] = k; placed = true;
+              for (int m = 3; m > j; m--) { bd4[m] = bd4[m - 1]; bi4[m] = bi4[m - 1]; }
+              bd4[j] = h.dist; bi4[j] = k; placed = true;
+            }
           }
         }
-      }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int k = bi4[j] < 0 ? 0 : bi4[j];
-        cfp pp = sc.PF + 3 * (a.poff + k);  // per-lane index: vector load
-        Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
-        h.hit = h.hit && bi4[j] >= 0;
-        emit_contact(ln, cnt, pi, h, flip);
+        for (int j = 0; j < 4; j++) {
+          int k = bi4[j] < 0 ? 0 : bi4[j];
+          cfp pp = sc.PF + 3 * (poff + k);  // per-lane index: vector load
+          Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
+          h.hit = h.hit && bi4[j] >= 0;
+          emit_contact(ln, cnt, pi, h, flip);
+        }
       }
     }
   }
@@ -185,20 +231,110 @@ DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, 
   float res = delta * diag; return res * res;
 }
 
+// ---- motor / joint-limit rows of one body, one Gauss-Seidel sweep ------------------------------------
+// generic version: any body, everything through LDS
+template <int LANES, bool LIMITS>
+DGD float pgs_rows_generic(const Lane<LANES>& ln, int b, bool live) {
+  const DevScene& sc = ln.sc; const float h = sc.h; float maxres = 0.f;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
+  const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
+  for (int i = 0; i < n; i++) {
+    const int gl = first + i, j = k0 + i, mo = ln.pll(gl)[PLL_MROW], col = mvo + j * nv;
+    const float diag = ln.L(col + j);
+    if (!LIMITS) {
+      const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+      if (!(maximp > 0.f)) continue;
+      const float acc = ln.L(mo + MR_ACC);
+      float delta = (ln.L(mo + MR_B) - ln.L(dvo + j)) / diag;
+      float nacc = fminf(fmaxf(acc + delta, -maximp), maximp);
+      delta = live ? nacc - acc : 0.f; ln.L(mo + MR_ACC) = acc + delta;
+      for (int k = 0; k < nv; k++) ln.L(dvo + k) += ln.L(col + k) * delta;
+      float res = delta * diag; maxres = fmaxf(maxres, res * res);
+    } else {
+      cfp f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        const float sg = side == 0 ? 1.f : -1.f; const int bo = mo + (side == 0 ? MR_LO_B : MR_HI_B);
+        const float acc = ln.L(bo + 1); const bool act = acc >= 0.f;
+        if (!__any(act)) continue;
+        float delta = (ln.L(bo) - sg * ln.L(dvo + j)) / diag;
+        float nacc = fmaxf(acc + delta, 0.f);
+        delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
+        for (int k = 0; k < nv; k++) ln.L(dvo + k) += sg * ln.L(col + k) * delta;
+        float res = delta * diag; maxres = fmaxf(maxres, res * res);
+      }
+    }
+  }
+  return maxres;
+}
+// fixed-base body with at most MAXN joints (every arm): the body's velocity change stays in registers for the
+// whole sweep and the loops are unrolled, so a row costs 2 LDS reads + one M^-1 column instead of 3 n accesses
+template <int LANES, int MAXN, bool LIMITS>
+DGD float pgs_rows_small(const Lane<LANES>& ln, int b, bool live) {
+  const DevScene& sc = ln.sc; const float h = sc.h; float maxres = 0.f;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS];
+  const int dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
+  float dv[MAXN];
+#pragma unroll
+  for (int k = 0; k < MAXN; k++) dv[k] = k < n ? ln.L(dvo + k) : 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXN; i++) {
+    if (i < n) {
+      const int gl = first + i, mo = mo0 + i * MR_STRIDE /* MROW blocks of a body are contiguous */, col = mvo + i * n;
+      const float diag = ln.L(col + i);
+      if (!LIMITS) {
+        const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+        if (maximp > 0.f) {
+          const float acc = ln.L(mo + MR_ACC);
+          float delta = (ln.L(mo + MR_B) - dv[i]) / diag;
+          float nacc = fminf(fmaxf(acc + delta, -maximp), maximp);
+          delta = live ? nacc - acc : 0.f; ln.L(mo + MR_ACC) = acc + delta;
+#pragma unroll
+          for (int k = 0; k < MAXN; k++) if (k < n) dv[k] += ln.L(col + k) * delta;
+          float res = delta * diag; maxres = fmaxf(maxres, res * res);
+        }
+      } else {
+        cfp f = ln.lf(gl);
+        if (f[DG_LF_LOWER] <= f[DG_LF_UPPER]) {
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+            const float sg = side == 0 ? 1.f : -1.f; const int bo = mo + (side == 0 ? MR_LO_B : MR_HI_B);
+            const float acc = ln.L(bo + 1); const bool act = acc >= 0.f;
+            if (__any(act)) {
+              float delta = (ln.L(bo) - sg * dv[i]) / diag;
+              float nacc = fmaxf(acc + delta, 0.f);
+              delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
+#pragma unroll
+              for (int k = 0; k < MAXN; k++) if (k < n) dv[k] += sg * ln.L(col + k) * delta;
+              float res = delta * diag; maxres = fmaxf(maxres, res * res);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXN; k++) if (k < n) ln.L(dvo + k) = dv[k];
+  return maxres;
+}
+
 // ---------------------------------------------------------------- substep
-template <int LANES>
-DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
+template <int LANES, bool PROF>
+DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc; const float h = sc.h;
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
   const int ncont = collide(ln);
+  prof.stamp(PS_COLLIDE);
   for (int b = 0; b < sc.nb; b++) {
     if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
-    ln.dynamics(b);
+    ln.dynamics(b, prof);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
     for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
+  uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
   for (int gl = 0; gl < sc.nl; gl++) {
     const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
     const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
@@ -210,6 +346,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
     // acc < 0 marks an inactive limit row
     ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
     ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
+    if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
   }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   const int wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
@@ -224,40 +361,73 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
       todo = todo && !mine;
     }
   }
+  prof.stamp(PS_ROWS);
   // ---- projected Gauss-Seidel
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int nvm = sc.nv_max, rs = crow_stride(nvm);
   bool live = ln.valid; int iters_done = 0;
-  for (int it = 0; it < sc.iters; it++) {
-    float maxres = 0.f;
-    for (int gl = 0; gl < sc.nl; gl++) {  // motors
-      const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
-      if (!(maximp > 0.f)) continue;
-      const int b = ln.li(gl)[DG_LI_BODY]; const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
-      const int j = gl - ln.bi(b)[DG_BI_FIRST_LINK] + (ln.fixed(b) ? 0 : 6), mo = ln.pll(gl)[PLL_MROW];
-      const float diag = ln.L(mvo + ln.minv_idx(j, j)), acc = ln.L(mo + MR_ACC);
-      float delta = (ln.L(mo + MR_B) - ln.L(dvo + j)) / diag;
-      float nacc = fminf(fmaxf(acc + delta, -maximp), maximp);
-      delta = live ? nacc - acc : 0.f; ln.L(mo + MR_ACC) = acc + delta;
-      for (int k = 0; k < nv; k++) ln.L(dvo + k) += ln.L(mvo + ln.minv_idx(k, j)) * delta;
-      float res = delta * diag; maxres = fmaxf(maxres, res * res);
-    }
-    for (int gl = 0; gl < sc.nl; gl++) {  // joint limits
-      cfp f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
-      const int b = ln.li(gl)[DG_LI_BODY]; const int nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
-      const int j = gl - ln.bi(b)[DG_BI_FIRST_LINK] + (ln.fixed(b) ? 0 : 6), mo = ln.pll(gl)[PLL_MROW];
-      const float diag = ln.L(mvo + ln.minv_idx(j, j));
+  // Register-resident rows: for up to NBR fixed-base bodies with <= RN joints (every 6-axis arm) M^-1, the
+  // velocity change, the motor targets and the accumulated impulses are loaded once and the sweeps below touch
+  // no LDS at all -- a dependent LDS round trip per row is what bounds the generic path with one wave per SIMD.
+  constexpr int NBR = 2, RN = 6;
+  float rM[NBR][RN * RN], rdv[NBR][RN], rb[NBR][RN], racc[NBR][RN], rdi[NBR][RN], rdg[NBR][RN]; float smax[NBR][RN]; int rn[NBR];
 #pragma unroll
-      for (int side = 0; side < 2; side++) {
-        const float sg = side == 0 ? 1.f : -1.f; const int bo = mo + (side == 0 ? MR_LO_B : MR_HI_B);
-        const float acc = ln.L(bo + 1); const bool act = acc >= 0.f;
-        if (!__any(act)) continue;
-        float delta = (ln.L(bo) - sg * ln.L(dvo + j)) / diag;
-        float nacc = fmaxf(acc + delta, 0.f);
-        delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
-        for (int k = 0; k < nv; k++) ln.L(dvo + k) += sg * ln.L(mvo + ln.minv_idx(k, j)) * delta;
-        float res = delta * diag; maxres = fmaxf(maxres, res * res);
+  for (int k = 0; k < NBR; k++) {
+    const int b = sc.reg_body[k]; rn[k] = 0;
+    if (b >= 0) {
+      const int n = ln.bi(b)[DG_BI_N_LINKS], first = ln.bi(b)[DG_BI_FIRST_LINK], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
+      rn[k] = n;
+#pragma unroll
+      for (int i = 0; i < RN; i++) {
+        rdv[k][i] = 0.f; rb[k][i] = 0.f; racc[k][i] = 0.f; rdi[k][i] = 0.f; rdg[k][i] = 0.f; smax[k][i] = 0.f;
+        if (i < n) {
+          const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[k][i] = maxf < 0.f ? -maxf : maxf * h;
+          rb[k][i] = ln.L(mo0 + i * MR_STRIDE + MR_B); rdg[k][i] = ln.L(mvo + i * n + i); rdi[k][i] = 1.0f / rdg[k][i];
+        }
+#pragma unroll
+        for (int c = 0; c < RN; c++) rM[k][i * RN + c] = (i < n && c < n) ? ln.L(mvo + i * n + c) : 0.f;
       }
     }
+  }
+  auto regs_to_lds = [&](int k) { const int b = sc.reg_body[k]; if (b < 0) return; const int dvo = ln.plb(b)[PLB_DV];
+    _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) ln.L(dvo + i) = rdv[k][i]; };
+  auto lds_to_regs = [&](int k) { const int b = sc.reg_body[k]; if (b < 0) return; const int dvo = ln.plb(b)[PLB_DV];
+    _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) rdv[k][i] = ln.L(dvo + i); };
+  for (int it = 0; it < sc.iters; it++) {
+    float maxres = 0.f;
+    // motor rows of every body first, then joint-limit rows of every body (oracle order; rows of different
+    // bodies share no unknowns, so only the order inside a body matters)
+#pragma unroll
+    for (int k = 0; k < NBR; k++) {
+      if (sc.reg_body[k] < 0) continue;
+#pragma unroll
+      for (int i = 0; i < RN; i++) {
+        if (i < rn[k] && smax[k][i] > 0.f) {
+          float delta = (rb[k][i] - rdv[k][i]) * rdi[k][i];
+          const float nacc = fminf(fmaxf(racc[k][i] + delta, -smax[k][i]), smax[k][i]);
+          delta = live ? nacc - racc[k][i] : 0.f; racc[k][i] += delta;
+#pragma unroll
+          for (int c = 0; c < RN; c++) rdv[k][c] += rM[k][i * RN + c] * delta;
+          const float res = delta * rdg[k][i]; maxres = fmaxf(maxres, res * res);
+        }
+      }
+    }
+    for (int b = 0; b < sc.nb; b++) {
+      const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || b == sc.reg_body[0] || b == sc.reg_body[1]) continue;
+      if (ln.fixed(b) && n <= 8) maxres = fmaxf(maxres, pgs_rows_small<LANES, 8, false>(ln, b, live));
+      else maxres = fmaxf(maxres, pgs_rows_generic<LANES, false>(ln, b, live));
+    }
+    if (limit_mask) {
+      for (int b = 0; b < sc.nb; b++) {
+        const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || !((limit_mask >> (b & 63)) & 1ull)) continue;
+        if (b == sc.reg_body[0]) regs_to_lds(0);
+        if (b == sc.reg_body[1]) regs_to_lds(1);
+        if (ln.fixed(b) && n <= 8) maxres = fmaxf(maxres, pgs_rows_small<LANES, 8, true>(ln, b, live));
+        else maxres = fmaxf(maxres, pgs_rows_generic<LANES, true>(ln, b, live));
+        if (b == sc.reg_body[0]) lds_to_regs(0);
+        if (b == sc.reg_body[1]) lds_to_regs(1);
+      }
+    }
+    if (wave_max_cont > 0) { regs_to_lds(0); regs_to_lds(1); }
     for (int c = 0; c < wave_max_cont; c++) {  // contact normals
       const bool has = c < ncont;
       float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, sc.cont_off + 1 + c * CL_STRIDE, 0.f, 3.0e38f, live, has);
@@ -273,10 +443,22 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
 #pragma unroll
       for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
     }
+    if (wave_max_cont > 0) { lds_to_regs(0); lds_to_regs(1); }
     if (live) iters_done = it + 1;
     live = live && !(maxres <= thr);
     if (!__any(live)) break;
   }
+#pragma unroll
+  for (int k = 0; k < NBR; k++) {
+    const int b = sc.reg_body[k];
+    if (b >= 0) {
+      regs_to_lds(k);
+      const int mo0 = ln.pll(ln.bi(b)[DG_BI_FIRST_LINK])[PLL_MROW];
+#pragma unroll
+      for (int i = 0; i < RN; i++) if (i < rn[k]) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = racc[k][i];
+    }
+  }
+  prof.stamp(PS_PGS);
   if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
   // ---- apply velocity changes and integrate positions
   const float vmax = sc.HF[DG_HF_MAX_COORD_VEL];
@@ -311,10 +493,10 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out) {
   }
 }
 
-template <int LANES>
-DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out) {
+template <int LANES, bool PROF>
+DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc;
-  for (int k = 0; k < sc.substeps; k++) substep(ln, diag_out);
+  for (int k = 0; k < sc.substeps; k++) { substep(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
   for (int b = 0; b < sc.nb; b++) { const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }
@@ -410,6 +592,111 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
   }
 }
 
+// Register-resident variant for serial chains of at most N joints on a fixed or floating base (every 6-axis arm):
+// forward kinematics, Jacobian columns, the 6x6 normal matrix and both solves live in registers; nothing goes
+// through LDS.  Same recursion as run_ik; selected per op at world creation (DG_IK_DEV_CHAIN).
+#define DG_IK_DEV_CHAIN 256
+template <int LANES, int N>
+DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_lane, float* qout) {
+  const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
+  const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
+  const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS];
+  const int eel = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK] - first;
+  cfp rest = sc.FL + oi[DG_OI_FLIST]; cfp ff = sc.FF + fr * DG_FF_STRIDE;
+  const V3 off = v3(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2]);
+  const Q4 qoff = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
+  const M3 R0 = ln.LR(ln.plb(b)[PLB_R0]); const V3 p0 = ln.base_pos(b);
+  float q[N]; V3 ow[N], aw[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = i < n ? ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q) : 0.f;
+  V3 pe; Q4 qe;
+  auto fk = [&]() {
+    M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (i < n) {
+        M3 Rpc; V3 r; ln.joint_xform(first + i, q[i], Rpc, r);
+        p = p + mul(R, r); R = mul(R, Rpc);
+        cfp f = ln.lf(first + i); ow[i] = p; aw[i] = mul(R, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+        if (i == eel) { Rl = R; pl = p; }
+      }
+    }
+    pe = pl + mul(Rl, off); qe = qnormalize(qmul(qfrom_mat(Rl), qoff));
+  };
+  fk();
+  const V3 tp = pe + v3(act[0], act[1], act[2]); Q4 tq = qe;
+  if (use_orn) tq = qmul(qe, qfrom_euler(act[3], act[4], act[5]));
+  const float lam2 = sc.HF[DG_HF_IK_LAMBDA_SQ], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
+  const float resid = sc.HF[DG_HF_IK_RESIDUAL];
+  bool live = live_lane;
+  for (int it = 0; it < sc.ik_iters; it++) {
+    if (it > 0) fk();
+    const V3 ep = tp - pe;
+    if (it > 0 && norm(ep) < resid) live = false;
+    if (!__any(live)) break;
+    float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
+    if (use_orn) {
+      Q4 dq = qmul(tq, qconj(qe)); if (dq.w < 0.f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
+      const float sn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0f * atan2f(sn, dq.w), k = sn > 1e-12f ? an / sn : 2.0f;
+      dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
+    }
+    float U[21], Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0[N];
+#pragma unroll
+    for (int k = 0; k < 21; k++) U[k] = 0.f;
+    auto column = [&](int i, float* col) {
+      const bool rev = ln.li(first + i)[DG_LI_TYPE] == 0;
+      const V3 jl = rev ? cross(aw[i], pe - ow[i]) : aw[i]; const V3 ja = (rev && use_orn) ? aw[i] : v3(0.f, 0.f, 0.f);
+      col[0] = jl.x; col[1] = jl.y; col[2] = jl.z; col[3] = ja.x; col[4] = ja.y; col[5] = ja.z;
+    };
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      v0[i] = 0.f;
+      if (i < n) {
+        if (nullsp) {
+          const float lo = rest[n + i], hi = rest[2 * n + i], rg = rest[3 * n + i];
+          v0[i] = g0 * (rest[i] - q[i]);
+          if (q[i] > hi) v0[i] += g1 * (hi - q[i]) / rg;
+          if (q[i] < lo) v0[i] += g1 * (lo - q[i]) / rg;
+        }
+        if (i <= eel) {
+          float col[6]; column(i, col);
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            Jv[r] += col[r] * v0[i];
+#pragma unroll
+            for (int c = 0; c <= r; c++) U[r * (r + 1) / 2 + c] += col[r] * col[c];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) U[r * (r + 1) / 2 + r] += lam2;
+    chol6(U);
+    float y[6], z[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; chol6_solve(U, dS, y);
+    if (nullsp) chol6_solve(U, Jv, z);
+    float dth[N], mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      dth[i] = 0.f;
+      if (i < n) {
+        float t = 0.f, tz = 0.f;
+        if (i <= eel) {
+          float col[6]; column(i, col);
+#pragma unroll
+          for (int r = 0; r < 6; r++) { t += col[r] * y[r]; tz += col[r] * z[r]; }
+        }
+        dth[i] = nullsp ? (t + v0[i] - tz) : t; mx = fmaxf(mx, fabsf(dth[i]));
+      }
+    }
+    const float scl = mx > maxang ? maxang / mx : 1.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (i < n && live) q[i] += scl * dth[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) qout[i] = q[i];
+}
+
 // ------------------------------------------------------------ addon program
 template <int LANES>
 DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask) {
@@ -431,7 +718,18 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
       const int b = oi[DG_OI_BODY];
       float av[6] = {a[0], a[1], a[2], 0.f, 0.f, 0.f};
       if (oi[DG_OI_FLAGS] & DG_IK_USE_ORIENTATION) { av[3] = a[3]; av[4] = a[4]; av[5] = a[5]; }
-      run_ik(ln, op, av, true);
+      if (oi[DG_OI_FLAGS] & DG_IK_DEV_CHAIN) {
+        float qs[6]; run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
+        const int first = ln.bi(b)[DG_BI_FIRST_LINK];
+        for (int k = 0; k < n; k++) {
+          const int lo = ln.li(il[k])[DG_LI_STATE_OFF], j = il[k] - first; float v = qs[0];
+#pragma unroll
+          for (int c = 1; c < 6; c++) v = (j == c) ? qs[c] : v;
+          ln.Sset(lo + DG_LS_TARGET_POS, v); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f);
+        }
+        continue;  // POSE was not touched
+      }
+      run_ik(ln, op, av, ln.valid);
       for (int k = 0; k < n; k++) {
         const int lo = ln.li(il[k])[DG_LI_STATE_OFF];
         ln.Sset(lo + DG_LS_TARGET_POS, ln.L(sc.tr_off + (il[k] - ln.bi(b)[DG_BI_FIRST_LINK]))); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f);

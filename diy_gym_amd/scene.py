@@ -269,7 +269,7 @@ class SceneBuilder:
         # in the env config overrides it.  Contacts beyond the budget are dropped in pair order --
         # by the oracle and the kernels alike.
         n_dyn = sum(1 for b in self.bodies if not (b[0].fixed_base and len(b[0].links) == 0))
-        budget = self.max_contacts if self.max_contacts is not None else max(4, static_pairs + n_dyn)
+        budget = self.max_contacts if self.max_contacts is not None else max(3, static_pairs + n_dyn)
         max_contacts = min(max_contacts, int(budget), 32)
 
         def arr(rows, width, dtype):

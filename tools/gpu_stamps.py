@@ -1,0 +1,26 @@
+"""Where does a step spend its cycles?  Runs the stamped (diagnostic) step kernel and prints section shares."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+import diy_gym_amd.examples
+from diy_gym_amd import DIYGym
+import test_parity_gpu as T
+name = sys.argv[1] if len(sys.argv) > 1 else 'ur_ik'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0')
+lo, hi = T.action_bounds(env)
+gen = torch.Generator().manual_seed(1)
+ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0') for _ in range(8)]
+for i in range(10): env.sim.step(env._all_slots, ring[i % 8])
+cyc = env.sim.enable_stamps()
+tot = torch.zeros(len(env.sim.SECTIONS), dtype=torch.float64)
+n = 16
+for i in range(n):
+    env.sim.step(env._all_slots, ring[i % 8]); torch.cuda.synchronize()
+    tot += cyc.double().mean(0).cpu()
+tot /= n
+s = float(tot.sum())
+print('%s B=%d: %.0f cycles per wave per step (median wave)' % (name, B, s))
+for k, v in zip(env.sim.SECTIONS, tot.tolist()):
+    print('  %-13s %9.0f  %5.1f %%' % (k, v, 100 * v / s))

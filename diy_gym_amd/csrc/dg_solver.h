@@ -373,6 +373,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
 #pragma unroll
   for (int k = 0; k < NBR; k++) {
     const int b = sc.reg_body[k]; rn[k] = 0;
+#pragma unroll
+    for (int i = 0; i < RN; i++) { rdv[k][i] = 0.f; rb[k][i] = 0.f; racc[k][i] = 0.f; rdi[k][i] = 0.f; rdg[k][i] = 0.f; smax[k][i] = 0.f;
+      _Pragma("unroll") for (int c = 0; c < RN; c++) rM[k][i * RN + c] = 0.f; }
     if (b >= 0) {
       const int n = ln.bi(b)[DG_BI_N_LINKS], first = ln.bi(b)[DG_BI_FIRST_LINK], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
       rn[k] = n;
@@ -392,26 +395,31 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) ln.L(dvo + i) = rdv[k][i]; };
   auto lds_to_regs = [&](int k) { const int b = sc.reg_body[k]; if (b < 0) return; const int dvo = ln.plb(b)[PLB_DV];
     _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) rdv[k][i] = ln.L(dvo + i); };
+  bool has_generic = false;
+  for (int b = 0; b < sc.nb; b++) if (ln.bi(b)[DG_BI_N_LINKS] > 0 && b != sc.reg_body[0] && b != sc.reg_body[1]) has_generic = true;
+  const float thr_abs = sqrtf(thr);  // the register rows track |residual|; same test as residual^2 <= thr
   for (int it = 0; it < sc.iters; it++) {
-    float maxres = 0.f;
+    float maxres = 0.f, maxabs = 0.f;
     // motor rows of every body first, then joint-limit rows of every body (oracle order; rows of different
     // bodies share no unknowns, so only the order inside a body matters)
-#pragma unroll
-    for (int k = 0; k < NBR; k++) {
-      if (sc.reg_body[k] < 0) continue;
+    // Straight-line code, no branches: an absent row has smax = 0, so its impulse stays 0 and its delta is 0.
+    // The rows of the two bodies are independent chains the scheduler can interleave.
+    {
+      const float lv = live ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < RN; i++) {
-        if (i < rn[k] && smax[k][i] > 0.f) {
-          float delta = (rb[k][i] - rdv[k][i]) * rdi[k][i];
-          const float nacc = fminf(fmaxf(racc[k][i] + delta, -smax[k][i]), smax[k][i]);
-          delta = live ? nacc - racc[k][i] : 0.f; racc[k][i] += delta;
+#pragma unroll
+        for (int k = 0; k < NBR; k++) {
+          const float want = racc[k][i] + (rb[k][i] - rdv[k][i]) * rdi[k][i];
+          const float nacc = __builtin_amdgcn_fmed3f(want, -smax[k][i], smax[k][i]);
+          const float delta = (nacc - racc[k][i]) * lv; racc[k][i] += delta;
 #pragma unroll
           for (int c = 0; c < RN; c++) rdv[k][c] += rM[k][i * RN + c] * delta;
-          const float res = delta * rdg[k][i]; maxres = fmaxf(maxres, res * res);
+          maxabs = fmaxf(maxabs, fabsf(delta * rdg[k][i]));
         }
       }
     }
-    for (int b = 0; b < sc.nb; b++) {
+    if (has_generic) for (int b = 0; b < sc.nb; b++) {
       const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || b == sc.reg_body[0] || b == sc.reg_body[1]) continue;
       if (ln.fixed(b) && n <= 8) maxres = fmaxf(maxres, pgs_rows_small<LANES, 8, false>(ln, b, live));
       else maxres = fmaxf(maxres, pgs_rows_generic<LANES, false>(ln, b, live));
@@ -445,7 +453,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     }
     if (wave_max_cont > 0) { lds_to_regs(0); lds_to_regs(1); }
     if (live) iters_done = it + 1;
-    live = live && !(maxres <= thr);
+    live = live && !(maxres <= thr && maxabs <= thr_abs);
     if (!__any(live)) break;
   }
 #pragma unroll
@@ -608,17 +616,36 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   const Q4 qoff = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
   const M3 R0 = ln.LR(ln.plb(b)[PLB_R0]); const V3 p0 = ln.base_pos(b);
   float q[N]; V3 ow[N], aw[N];
+  // chain constants pinned in VGPRs for the whole solve (the loop is too long for them to stay in SGPRs, and
+  // re-fetching them through the scalar cache every iteration costs a memory round trip per link)
+  float cR[N][9], cP[N][3], cA[N][3]; bool rev[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) q[i] = i < n ? ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q) : 0.f;
+  for (int i = 0; i < N; i++) {
+    q[i] = 0.f; rev[i] = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) cR[i][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cP[i][k] = 0.f; cA[i][k] = 0.f; }
+    if (i < n) {
+      cfp f = ln.lf(first + i); q[i] = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q); rev[i] = ln.li(first + i)[DG_LI_TYPE] == 0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) cR[i][k] = pin(f[DG_LF_ROT + k]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { cP[i][k] = pin(f[DG_LF_POS + k]); cA[i][k] = pin(f[DG_LF_AXIS + k]); }
+    }
+  }
   V3 pe; Q4 qe;
   auto fk = [&]() {
     M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       if (i < n) {
-        M3 Rpc; V3 r; ln.joint_xform(first + i, q[i], Rpc, r);
+        M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = cR[i][k];
+        const V3 pT = v3(cP[i][0], cP[i][1], cP[i][2]), ax = v3(cA[i][0], cA[i][1], cA[i][2]);
+        M3 Rpc; V3 r;
+        if (rev[i]) { Rpc = mul(RT, rot_axis(ax, q[i])); r = pT; } else { Rpc = RT; r = pT + mul(RT, ax * q[i]); }
         p = p + mul(R, r); R = mul(R, Rpc);
-        cfp f = ln.lf(first + i); ow[i] = p; aw[i] = mul(R, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+        ow[i] = p; aw[i] = mul(R, ax);
         if (i == eel) { Rl = R; pl = p; }
       }
     }
@@ -645,8 +672,7 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
 #pragma unroll
     for (int k = 0; k < 21; k++) U[k] = 0.f;
     auto column = [&](int i, float* col) {
-      const bool rev = ln.li(first + i)[DG_LI_TYPE] == 0;
-      const V3 jl = rev ? cross(aw[i], pe - ow[i]) : aw[i]; const V3 ja = (rev && use_orn) ? aw[i] : v3(0.f, 0.f, 0.f);
+      const V3 jl = rev[i] ? cross(aw[i], pe - ow[i]) : aw[i]; const V3 ja = (rev[i] && use_orn) ? aw[i] : v3(0.f, 0.f, 0.f);
       col[0] = jl.x; col[1] = jl.y; col[2] = jl.z; col[3] = ja.x; col[4] = ja.y; col[5] = ja.z;
     };
 #pragma unroll

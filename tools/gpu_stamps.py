@@ -24,3 +24,11 @@ s = float(tot.sum())
 print('%s B=%d: %.0f cycles per wave per step (median wave)' % (name, B, s))
 for k, v in zip(env.sim.SECTIONS, tot.tolist()):
     print('  %-13s %9.0f  %5.1f %%' % (k, v, 100 * v / s))
+env.sim.enable_stamps(False)
+d = env.sim.enable_diagnostics()
+for i in range(4): env.sim.step(env._all_slots, ring[i % 8])
+torch.cuda.synchronize()
+it = d[:, 1].float()
+wave_max = it.reshape(-1, 64).max(1).values
+print('PGS iterations (last substep): mean %.1f  p50 %.0f  p99 %.0f  max %.0f | per-wave max: mean %.1f max %.0f | contacts max %d' % (
+    it.mean(), it.median(), it.quantile(0.99), it.max(), wave_max.mean(), wave_max.max(), int(d[:, 0].max())))

@@ -60,7 +60,8 @@ def cpu_baseline(cfg, act_dim, lo, hi, seconds=12.0):
     import oracle_backend
     from diy_gym_amd import DIYGym
     omp = os.path.join(ROOT, 'oracle', 'libdgsim_oracle_omp.so')
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    os.environ['OMP_NUM_THREADS'] = str(cores)
     if os.path.isfile(omp):
         oracle_backend._LIB = None
         oracle_backend.ORACLE_LIB = omp
@@ -79,6 +80,24 @@ def cpu_baseline(cfg, act_dim, lo, hi, seconds=12.0):
     return {'value': envs * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
             'sample': '%d envs x %d steps of the same config in %.1f s, C oracle (fp64, OpenMP over envs); pybullet itself is %s' %
                       (envs, steps, dt, pybullet_status())}
+
+
+def usable_cores():
+    """Host cores this job may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
 
 
 def pybullet_status():

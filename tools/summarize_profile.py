@@ -7,7 +7,8 @@ src = os.path.join(ROOT, 'gpurun_out', 'prof_r1')
 dst = os.path.join(ROOT, 'profiles')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+ks = newest(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
 shutil.copy(ks, os.path.join(dst, '%s_ur_high_5_16384_kernel_stats.csv' % tag))
 means = {}
 for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
@@ -15,7 +16,7 @@ for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
     if not files:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if 'step_kernel' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():

@@ -107,7 +107,7 @@ struct dg_world {
 
 extern "C" {
 
-int32_t dg_version(void) { return (0 << 16) | 3; }
+int32_t dg_version(void) { return (0 << 16) | 4; }
 const char* dg_last_error(void) { return g_err.c_str(); }
 
 int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t n_f, int32_t num_envs, int32_t env_stride,
@@ -130,7 +130,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     const int32_t* B = BI + b * DG_BI_STRIDE; const bool fx = B[DG_BI_FLAGS] & DG_BODY_FIXED; const int n = B[DG_BI_N_LINKS];
     const int nv = (fx ? 0 : 6) + n;
     if (!fx) any_float = true;
-    PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6;
+    if (B[DG_BI_FLAGS] & DG_BODY_FROZEN) PLB[b * PLB_STRIDE + PLB_R0] = -1; else { PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6; }
     PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * nv;
     PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += nv;
     PLB[b * PLB_STRIDE + PLB_NV] = nv;

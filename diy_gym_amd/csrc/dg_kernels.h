@@ -118,6 +118,7 @@ struct Lane {
   DGD cip plb(int b) const { return sc.PLB + b * PLB_STRIDE; }
   DGD cip pll(int l) const { return sc.PLL + l * PLL_STRIDE; }
   DGD bool fixed(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
+  DGD bool frozen(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FROZEN; }
   DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
 
   DGD V3 base_pos(int b) const { int o = bi(b)[DG_BI_STATE_OFF]; return v3(S(o), S(o + 1), S(o + 2)); }
@@ -125,7 +126,7 @@ struct Lane {
 
   // link (global index, -1 = base of body b) world frame from the POSE region
   DGD void link_world(int b, int gl, M3& R, V3& p) const {
-    if (gl < 0) { R = LR(plb(b)[PLB_R0]); p = base_pos(b); }
+    if (gl < 0) { R = frozen(b) ? qmat(base_quat(b)) : LR(plb(b)[PLB_R0]); p = base_pos(b); }
     else { int o = pll(gl)[PLL_POSE]; R = LR(o); p = L3(o + 6); }
   }
 
@@ -143,6 +144,7 @@ struct Lane {
   // world pose of every link of body b into the POSE region (q from state, or from LDS at qoff when qoff >= 0)
   DGD void kinematics(int b, int qoff = -1) const {
     cip B = bi(b);
+    if (B[DG_BI_FLAGS] & DG_BODY_FROZEN) return;  // no per-env pose storage: its shapes are in world coordinates
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
     LRset(plb(b)[PLB_R0], R0);

@@ -29,9 +29,10 @@ template <int LANES>
 DGD void shape_world(const Lane<LANES>& ln, int sh, WShape& o) {
   cip si = ln.sc.SI + sh * DG_SI_STRIDE; cfp sf = ln.sc.SF + sh * DG_SF_STRIDE;
   o.type = si[DG_SI_TYPE]; o.body = si[DG_SI_BODY]; o.glink = si[DG_SI_LINK]; o.poff = si[DG_SI_POINT_OFF]; o.npts = si[DG_SI_N_POINTS];
-  M3 Rl; V3 pl; ln.link_world(o.body, o.glink, Rl, pl);
   M3 Rs; _Pragma("unroll") for (int k = 0; k < 9; k++) Rs.m[k] = sf[DG_SF_ROT + k];
-  o.R = mul(Rl, Rs); o.p = pl + mul(Rl, v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]));
+  const V3 ps = v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]);
+  if (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) { o.R = Rs; o.p = ps; }  // frozen body: table holds world coordinates
+  else { M3 Rl; V3 pl; ln.link_world(o.body, o.glink, Rl, pl); o.R = mul(Rl, Rs); o.p = pl + mul(Rl, ps); }
   o.prm0 = sf[DG_SF_PARAMS]; o.prm1 = sf[DG_SF_PARAMS + 1]; o.prm2 = sf[DG_SF_PARAMS + 2]; o.mu = sf[DG_SF_FRICTION];
 }
 
@@ -145,7 +146,9 @@ DGD int collide(const Lane<LANES>& ln) {
         const int abody = sc.SI[sa * DG_SI_STRIDE + DG_SI_BODY], alink = sc.SI[sa * DG_SI_STRIDE + DG_SI_LINK];
         const int poff = sc.SI[sa * DG_SI_STRIDE + DG_SI_POINT_OFF], npts = sc.SI[sa * DG_SI_STRIDE + DG_SI_N_POINTS];
         int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-        M3 Rl; V3 pl; ln.link_world(abody, alink, Rl, pl);
+        M3 Rl; V3 pl;
+        if (sc.SI[sa * DG_SI_STRIDE + DG_SI_FLAGS] & DG_SHAPE_WORLD) { M3 Id = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; Rl = Id; pl = v3(0.f, 0.f, 0.f); }
+        else ln.link_world(abody, alink, Rl, pl);
         for (int k = 0; k < npts; k++) {
           cfp pp = sc.PF + 3 * (poff + k);
           Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);

@@ -96,6 +96,56 @@ def fit_capsule(points):
     return Transform(R, centre), max(r, 1e-4), half
 
 
+def as_box(points, tol=1e-6):
+    """If the 8 points are the corners of a box return (Transform, half_extents), else None."""
+    pts = np.asarray(points, dtype=np.float64)
+    if pts.shape != (8, 3):
+        return None
+    c = pts.mean(axis=0)
+    d = pts - c
+    # the three edge directions at corner 0: differences to the three nearest corners
+    dist = np.linalg.norm(pts - pts[0], axis=1)
+    order = np.argsort(dist)[1:4]
+    e = pts[order] - pts[0]
+    lens = np.linalg.norm(e, axis=1)
+    if np.any(lens < tol):
+        return None
+    u = e / lens[:, None]
+    if abs(u[0] @ u[1]) > 1e-6 or abs(u[0] @ u[2]) > 1e-6 or abs(u[1] @ u[2]) > 1e-6:
+        return None
+    if np.linalg.det(u) < 0:
+        u[2] = -u[2]
+    R = u.T
+    local = d @ R
+    half = 0.5 * lens
+    scale = max(1.0, float(np.abs(local).max()))
+    if not np.allclose(np.abs(local), half[None, :], atol=1e-6 * scale):
+        return None
+    return Transform(R, c), half
+
+
+def box_corners(T, half):
+    s = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    return (s * half[None, :]) @ T.R.T + T.p
+
+
+def hull_planes(points):
+    """Unique face planes (n, d) of the convex hull, n.x + d <= 0 inside."""
+    pts = np.asarray(points, dtype=np.float64)
+    try:
+        from scipy.spatial import ConvexHull
+        eq = ConvexHull(pts).equations
+    except Exception:
+        return np.zeros((0, 4))
+    keys, out = set(), []
+    for row in eq:
+        k = tuple(np.round(row, 6))
+        if k not in keys:
+            keys.add(k)
+            out.append(row)
+    return np.asarray(out, dtype=np.float64)
+
+
 class OpHandle:
     def __init__(self, index, kind, io_off, io_dim, state_off, slot):
         self.index = index
@@ -124,6 +174,8 @@ class SceneBuilder:
                 raise KeyError('unknown engine parameter: ' + k)
             self.params[k] = v
         self.bodies = []  # (FlatBody, pos, quat)
+        self.colors = []
+        self.cameras = []  # (body, frame, width, height, flags, Transform, fov, near, far)
         self.ops = []
         self.ilist = []
         self.flist = []
@@ -140,7 +192,16 @@ class SceneBuilder:
         T_link = Transform.from_xyz_quat([0, 0, 0], q_link)
         p_link = np.asarray(pos, dtype=np.float64) - T_link.R @ flat.T_base_report.p
         self.bodies.append((flat, p_link, q_link))
+        self.colors.append([0.8, 0.8, 0.8, 1.0])
         return len(self.bodies) - 1
+
+    def set_color(self, body, rgba):
+        self.colors[body] = [float(v) for v in rgba]
+
+    def add_camera(self, body, frame, width, height, flags, T_parent_cam, fov, near, far):
+        self.cameras.append((body, self.global_frame(body, frame) if body >= 0 else -1, int(width), int(height), int(flags),
+                             T_parent_cam, float(fov), float(near), float(far)))
+        return len(self.cameras) - 1
 
     def link_base(self, body):
         return sum(len(b[0].links) for b in self.bodies[:body])
@@ -201,20 +262,23 @@ class SceneBuilder:
     def finalize(self):
         nb = len(self.bodies)
         body_i, body_f, link_i, link_f, frame_i, frame_f = [], [], [], [], [], []
-        shape_i, shape_f, points = [], [], []
+        shape_i, shape_f, points, planes = [], [], [], []
         shape_dyn = []
         state_off = K.ST_PREFIX
         link_state_offs = []
         gl = 0
+        respawned = {row[K.OI_BODY] for row, _ in self.ops if row[K.OI_CODE] == K.OP_RESPAWN}
         for b, (flat, p_link, q_link) in enumerate(self.bodies):
             first = gl
-            flags = K.BODY_FIXED if flat.fixed_base else 0
+            dynamic = not (flat.fixed_base and len(flat.links) == 0)
+            frozen = (not dynamic) and b not in respawned
+            flags = (K.BODY_FIXED if flat.fixed_base else 0) | (K.BODY_FROZEN if frozen else 0)
             body_i.append([flags, first, len(flat.links), state_off])
             state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
             I = flat.base_inertia
             rep_q = quat_from_mat(flat.T_base_report.R)
             body_f.append([flat.base_mass, *flat.base_com, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2], *p_link,
-                           *q_link, *flat.T_base_report.p, *rep_q])
+                           *q_link, *flat.T_base_report.p, *rep_q, *self.colors[b]])
             for i, fl in enumerate(flat.links):
                 parent = -1 if fl.parent < 0 else first + fl.parent
                 link_i.append([parent, fl.joint_type, b, state_off])
@@ -228,21 +292,42 @@ class SceneBuilder:
             for fr in flat.frames:
                 frame_i.append([b, -1 if fr.link < 0 else first + fr.link])
                 frame_f.append([*fr.T.p, *fr.T.quat, *fr.T_com.p, *fr.T_com.quat])
-            dynamic = not (flat.fixed_base and len(flat.links) == 0)
+            T_body = Transform.from_xyz_quat(p_link, q_link)
             for sh in flat.shapes:
-                T, prm, poff, npts = sh.T, np.zeros(3), 0, 0
-                if sh.kind == SHAPE_SPHERE:
+                kind, T, prm, pts = sh.kind, sh.T, np.zeros(3), None
+                if kind == SHAPE_SPHERE:
                     prm[0] = sh.params[0]
-                elif sh.kind == SHAPE_BOX:
+                elif kind == SHAPE_BOX:
                     prm[:] = sh.params
-                elif sh.kind == SHAPE_CAPSULE:
+                elif kind == SHAPE_CAPSULE:
                     prm[:2] = sh.params
-                elif sh.kind == SHAPE_POINTS:
-                    T, r, half = fit_capsule(sh.points)
-                    prm[:2] = (r, half)
-                    poff, npts = len(points), len(sh.points)
-                    points.extend(sh.points.tolist())
-                shape_i.append([sh.kind, b, -1 if sh.link < 0 else first + sh.link, poff, npts])
+                elif kind == SHAPE_POINTS:
+                    pts = np.asarray(sh.points, dtype=np.float64)
+                    box = as_box(pts)
+                    if box is not None:  # a box given as a mesh (wall.obj): use the analytic box
+                        kind, (T, half), pts = SHAPE_BOX, box, None
+                        prm[:] = half
+                # Boxes on bodies that move are collided through their corners (there is no box-box routine);
+                # boxes of the static world stay analytic.
+                if kind == SHAPE_BOX and dynamic:
+                    pts = box_corners(T, prm)
+                    kind = SHAPE_POINTS
+                if kind == SHAPE_POINTS:
+                    T, r, half = fit_capsule(pts)
+                    prm = np.array([r, half, 0.0])
+                wflag = (K.SHAPE_WORLD if frozen else 0) | (K.SHAPE_NO_COLLIDE if getattr(sh, 'visual_only', False) else 0)
+                if frozen:  # bake the body pose in
+                    T = T_body * T
+                    if pts is not None:
+                        pts = pts @ T_body.R.T + T_body.p
+                poff, npts, ploff, npl = 0, 0, 0, 0
+                if pts is not None:
+                    poff, npts = len(points), len(pts)
+                    points.extend(pts.tolist())
+                    pl = hull_planes(pts)
+                    ploff, npl = len(planes), len(pl)
+                    planes.extend(pl.tolist())
+                shape_i.append([kind, b, -1 if sh.link < 0 else first + sh.link, poff, npts, ploff, npl, wflag])
                 shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction])
                 shape_dyn.append(dynamic)
         addon_off = state_off
@@ -254,6 +339,8 @@ class SceneBuilder:
         for a in range(len(shape_i)):
             for c in range(a + 1, len(shape_i)):
                 if shape_i[a][1] == shape_i[c][1] or not (shape_dyn[a] or shape_dyn[c]):
+                    continue
+                if (shape_i[a][7] | shape_i[c][7]) & K.SHAPE_NO_COLLIDE:
                     continue
                 ta, tc = shape_i[a][0], shape_i[c][0]
                 if ta == SHAPE_BOX and tc == SHAPE_BOX:
@@ -283,6 +370,7 @@ class SceneBuilder:
             ('OFF_FRAME_I', arr(frame_i, K.FI_STRIDE, np.int32)),
             ('OFF_SHAPE_I', arr(shape_i, K.SI_STRIDE, np.int32)),
             ('OFF_PAIR_I', arr(pairs, K.PI_STRIDE, np.int32)),
+            ('OFF_CAMERA_I', arr([[c[0], c[1], c[2], c[3], c[4]] for c in self.cameras], K.CI_STRIDE, np.int32)),
             ('OFF_OP_I', arr([o[0] for o in self.ops], K.OI_STRIDE, np.int32)),
             ('OFF_ILIST', np.asarray(self.ilist, dtype=np.int32).reshape(-1, 1)),
         ]
@@ -292,6 +380,8 @@ class SceneBuilder:
             ('OFF_FRAME_F', arr(frame_f, K.FF_STRIDE, np.float64)),
             ('OFF_SHAPE_F', arr(shape_f, K.SF_STRIDE, np.float64)),
             ('OFF_POINT_F', arr(points, 3, np.float64)),
+            ('OFF_PLANE_F', arr(planes, 4, np.float64)),
+            ('OFF_CAMERA_F', arr([[*c[5].p, *c[5].quat, c[6], c[7], c[8], 0.0, 0.0] for c in self.cameras], K.CF_STRIDE, np.float64)),
             ('OFF_OP_F', arr([o[1] for o in self.ops], K.OF_STRIDE, np.float64)),
             ('OFF_FLIST', np.asarray(self.flist, dtype=np.float64).reshape(-1, 1)),
         ]
@@ -303,6 +393,8 @@ class SceneBuilder:
         H[K.H_N_FRAMES] = len(frame_i)
         H[K.H_N_SHAPES] = len(shape_i)
         H[K.H_N_POINTS] = len(points)
+        H[K.H_N_PLANES] = len(planes)
+        H[K.H_N_CAMERAS] = len(self.cameras)
         H[K.H_N_PAIRS] = len(pairs)
         H[K.H_N_OPS] = len(self.ops)
         H[K.H_N_ILIST] = len(self.ilist)

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 3
+#define DG_VERSION 4
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -29,6 +29,8 @@ enum {
   DG_H_N_FRAMES,
   DG_H_N_SHAPES,
   DG_H_N_POINTS,     /* convex hull points over all SHAPE_POINTS shapes   */
+  DG_H_N_PLANES,     /* convex hull face planes (ray casting only)         */
+  DG_H_N_CAMERAS,
   DG_H_N_PAIRS,      /* shape pairs that may collide                       */
   DG_H_N_OPS,        /* addon program length                               */
   DG_H_N_ILIST,      /* length of the op int-list pool                     */
@@ -61,6 +63,9 @@ enum {
   DG_H_OFF_FRAME_F,
   DG_H_OFF_SHAPE_F,
   DG_H_OFF_POINT_F,
+  DG_H_OFF_PLANE_F,  /* nx ny nz d per face, n.x + d <= 0 inside, same frame as the points */
+  DG_H_OFF_CAMERA_I,
+  DG_H_OFF_CAMERA_F,
   DG_H_OFF_OP_F,
   DG_H_OFF_FLIST,
   DG_H_INT_COUNT /* header length in I[] */
@@ -94,6 +99,7 @@ enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_E
 
 /* ---- body table ------------------------------------------------------ */
 #define DG_BODY_FIXED 1  /* base does not move (use_fixed_base / massless root) */
+#define DG_BODY_FROZEN 2 /* fixed, no joints and never respawned: its shapes are stored in WORLD coordinates */
 enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF, DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)
@@ -106,7 +112,8 @@ enum {
   DG_BF_REPORT_POS = 17, DG_BF_REPORT_QUAT = 20, /* root inertial frame in the
                                           base link frame: what pybullet's
                                           getBasePositionAndOrientation reports */
-  DG_BF_STRIDE = 24
+  DG_BF_COLOR = 24,                     /* rgba, visual only                  */
+  DG_BF_STRIDE = 28
 };
 
 /* ---- link table (one row per DoF, bodies contiguous, parents first) -- */
@@ -140,10 +147,22 @@ enum { DG_FF_POS = 0, DG_FF_QUAT = 3, DG_FF_COM_POS = 7, DG_FF_COM_QUAT = 10, DG
 
 /* ---- shapes ----------------------------------------------------------- */
 enum { DG_SHAPE_SPHERE = 0, DG_SHAPE_BOX = 1, DG_SHAPE_CAPSULE = 2, DG_SHAPE_POINTS = 3 };
-enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, DG_SI_STRIDE };
+enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, DG_SI_PLANE_OFF, DG_SI_N_PLANES, DG_SI_FLAGS, DG_SI_STRIDE };
+#define DG_SHAPE_WORLD 1 /* transform (and points / planes) are already in world coordinates (frozen body) */
+#define DG_SHAPE_NO_COLLIDE 2 /* visual only: seen by cameras, ignored by the narrow phase */
 enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3] | capsule r, half_len (axis = local z) */,
        DG_SF_FRICTION = 15, DG_SF_STRIDE = 16 };
 enum { DG_PI_A = 0, DG_PI_B, DG_PI_STRIDE };
+
+/* ---- cameras (reference diy_gym/addons/sensors/camera.py:26-98) ------- */
+/* A camera is rendered by its own launch (dg_world_render), not by the step kernel. */
+enum { DG_CI_BODY = 0 /* -1: fixed in the world */, DG_CI_FRAME /* global frame index or -1 = base */, DG_CI_WIDTH, DG_CI_HEIGHT,
+       DG_CI_FLAGS, DG_CI_STRIDE };
+enum { DG_CF_POS = 0, DG_CF_QUAT = 3 /* T_parent_cam */, DG_CF_FOV = 7 /* vertical, degrees */, DG_CF_NEAR = 8, DG_CF_FAR = 9,
+       DG_CF_STRIDE = 12 };
+#define DG_CAM_DEPTH 1
+#define DG_CAM_SEGMENTATION 2
+/* per-body flat colour for the (non parity) rgb output lives in the body float table */
 
 /* ---- addon program ---------------------------------------------------- */
 /* phases: an op runs in exactly one phase */

@@ -510,7 +510,7 @@ static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, double
 }
 
 /* ----------------------------------------------------------- collision */
-typedef struct { int type, body, llink /* local */, glink; m3 R; v3 p; const double* prm; double mu; int poff, npts; } WShape;
+typedef struct { int type, body, llink /* local */, glink; m3 R; v3 p; m3 Rl; v3 pl; /* frame the hull points live in */ const double* prm; double mu; int poff, npts; } WShape;
 
 static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
   const int32_t* si = s->SI + sh * DG_SI_STRIDE; const double* sf = s->SF + sh * DG_SF_STRIDE;
@@ -518,6 +518,8 @@ static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
   const BodyWS* ws = &wsb[o->body];
   o->llink = o->glink < 0 ? -1 : o->glink - ws->first;
   m3 Rl; v3 pl; link_world(ws, o->llink, &Rl, &pl);
+  if (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) { Rl = mident(); pl = V(0, 0, 0); } /* frozen body: stored in world coordinates */
+  o->Rl = Rl; o->pl = pl;
   m3 Rs = mfrom9(sf + DG_SF_ROT);
   o->R = mmul(&Rl, &Rs); o->p = vadd(pl, mv(&Rl, V(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2])));
   o->prm = sf + DG_SF_PARAMS; o->mu = sf[DG_SF_FRICTION]; o->poff = si[DG_SI_POINT_OFF]; o->npts = si[DG_SI_N_POINTS];
@@ -613,7 +615,7 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
     } else if (a->type == DG_SHAPE_POINTS && b->type == DG_SHAPE_BOX) {
       /* hull vertices against the box: keep the 4 deepest (ties -> lower index) */
       int bi[4] = {-1, -1, -1, -1}; double bd[4] = {1e300, 1e300, 1e300, 1e300};
-      m3 Rl; v3 pl; link_world(&wsb[a->body], a->llink, &Rl, &pl);
+      m3 Rl = a->Rl; v3 pl = a->pl;
       for (int k = 0; k < a->npts; k++) {
         const double* pp = s->PF + 3 * (a->poff + k);
         v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));

@@ -28,10 +28,10 @@ class AddonFactory:
     class _Registry:
         def __init__(self):
             from .controllers import InverseKinematicsController, JointController, ExternalForce
-            from .sensors import JointStateSensor, ObjectStateSensor
+            from .sensors import Camera, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
             from .misc import Respawn
-            from .unsupported import (AdmittanceController, Camera, ForceTorqueSensor, StuckJointCost, SpawnMultiple,
+            from .unsupported import (AdmittanceController, ForceTorqueSensor, StuckJointCost, SpawnMultiple,
                                       DrawCoords, VisualRandomizer, DynamicsRandomizer)
             # same 17 keys as reference addon.py:36-54
             self.addons = {

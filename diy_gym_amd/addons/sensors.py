@@ -105,3 +105,68 @@ class ObjectStateSensor(Addon):
         if self.include_rotation and self.include_velocity:
             obs['angular_velocity'] = env._obs_view(k, 3)
         return obs
+
+
+class Camera(Addon):
+    """RGB (+ depth, default ON; + segmentation) from a pinhole camera attached to a model frame or fixed in
+    the world (reference: diy_gym/addons/sensors/camera.py:26-98).  Same config keys and defaults
+    (``clipping_boundaries`` [0.01, 100], ``field_of_view`` 70, ``resolution`` [640, 480], ``frame``, ``xyz``,
+    ``rpy``, ``use_depth`` True, ``use_segmentation_mask`` False).  Rendered by its own kernel launch
+    (``dg_world_render``), lazily, the first time ``observe()`` is called after a step.
+
+    * ``depth`` is what the reference's formula (:82-85) yields: the eye-space z of the nearest surface,
+      i.e. NEGATIVE values in [-far, -near]; -far where the ray hits nothing.
+    * ``segmentation_mask`` is ``uid + ((link + 1) << 24)``, -1 for background.
+    * ``rgb`` is flat-shaded collision geometry -- not comparable with pybullet's lit visual meshes.
+    * Images are the row-major ``height x width`` buffer viewed with shape ``resolution`` (= [w, h]),
+      exactly like the reference's ``reshape`` (:77), so non-square images are scrambled there too.
+    """
+    def __init__(self, parent, config):
+        super().__init__(parent, config)
+        from ..mathx import Transform, quat_from_euler
+        from ..model import Model
+        self.near, self.far = config.get('clipping_boundaries', [0.01, 100])
+        self.fov = config.get('field_of_view', 70.0)
+        self.resolution = list(config.get('resolution', [640, 480]))
+        self.aspect = self.resolution[0] / self.resolution[1]
+        self.uid = parent.uid if isinstance(parent, Model) else -1
+        self.frame_id = parent.get_frame_id(config.get('frame')) if 'frame' in config else -1
+        xyz = config.get('xyz', [0., 0., 0.])
+        rpy = config.get('rpy', [0., 0., 0.])
+        self.use_depth = config.get('use_depth', True)
+        self.use_seg_mask = config.get('use_segmentation_mask', False)
+        self.T_parent_cam = Transform.from_xyz_quat(xyz, quat_from_euler(rpy))
+        sp = OrderedDict(rgb=spaces.Box(0., 1., shape=self.resolution + [3], dtype='float32'))
+        if self.use_depth:
+            sp['depth'] = spaces.Box(0., 10., shape=self.resolution, dtype='float32')
+        if self.use_seg_mask:
+            sp['segmentation_mask'] = spaces.Box(0., 10., shape=self.resolution, dtype='float32')
+        self.observation_space = spaces.Dict(sp)
+        self._tick = None
+        self._buffers = None
+
+    def compile(self, builder):
+        from ..scene import K as _K
+        flags = (_K.CAM_DEPTH if self.use_depth else 0) | (_K.CAM_SEGMENTATION if self.use_seg_mask else 0)
+        self.camera_index = builder.add_camera(self.uid, self.frame_id, self.resolution[0], self.resolution[1], flags,
+                                               self.T_parent_cam, self.fov, self.near, self.far)
+
+    def observe(self):
+        import torch
+        env = self.env
+        B, (w, h) = env.num_envs, self.resolution
+        if self._buffers is None:
+            dev = env.device
+            self._buffers = (torch.zeros((B, w, h, 3), dtype=torch.float32, device=dev),
+                             torch.zeros((B, w, h), dtype=torch.float32, device=dev) if self.use_depth else None,
+                             torch.zeros((B, w, h), dtype=torch.int32, device=dev) if self.use_seg_mask else None)
+        rgb, depth, seg = self._buffers
+        if self._tick != env._tick:
+            env.sim.render(self.camera_index, rgb, depth, seg)
+            self._tick = env._tick
+        obs = OrderedDict(rgb=env._out(rgb))
+        if self.use_depth:
+            obs['depth'] = env._out(depth)
+        if self.use_seg_mask:
+            obs['segmentation_mask'] = env._out(seg)
+        return obs

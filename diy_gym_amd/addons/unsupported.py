@@ -12,7 +12,6 @@ def _stub(name, why):
 
 
 AdmittanceController = _stub('admittance_controller', 'needs batched Jacobian + inverse dynamics (SURVEY 8(f) N1)')
-Camera = _stub('camera', 'batched depth/segmentation rasteriser is scheduled after the state-only configs (SURVEY 8(a) A13)')
 ForceTorqueSensor = _stub('force_torque_sensor', 'joint reaction wrench output is not wired yet (SURVEY 8(f) N1)')
 StuckJointCost = _stub('stuck_joint_cost', 'the reference implementation raises NameError on first use '
                        '(stuck_joint_cost.py:16-21); there is no behaviour to match')

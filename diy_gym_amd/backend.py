@@ -35,6 +35,7 @@ SYMBOLS = {
     'dg_world_step': (ctypes.c_int32, [_vp, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dg_world_observe': (ctypes.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dg_world_frame_state': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
+    'dg_world_render': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     'dg_world_set_diag_buffer': (ctypes.c_int32, [_vp, _vp]),
     'dg_world_set_profile_buffer': (ctypes.c_int32, [_vp, _vp]),
 }
@@ -137,6 +138,9 @@ class HipBackend:
         self._check(self.lib.dg_world_frame_state(self.handle, _ptr(self.state), int(body), int(frame), int(bool(com)), _ptr(out),
                                                   self._stream()))
         return out
+
+    def render(self, camera, rgb=None, depth=None, seg=None):
+        self._check(self.lib.dg_world_render(self.handle, _ptr(self.state), int(camera), _ptr(rgb), _ptr(depth), _ptr(seg), self._stream()))
 
     def motor_cfg(self):
         cfg = np.zeros((self.n_links, 3), dtype=np.float64)

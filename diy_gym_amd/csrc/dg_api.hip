@@ -11,6 +11,7 @@
 
 #include "../../include/diygym_hip.h"
 #include "dg_solver.h"
+#include "dg_render.h"
 
 using namespace dg;
 
@@ -103,6 +104,7 @@ struct dg_world {
   void* d_blob_i = nullptr; void* d_blob_f = nullptr; void* d_plan = nullptr; float* d_init = nullptr;
   int32_t* diag = nullptr;
   unsigned long long* profile_cycles = nullptr;
+  int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
 };
 
 extern "C" {
@@ -217,11 +219,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     for (int k = 0; k < 4; k++) init[so + DG_BS_QUAT + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_QUAT + k];
   }
   HIP_TRY(hipMalloc((void**)&w->d_init, sizeof(float) * init.size())); HIP_TRY(hipMemcpy(w->d_init, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
+  // cameras: per-env shape/camera pose table written by pose_kernel, read by render_kernel
+  w->ncam = I[DG_H_N_CAMERAS]; w->d_CI = dI + I[DG_H_OFF_CAMERA_I]; w->d_CF = dF + I[DG_H_OFF_CAMERA_F]; w->d_PLN = dF + I[DG_H_OFF_PLANE_F];
+  if (w->ncam > 0) HIP_TRY(hipMalloc((void**)&w->d_render_table, sizeof(float) * (size_t)num_envs * (size_t)(sc.nsh * RS_STRIDE + w->ncam * RC_STRIDE)));
   // allow > 64 KiB of dynamic LDS
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
-  if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); }
-  else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); }
-  else { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); }
+  if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
+  else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); SET_ATTR(pose_kernel<32>); }
+  else { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
 #undef SET_ATTR
   *out = w;
   return DG_OK;
@@ -229,7 +234,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
 
 void dg_world_destroy(dg_world* w) {
   if (!w) return;
-  (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
+  (void)hipFree(w->d_render_table); (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
   delete w;
 }
 
@@ -303,6 +308,18 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
     else hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
   }
+  return DG_OK;
+}
+
+int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  if (camera < 0 || camera >= w->ncam) return fail(DG_ERR_ARG, "camera %d out of range (scene has %d)", camera, w->ncam);
+  LAUNCH(pose_kernel, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table);
+  const int32_t* I = w->I.data(); const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE;
+  const int npix = ci[DG_CI_WIDTH] * ci[DG_CI_HEIGHT];
+  hipLaunchKernelGGL(render_kernel, dim3((npix + 255) / 256, w->num_envs), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+                     (cfp)w->d_render_table, rgb, depth, seg);
+  HIP_TRY(hipGetLastError());
   return DG_OK;
 }
 

@@ -95,6 +95,7 @@ class DIYGym(Receptor):
         self.sim = backend_factory(self.layout, self.num_envs, device=device, seed=seed, env_index_base=env_index_base)
         self.device = self.sim.device
         self._mask = 0
+        self._tick = 0  # bumps whenever the simulation state changes (cameras render lazily per tick)
         self._all_slots = (1 << self.layout.n_slots) - 1 if self.layout.n_slots else 0
         self._has_hook_rewards = any(type(a).reward is not Addon.reward for a in self._hook_addons)
         self._has_hook_terminals = any(type(a).is_terminal is not Addon.is_terminal for a in self._hook_addons)
@@ -168,6 +169,7 @@ class DIYGym(Receptor):
         for addon in self._hook_addons:
             addon.reset()
         self.sim.reset(mask)
+        self._tick += 1
         return self.observe(_refresh=False)
 
     def observe(self, _refresh=True):
@@ -201,6 +203,7 @@ class DIYGym(Receptor):
                 # the flat action tensor already has the kernel's column order: hand it over as is
                 act = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, -1).contiguous()
                 self.sim.step(self._all_slots, act)
+                self._tick += 1
                 return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}
             action = unflatten(torch.as_tensor(np.asarray(action, dtype=np.float32)) if not isinstance(action, torch.Tensor)
                                else action, self.original_action_space, batch_dims=0 if self.compat else 1)
@@ -209,6 +212,7 @@ class DIYGym(Receptor):
             for addon_name, addon_action in receptor_action.items():
                 self.receptors[receptor_name].addons[addon_name].update(addon_action)
         self.sim.step(self._mask)
+        self._tick += 1
         return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}
 
     def walk_addons(self, func):

@@ -61,7 +61,9 @@ class Model(Receptor):
                              mass_override=config.get('mass') if 'mass' in config else None,
                              mesh_loader=mesh.load_convex, max_hull_points=self.env.max_hull_points)
         self.uid = self.env.builder.add_body(self.flat, self.position, self.orientation)
-        self.color = config.get('color') if 'color' in config else None  # visual only
+        self.color = config.get('color') if 'color' in config else None  # visual only (camera rgb)
+        if self.color is not None:
+            self.env.builder.set_color(self.uid, list(self.color) + [1.0] * (4 - len(self.color)))
 
         self.addons = OrderedDict(
             sorted(((child.name, AddonFactory.build(child.get('addon'), self, child)) for child in config.find_all('addon')),

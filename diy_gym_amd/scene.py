@@ -316,6 +316,7 @@ class SceneBuilder:
                     T, r, half = fit_capsule(pts)
                     prm = np.array([r, half, 0.0])
                 wflag = (K.SHAPE_WORLD if frozen else 0) | (K.SHAPE_NO_COLLIDE if getattr(sh, 'visual_only', False) else 0)
+                wflag |= ((sh.urdf_link + 1) & 0xFFFF) << 8  # pybullet link index + 1, for segmentation masks
                 if frozen:  # bake the body pose in
                     T = T_body * T
                     if pts is not None:

@@ -265,7 +265,8 @@ class FlatFrame:
 
 
 class FlatShape:
-    def __init__(self, kind, link, T, params, points=None, friction=1.0):
+    def __init__(self, kind, link, T, params, points=None, friction=1.0, urdf_link=-1):
+        self.urdf_link = urdf_link  # pybullet link index of the URDF link that owns the shape (-1 = base)
         self.kind = kind
         self.link = link
         self.T = T  # shape frame in the link's reference frame
@@ -311,8 +312,9 @@ class FlatBody:
             a[1] += mass * c
             a[2] += Ic + mass * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
 
-        def add_shapes(anchor, T_anchor_link, link):
+        def add_shapes(anchor, T_anchor_link, link, urdf_link=-1):
             mu = link.lateral_friction if link.lateral_friction is not None else 0.5
+            n_before = len(self.shapes)
             for sh in link.collisions:
                 T = T_anchor_link * Transform(sh.origin.R, sh.origin.p * s)
                 if sh.kind == 'sphere':
@@ -333,6 +335,8 @@ class FlatBody:
                         continue
                     pts = (pts * sh.mesh_scale[None, :] * s) @ T.R.T + T.p
                     self.shapes.append(FlatShape(SHAPE_POINTS, anchor, Transform(), np.zeros(3), points=pts, friction=mu))
+            for shp in self.shapes[n_before:]:
+                shp.urdf_link = urdf_link
 
         # root
         self.base_name = root.name
@@ -365,7 +369,7 @@ class FlatBody:
                 anchor, T_anchor_child = p_anchor, T_joint
             anchor_of[j.child] = (anchor, T_anchor_child)
             add_inertia(anchor, T_anchor_child, child, child.mass, child.inertia)
-            add_shapes(anchor, T_anchor_child, child)
+            add_shapes(anchor, T_anchor_child, child, j.index)
             T_com = T_anchor_child * Transform(child.inertial_origin.R, child.inertial_origin.p * s)
             self.frames.append(FlatFrame(j.name, anchor, T_anchor_child, T_com))
 

@@ -92,6 +92,14 @@ int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew
 int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int32_t frame, int32_t com, float* out,
                              void* stream);
 
+/* Replaces Camera.observe -> p.computeProjectionMatrixFOV / p.getCameraImage (reference
+ * diy_gym/addons/sensors/camera.py:44,58-92) for camera `camera` of the scene, all envs:
+ *   rgb   float [num_envs][h*w*3]  flat shaded body colour (NOT a parity output: pybullet renders visual meshes)
+ *   depth float [num_envs][h*w]    eye-space z exactly as camera.py:82-85 computes it (negative; -far = nothing hit)
+ *   seg   int32 [num_envs][h*w]    uid + ((link + 1) << 24), -1 = background
+ * flat pixel index = row * width + col, row 0 at the top; any pointer may be NULL. */
+int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream);
+
 /* Per-env diagnostics of the last step: diag[num_envs][2] = contact count,
  * solver iterations of the final substep (int32).  Optional; pass NULL to
  * disable (default).  The buffer must stay valid until changed. */

@@ -150,6 +150,7 @@ enum { DG_SHAPE_SPHERE = 0, DG_SHAPE_BOX = 1, DG_SHAPE_CAPSULE = 2, DG_SHAPE_POI
 enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, DG_SI_PLANE_OFF, DG_SI_N_PLANES, DG_SI_FLAGS, DG_SI_STRIDE };
 #define DG_SHAPE_WORLD 1 /* transform (and points / planes) are already in world coordinates (frozen body) */
 #define DG_SHAPE_NO_COLLIDE 2 /* visual only: seen by cameras, ignored by the narrow phase */
+/* flags bits 8..23: (pybullet link index of the owning URDF link) + 1, 0 = base; used by segmentation masks */
 enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3] | capsule r, half_len (axis = local z) */,
        DG_SF_FRICTION = 15, DG_SF_STRIDE = 16 };
 enum { DG_PI_A = 0, DG_PI_B, DG_PI_STRIDE };

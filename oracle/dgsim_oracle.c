@@ -1127,6 +1127,117 @@ int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* 
   return dgo_observe(w, obs, rew, term, rew_sum, term_flag);
 }
 
+/* --------------------------------------------------------------- camera */
+/* Restates Camera.observe (camera.py:58-92): view = inv(T_world_parent T_parent_cam), OpenGL eye frame
+ * (looks down -z, +y up), gluPerspective(fov, aspect = res[0]/res[1], near, far); the reference's depth
+ * formula (:82-85) returns the eye-space z of the nearest surface (negative; -far where nothing is hit).
+ * pybullet's DIRECT-mode renderer draws the VISUAL meshes with lighting; this restatement ray-casts the
+ * collision geometry, so rgb is not a parity quantity. */
+typedef struct { double t; v3 n; int shape; } RayHit;
+static void ray_sphere(v3 o, v3 d, v3 c, double r, RayHit* h, int sh) {
+  v3 oc = vsub(o, c); double a = vdot(d, d), b = vdot(oc, d), cc = vdot(oc, oc) - r * r, disc = b * b - a * cc;
+  if (disc < 0) return;
+  double t = (-b - sqrt(disc)) / a;
+  if (t > 0 && t < h->t) { h->t = t; h->n = vscale(vsub(vadd(o, vscale(d, t)), c), 1.0 / r); h->shape = sh; }
+}
+static void ray_slabs(v3 o, v3 d, const double* hx, double* tn, double* tf, int* axis, double* sgn) {
+  double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}; *tn = -1e300; *tf = 1e300; *axis = 0; *sgn = 1;
+  for (int k = 0; k < 3; k++) {
+    if (fabs(dd[k]) < 1e-300) { if (fabs(oo[k]) > hx[k]) { *tn = 1e300; *tf = -1e300; } continue; }
+    double t1 = (-hx[k] - oo[k]) / dd[k], t2 = (hx[k] - oo[k]) / dd[k], s = -1;
+    if (t1 > t2) { double tt = t1; t1 = t2; t2 = tt; s = 1; }
+    if (t1 > *tn) { *tn = t1; *axis = k; *sgn = s; }
+    if (t2 < *tf) *tf = t2;
+  }
+}
+static void ray_box(v3 o, v3 d, const m3* R, v3 p, const double* hx, RayHit* h, int sh) {
+  v3 ol = mtv(R, vsub(o, p)), dl = mtv(R, d); double tn, tf, sg; int ax;
+  ray_slabs(ol, dl, hx, &tn, &tf, &ax, &sg);
+  if (tn > tf || tn <= 0 || tn >= h->t) return;
+  v3 nl = V(ax == 0 ? sg : 0, ax == 1 ? sg : 0, ax == 2 ? sg : 0);
+  h->t = tn; h->n = mv(R, nl); h->shape = sh;
+}
+static void ray_capsule(v3 o, v3 d, v3 e0, v3 e1, double r, RayHit* h, int sh) {
+  v3 ax = vsub(e1, e0); double L2 = vdot(ax, ax);
+  if (L2 > 1e-24) {
+    v3 oc = vsub(o, e0); double dax = vdot(d, ax), oax = vdot(oc, ax);
+    double a = vdot(d, d) - dax * dax / L2, b = vdot(oc, d) - oax * dax / L2, c = vdot(oc, oc) - oax * oax / L2 - r * r, disc = b * b - a * c;
+    if (a > 1e-24 && disc >= 0) {
+      double t = (-b - sqrt(disc)) / a, s = (oax + t * dax) / L2;
+      if (t > 0 && t < h->t && s >= 0 && s <= 1) {
+        v3 pt = vadd(o, vscale(d, t)); v3 q = vadd(e0, vscale(ax, s));
+        h->t = t; h->n = vscale(vsub(pt, q), 1.0 / r); h->shape = sh;
+      }
+    }
+  }
+  ray_sphere(o, d, e0, r, h, sh); ray_sphere(o, d, e1, r, h, sh);
+}
+static void ray_hull(v3 o, v3 d, const m3* Rl, v3 pl, const double* planes, int np, RayHit* h, int sh) {
+  v3 ol = mtv(Rl, vsub(o, pl)), dl = mtv(Rl, d); double tn = -1e300, tf = 1e300; v3 nn = V(0, 0, 1);
+  for (int k = 0; k < np; k++) {
+    const double* pp = planes + 4 * k; v3 n = V(pp[0], pp[1], pp[2]);
+    double den = vdot(n, dl), dist = vdot(n, ol) + pp[3];
+    if (fabs(den) < 1e-300) { if (dist > 0) return; continue; }
+    double t = -dist / den;
+    if (den < 0) { if (t > tn) { tn = t; nn = n; } } else if (t < tf) tf = t;
+  }
+  if (np == 0 || tn > tf || tn <= 0 || tn >= h->t) return;
+  h->t = tn; h->n = mv(Rl, nn); h->shape = sh;
+}
+int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t* seg) {
+  Scene* s = &w->sc; const int32_t* I = s->I; const double* F = s->F;
+  if (camera < 0 || camera >= I[DG_H_N_CAMERAS]) { set_err("camera %d out of range", camera); return -1; }
+  const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE; const double* cf = F + I[DG_H_OFF_CAMERA_F] + camera * DG_CF_STRIDE;
+  const double* PLN = F + I[DG_H_OFF_PLANE_F];
+  const int W = ci[DG_CI_WIDTH], Hh = ci[DG_CI_HEIGHT]; const double fov = cf[DG_CF_FOV], zn = cf[DG_CF_NEAR], zf = cf[DG_CF_FAR];
+  const double tanh2 = tan(0.5 * fov * M_PI / 180.0), aspect = (double)W / (double)Hh;
+  const v3 light = V(0.30151134457776363, 0.30151134457776363, 0.9045340337332909);
+  for (int e = 0; e < w->B; e++) {
+    const double* st = env_state(w, e);
+    BodyWS* wsb = (BodyWS*)malloc(sizeof(BodyWS) * (size_t)s->nb);
+    for (int b = 0; b < s->nb; b++) body_kinematics(s, st, b, &wsb[b], NULL);
+    /* camera pose */
+    m3 Rp = mident(); v3 pp = V(0, 0, 0);
+    if (ci[DG_CI_BODY] >= 0) {
+      FrameState f; frame_state(s, st, ci[DG_CI_BODY], ci[DG_CI_FRAME], ci[DG_CI_FRAME] < 0, NULL, &f); /* link: item 4,5; base: reported pose */
+      Rp = qmat(f.q); pp = f.p;
+    }
+    qt qc = {cf[DG_CF_QUAT], cf[DG_CF_QUAT + 1], cf[DG_CF_QUAT + 2], cf[DG_CF_QUAT + 3]}; m3 Rc0 = qmat(qc);
+    m3 Rc = mmul(&Rp, &Rc0); v3 pc = vadd(pp, mv(&Rp, V(cf[DG_CF_POS], cf[DG_CF_POS + 1], cf[DG_CF_POS + 2])));
+    WShape* shp = (WShape*)malloc(sizeof(WShape) * (size_t)(s->nsh > 0 ? s->nsh : 1));
+    for (int k = 0; k < s->nsh; k++) shape_world(s, wsb, k, &shp[k]);
+    for (int row = 0; row < Hh; row++) for (int col = 0; col < W; col++) {
+      const double xn = ((col + 0.5) / W) * 2.0 - 1.0, yn = 1.0 - ((row + 0.5) / Hh) * 2.0;
+      v3 d = mv(&Rc, V(xn * tanh2 * aspect, yn * tanh2, -1.0));
+      RayHit h; h.t = zf; h.shape = -1; h.n = V(0, 0, 1);
+      for (int k = 0; k < s->nsh; k++) {
+        const WShape* a = &shp[k]; const int32_t* si = s->SI + k * DG_SI_STRIDE;
+        if (a->type == DG_SHAPE_SPHERE) ray_sphere(pc, d, a->p, a->prm[0], &h, k);
+        else if (a->type == DG_SHAPE_BOX) ray_box(pc, d, &a->R, a->p, a->prm, &h, k);
+        else if (a->type == DG_SHAPE_CAPSULE) { v3 e0, e1; seg_ends(a, &e0, &e1); ray_capsule(pc, d, e0, e1, a->prm[0], &h, k); }
+        else ray_hull(pc, d, &a->Rl, a->pl, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], &h, k);
+      }
+      const int hit = h.shape >= 0 && h.t >= zn; const size_t px = (size_t)e * W * Hh + (size_t)row * W + col;
+      if (depth) depth[px] = hit ? -h.t : -zf;
+      if (seg) {
+        if (!hit) seg[px] = -1;
+        else { const int32_t* si = s->SI + h.shape * DG_SI_STRIDE; seg[px] = si[DG_SI_BODY] + ((((si[DG_SI_FLAGS] >> 8) & 0xFFFF)) << 24); }
+      }
+      if (rgb) {
+        double c[3] = {0.75, 0.75, 0.75};
+        if (hit) {
+          const double* col4 = body_f(s, s->SI[h.shape * DG_SI_STRIDE + DG_SI_BODY]) + DG_BF_COLOR;
+          double nl = vdot(h.n, light); double sh = 0.4 + 0.6 * (nl > 0 ? nl : 0);
+          for (int k = 0; k < 3; k++) c[k] = col4[k] * sh;
+        }
+        for (int k = 0; k < 3; k++) rgb[3 * px + k] = c[k];
+      }
+    }
+    free(shp); free(wsb);
+  }
+  return 0;
+}
+
 int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, double* qdd_out, double* base_acc6_out) {
   Scene* s = &w->sc; double* st = env_state(w, env);
   BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));

@@ -50,6 +50,13 @@ int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* r
  * inertial frame (getLinkState items 0,1,6,7), else the URDF link frame (4,5). */
 int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, double* out13);
 
+/* camera `camera` (index in the blob's camera table) for every env, by ray casting the collision
+ * geometry (reference diy_gym/addons/sensors/camera.py:58-92).  rgb[num_envs][h*w*3] (flat shaded,
+ * NOT a parity output), depth[num_envs][h*w] = eye-space z as the reference's formula yields it
+ * (negative, -far for background), seg[num_envs][h*w] = uid + ((link + 1) << 24), -1 background.
+ * Flat pixel index = row * width + col, row 0 at the top.  Any pointer may be NULL. */
+int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t* seg);
+
 /* diagnostics from the most recent substep of env `env` */
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env);
 int32_t dgo_last_iterations(const dgo_world* w, int32_t env);

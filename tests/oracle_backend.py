@@ -41,6 +41,7 @@ def lib():
         L.dgo_forward_dynamics.argtypes = [vp, i32, i32, vp, vp]
         L.dgo_unit_response.argtypes = [vp, i32, i32, i32, vp]
         L.dgo_ik.argtypes = [vp, i32, i32, vp, vp]
+        L.dgo_render.argtypes = [vp, i32, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -126,6 +127,21 @@ class OracleBackend:
         FI = I[I[K.H_OFF_FRAME_I]:I[K.H_OFF_FRAME_I] + I[K.H_N_FRAMES] * K.FI_STRIDE].reshape(-1, K.FI_STRIDE)
         idx = np.nonzero(FI[:, K.FI_BODY] == body)[0]
         return int(idx[frame])
+
+    def render(self, camera, rgb=None, depth=None, seg=None):
+        r64 = np.zeros(tuple(rgb.shape)) if rgb is not None else None
+        d64 = np.zeros(tuple(depth.shape)) if depth is not None else None
+        s32 = np.zeros(tuple(seg.shape), dtype=np.int32) if seg is not None else None
+        rc = self.L.dgo_render(self.handle, int(camera), _p(r64), _p(d64), _p(s32))
+        if rc:
+            raise RuntimeError(self.L.dgo_last_error().decode())
+        if rgb is not None:
+            rgb.copy_(torch.from_numpy(r64).float())
+        if depth is not None:
+            depth.copy_(torch.from_numpy(d64).float())
+        if seg is not None:
+            seg.copy_(torch.from_numpy(s32))
+        self.last_render64 = (r64, d64, s32)
 
     def motor_cfg(self):
         return self._mcfg[:self.n_links].copy()

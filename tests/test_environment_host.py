@@ -147,4 +147,4 @@ def test_error_conventions():
     with pytest.raises(ValueError, match='Could not find URDF'):
         DIYGym(Configuration.from_dict('e', {'x': {'model': 'nope.urdf'}}), backend_factory=OracleBackend)
     with pytest.raises(NotImplementedError):
-        DIYGym(Configuration.from_dict('e', {'cam': {'addon': 'camera'}}), backend_factory=OracleBackend)
+        DIYGym(Configuration.from_dict('e', {'gui': {'addon': 'draw_coords'}}), backend_factory=OracleBackend)

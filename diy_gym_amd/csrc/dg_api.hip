@@ -26,11 +26,13 @@ static int fail(int code, const char* fmt, ...) {
 template <int LANES, bool PROF>
 __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
                                                    float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
-                                                   unsigned long long* cycles) {
+                                                   unsigned long long* cycles, float* gws) {
   extern __shared__ float smem[];
-  const int lane = threadIdx.x; if (lane >= LANES) return;
-  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, valid);
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  // lanes past the batch use their own (padded) scratch column, never another env's
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
   Prof<PROF> prof; prof.start();
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   prof.stamp(PS_KIN);
@@ -48,11 +50,13 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
 }
 
 template <int LANES>
-__global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs) {
+__global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws) {
   extern __shared__ float smem[];
-  const int lane = threadIdx.x; if (lane >= LANES) return;
-  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, valid);
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  // lanes past the batch use their own (padded) scratch column, never another env's
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
   const bool doit = valid && (mask == nullptr || mask[e] != 0);
   if (doit) {
     ln.Sset(DG_ST_STEP, 0.0f);
@@ -68,11 +72,12 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
 
 template <int LANES>
 __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term,
-                                                      float* rew_sum, uint8_t* term_flag) {
+                                                      float* rew_sum, uint8_t* term_flag, float* gws) {
   extern __shared__ float smem[];
-  const int lane = threadIdx.x; if (lane >= LANES) return;
-  const int env = blockIdx.x * LANES + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, smem + lane, state + e, e, false);  // never stores state
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, false);  // never stores state
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
@@ -80,11 +85,12 @@ __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt,
 }
 
 template <int LANES>
-__global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out) {
+__global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws) {
   extern __shared__ float smem[];
-  const int lane = threadIdx.x; if (lane >= LANES) return;
-  const int env = blockIdx.x * LANES + lane; if (env >= sc.num_envs) return;
-  Lane<LANES> ln(sc, mt, smem + lane, state + env, env, false);
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + env, state + env, env, false);
   ln.kinematics(body);
   V3 p, v, w; Q4 q; ln.frame_state(body, frame, com != 0, p, q, v, w, true);
   float* o = out + (size_t)env * 13;
@@ -104,6 +110,7 @@ struct dg_world {
   void* d_blob_i = nullptr; void* d_blob_f = nullptr; void* d_plan = nullptr; float* d_init = nullptr;
   int32_t* diag = nullptr;
   unsigned long long* profile_cycles = nullptr;
+  float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
 };
 
@@ -156,19 +163,29 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     }
     tr = std::max(tr, need);
   }
-  tr = std::max(tr, 3 * maxc * (4 * nvmax + 3));
+  // contact rows carry a second body's Jacobian / response only if some candidate pair has two moving bodies
+  bool two_sided = false;
+  { const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
+    auto moving = [&](int sh) { const int32_t* B = BI + SIh[sh * DG_SI_STRIDE + DG_SI_BODY] * DG_BI_STRIDE; return !((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0); };
+    for (int p = 0; p < I[DG_H_N_PAIRS]; p++) if (moving(PIh[p * DG_PI_STRIDE + DG_PI_A]) && moving(PIh[p * DG_PI_STRIDE + DG_PI_B])) two_sided = true; }
+  const int crow_tail = (two_sided ? 4 : 2) * nvmax;
+  tr = std::max(tr, 3 * maxc * (crow_tail + 3));
   if (I[DG_H_N_PAIRS] > 0) tr = std::max(tr, (int)SC_STRIDE * I[DG_H_N_SHAPES]);  // narrow-phase shape cache
   for (int op = 0; op < I[DG_H_N_OPS]; op++)
     if (OI[op * DG_OI_STRIDE + DG_OI_CODE] == DG_OP_IK_CONTROL) {
       const int n = BI[OI[op * DG_OI_STRIDE + DG_OI_BODY] * DG_BI_STRIDE + DG_BI_N_LINKS];
-      if (!(OI[op * DG_OI_STRIDE + DG_OI_FLAGS] & DG_IK_NULLSPACE)) { delete w; return fail(DG_ERR_UNSUPPORTED, "joint-space DLS IK (non null-space variant) is not implemented on device yet"); }
       tr = std::max(tr, 9 * n);
     }
   slot += tr;
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
   while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
-  if (lanes < 16) { delete w; return fail(DG_ERR_UNSUPPORTED, "scene needs %d LDS slots per env; does not fit 160 KiB even at 16 envs per wavefront", total); }
+  if (lanes < 16) {
+    // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer [slot][env_stride]
+    // (coalesced, L2-resident); same kernels, Lane<0>
+    lanes = 0;
+    HIP_TRY(hipMalloc((void**)&w->d_gws, sizeof(float) * (size_t)total * (size_t)env_stride));
+  }
   w->lanes = lanes; w->lds_bytes = total * lanes * 4;
   // ---- device tables (floats converted once)
   std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
@@ -198,7 +215,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
   sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
-  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride;
+  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   // bodies whose solver rows are held in registers by the step kernel
   sc.reg_body[0] = sc.reg_body[1] = -1;
@@ -214,7 +231,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   std::vector<float> init((size_t)sc.state_dim, 0.f);
   const double* BF = F + I[DG_H_OFF_BODY_F];
   for (int b = 0; b < nb; b++) {
-    const int so = BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF];
+    const int so = BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF]; if (so < 0) continue;  // frozen: no state
     for (int k = 0; k < 3; k++) init[so + DG_BS_POS + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_POS + k];
     for (int k = 0; k < 4; k++) init[so + DG_BS_QUAT + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_QUAT + k];
   }
@@ -226,7 +243,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
   if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
   else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); SET_ATTR(pose_kernel<32>); }
-  else { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
+  else if (lanes == 16) { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
 #undef SET_ATTR
   *out = w;
   return DG_OK;
@@ -234,7 +251,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
 
 void dg_world_destroy(dg_world* w) {
   if (!w) return;
-  (void)hipFree(w->d_render_table); (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
+  (void)hipFree(w->d_gws); (void)hipFree(w->d_render_table); (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
   delete w;
 }
 
@@ -263,13 +280,15 @@ int32_t dg_world_init_state(dg_world* w, float* state, void* stream) {
   return DG_OK;
 }
 
-#define LAUNCH(KERNEL, ...)                                                                                              \
-  do {                                                                                                                   \
-    const dim3 grid((w->num_envs + w->lanes - 1) / w->lanes), block(64);                                                 \
-    if (w->lanes == 64) hipLaunchKernelGGL(KERNEL<64>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__);     \
-    else if (w->lanes == 32) hipLaunchKernelGGL(KERNEL<32>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<16>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__);                    \
-    HIP_TRY(hipGetLastError());                                                                                          \
+#define LAUNCH(KERNEL, ...)                                                                                                  \
+  do {                                                                                                                       \
+    const int per = w->lanes > 0 ? w->lanes : 64;                                                                            \
+    const dim3 grid((w->num_envs + per - 1) / per), block(64);                                                               \
+    if (w->lanes == 64) hipLaunchKernelGGL(KERNEL<64>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws);      \
+    else if (w->lanes == 32) hipLaunchKernelGGL(KERNEL<32>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws); \
+    else if (w->lanes == 16) hipLaunchKernelGGL(KERNEL<16>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws); \
+    else hipLaunchKernelGGL(KERNEL<0>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__, w->d_gws);                          \
+    HIP_TRY(hipGetLastError());                                                                                              \
   } while (0)
 
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
@@ -299,13 +318,17 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
     }
   }
   {
-    const dim3 grid((w->num_envs + w->lanes - 1) / w->lanes), block(64); hipStream_t st = (hipStream_t)stream;
+    const int per = w->lanes > 0 ? w->lanes : 64;
+    const dim3 grid((w->num_envs + per - 1) / per), block(64); hipStream_t st = (hipStream_t)stream;
+#define STEP_ARGS w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag
     if (w->profile_cycles) {
       if (w->lanes != 64) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 envs per wavefront only");
-      hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles);
-    } else if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
-    else if (w->lanes == 32) hipLaunchKernelGGL((step_kernel<32, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, (unsigned long long*)nullptr);
+      hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
+    } else if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
+    else if (w->lanes == 32) hipLaunchKernelGGL((step_kernel<32, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
+    else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
+    else hipLaunchKernelGGL((step_kernel<0, false>), grid, block, 0, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
+#undef STEP_ARGS
     HIP_TRY(hipGetLastError());
   }
   return DG_OK;

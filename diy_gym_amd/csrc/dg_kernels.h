@@ -45,6 +45,7 @@ struct DevScene {
   int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
+  int32_t crow_tail;    // contact row: [JA nv_max][RA nv_max]([JB][RB] only if some pair has two moving bodies)[b][acc][diag]
   int32_t reg_body[2];  // up to two fixed-base bodies with <= 6 joints whose solver rows live in registers (-1: none)
   int32_t num_envs, stride;
   uint64_t seed; int64_t env_base;
@@ -69,14 +70,15 @@ template <int LANES>
 struct Lane {
   const DevScene& sc;
   const MotorTable& mt;
-  float* lds;   // workspace base for this lane (already offset by lane)
+  float* lds;   // workspace base for this lane (already offset by lane): LDS, or -- LANES == 0 -- a per-env
+                // column of a global scratch buffer [slot][env_stride] for scenes too big for 160 KiB of LDS
   float* st;    // state base for this env (already offset by env)
   int env;      // clamped env index
   bool valid;   // this lane owns a real env (stores allowed)
 
   DGD Lane(const DevScene& s, const MotorTable& m, float* l, float* state, int e, bool v) : sc(s), mt(m), lds(l), st(state), env(e), valid(v) {}
 
-  DGD float& L(int slot) const { return lds[slot * LANES]; }
+  DGD float& L(int slot) const { if constexpr (LANES > 0) return lds[slot * LANES]; else return lds[(size_t)slot * sc.stride]; }
   DGD float S(int k) const { return st[(size_t)k * sc.stride]; }
   DGD void Sset(int k, float v) const { if (valid) st[(size_t)k * sc.stride] = v; }
 
@@ -121,8 +123,14 @@ struct Lane {
   DGD bool frozen(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FROZEN; }
   DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
 
-  DGD V3 base_pos(int b) const { int o = bi(b)[DG_BI_STATE_OFF]; return v3(S(o), S(o + 1), S(o + 2)); }
-  DGD Q4 base_quat(int b) const { int o = bi(b)[DG_BI_STATE_OFF] + DG_BS_QUAT; Q4 q = {S(o), S(o + 1), S(o + 2), S(o + 3)}; return q; }
+  DGD V3 base_pos(int b) const {
+    if (frozen(b)) { cfp f = bf(b) + DG_BF_INIT_POS; return v3(f[0], f[1], f[2]); }
+    int o = bi(b)[DG_BI_STATE_OFF]; return v3(S(o), S(o + 1), S(o + 2));
+  }
+  DGD Q4 base_quat(int b) const {
+    if (frozen(b)) { cfp f = bf(b) + DG_BF_INIT_QUAT; Q4 q = {f[0], f[1], f[2], f[3]}; return q; }
+    int o = bi(b)[DG_BI_STATE_OFF] + DG_BS_QUAT; Q4 q = {S(o), S(o + 1), S(o + 2), S(o + 3)}; return q;
+  }
 
   // link (global index, -1 = base of body b) world frame from the POSE region
   DGD void link_world(int b, int gl, M3& R, V3& p) const {

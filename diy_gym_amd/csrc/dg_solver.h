@@ -181,7 +181,7 @@ DGD int collide(const Lane<LANES>& ln) {
 // ------------------------------------------------------------------- rows
 // contact row r (3 per contact: normal, t1, t2) in the transient region:
 //   [JA nvmax][RA nvmax][JB nvmax][RB nvmax][b][acc][diag]     (dv offsets / lengths live in the contact list)
-DGD int crow_stride(int nvmax) { return 4 * nvmax + 3; }
+DGD int crow_stride(int tail) { return tail + 3; }
 
 DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
   if (fabsf(n.z) > 0.70710678118654752f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); t1 = v3(0.f, -n.z * k, n.y * k); t2 = v3(a * k, -n.x * t1.z, n.x * t1.y); }
@@ -191,7 +191,7 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
 // builds the three rows of contact slot c for the lanes whose contact belongs to (uniform) pair `pair`
 template <int LANES>
 DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
-  const DevScene& sc = ln.sc; const int nvm = sc.nv_max, rs = crow_stride(nvm);
+  const DevScene& sc = ln.sc; const int nvm = sc.nv_max, tl = sc.crow_tail, rs = crow_stride(tl);
   cip sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; cip sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
   const int ba = sa[DG_SI_BODY], la = sa[DG_SI_LINK], bb = sb[DG_SI_BODY], lb = sb[DG_SI_LINK];
   const bool a_dyn = !(ln.fixed(ba) && ln.bi(ba)[DG_BI_N_LINKS] == 0), b_dyn = !(ln.fixed(bb) && ln.bi(bb)[DG_BI_N_LINKS] == 0);
@@ -213,7 +213,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
     } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
     if (d == 0) { float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-    ln.L(ro + 4 * nvm) = b; ln.L(ro + 4 * nvm + 1) = 0.f; ln.L(ro + 4 * nvm + 2) = diag;
+    ln.L(ro + tl) = b; ln.L(ro + tl + 1) = 0.f; ln.L(ro + tl + 2) = diag;
   }
 }
 
@@ -221,15 +221,15 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
 template <int LANES>
 DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, bool live, bool has) {
   if (!has) return 0.f;  // lanes without this contact slot hold no row data at all
-  const int nvm = ln.sc.nv_max;
+  const int nvm = ln.sc.nv_max, tl = ln.sc.crow_tail;
   const int dA = (int)ln.L(co + CL_DVA), nA = (int)ln.L(co + CL_NVA), dB = (int)ln.L(co + CL_DVB), nB = (int)ln.L(co + CL_NVB);
   float jv = 0.f;
   for (int k = 0; k < nvm; k++) { if (k < nA) jv += ln.L(ro + k) * ln.L(dA + k); if (k < nB) jv += ln.L(ro + 2 * nvm + k) * ln.L(dB + k); }
-  float diag = ln.L(ro + 4 * nvm + 2), acc = ln.L(ro + 4 * nvm + 1);
-  float delta = (ln.L(ro + 4 * nvm) - jv) / diag;
+  float diag = ln.L(ro + tl + 2), acc = ln.L(ro + tl + 1);
+  float delta = (ln.L(ro + tl) - jv) / diag;
   float nacc = fminf(fmaxf(acc + delta, lo), hi);
   delta = live && diag > 1e-18f ? nacc - acc : 0.f;
-  ln.L(ro + 4 * nvm + 1) = acc + delta;
+  ln.L(ro + tl + 1) = acc + delta;
   for (int k = 0; k < nvm; k++) { if (k < nA) ln.L(dA + k) += ln.L(ro + nvm + k) * delta; if (k < nB) ln.L(dB + k) += ln.L(ro + 3 * nvm + k) * delta; }
   float res = delta * diag; return res * res;
 }
@@ -366,7 +366,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   }
   prof.stamp(PS_ROWS);
   // ---- projected Gauss-Seidel
-  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int nvm = sc.nv_max, rs = crow_stride(nvm);
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int rs = crow_stride(sc.crow_tail);
   bool live = ln.valid; int iters_done = 0;
   // Register-resident rows: for up to NBR fixed-base bodies with <= RN joints (every 6-axis arm) M^-1, the
   // velocity change, the motor targets and the accumulated impulses are loaded once and the sweeps below touch
@@ -450,7 +450,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       // per-lane pair id: shape friction is read with per-lane (vector) loads
       const float mu = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
       const bool act = has && mu > 0.f;
-      const float lim = act ? mu * ln.L(sc.tr_off + (3 * c) * rs + 4 * nvm + 1) : 0.f;
+      const float lim = act ? mu * ln.L(sc.tr_off + (3 * c) * rs + sc.crow_tail + 1) : 0.f;
 #pragma unroll
       for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
     }
@@ -508,7 +508,7 @@ template <int LANES, bool PROF>
 DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc;
   for (int k = 0; k < sc.substeps; k++) { substep(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
-  for (int b = 0; b < sc.nb; b++) { const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
+  for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }
 
@@ -529,7 +529,9 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
   V3 tp = cp + v3(act[0], act[1], act[2]); Q4 tq = cq;
   if (use_orn) tq = qmul(cq, qfrom_euler(act[3], act[4], act[5]));
   const int eel = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
-  const float lam2 = sc.HF[DG_HF_IK_LAMBDA_SQ], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
+  // without the null-space lists pybullet solves (J^T J + d I) dq = J^T e in joint space; by the push-through
+  // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d
+  const float lam2 = nullsp ? sc.HF[DG_HF_IK_LAMBDA_SQ] : sc.HF[DG_HF_IK_JOINT_DAMPING], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
   const float resid = sc.HF[DG_HF_IK_RESIDUAL];
   bool live = live_lane;
   for (int it = 0; it < sc.ik_iters; it++) {
@@ -657,7 +659,9 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   fk();
   const V3 tp = pe + v3(act[0], act[1], act[2]); Q4 tq = qe;
   if (use_orn) tq = qmul(qe, qfrom_euler(act[3], act[4], act[5]));
-  const float lam2 = sc.HF[DG_HF_IK_LAMBDA_SQ], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
+  // without the null-space lists pybullet solves (J^T J + d I) dq = J^T e in joint space; by the push-through
+  // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d
+  const float lam2 = nullsp ? sc.HF[DG_HF_IK_LAMBDA_SQ] : sc.HF[DG_HF_IK_JOINT_DAMPING], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
   const float resid = sc.HF[DG_HF_IK_RESIDUAL];
   bool live = live_lane;
   for (int it = 0; it < sc.ik_iters; it++) {

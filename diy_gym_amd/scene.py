@@ -273,8 +273,10 @@ class SceneBuilder:
             dynamic = not (flat.fixed_base and len(flat.links) == 0)
             frozen = (not dynamic) and b not in respawned
             flags = (K.BODY_FIXED if flat.fixed_base else 0) | (K.BODY_FROZEN if frozen else 0)
-            body_i.append([flags, first, len(flat.links), state_off])
-            state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
+            # frozen bodies have no per-env state at all: their pose is the load pose in the body table
+            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off])
+            if not frozen:
+                state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
             I = flat.base_inertia
             rep_q = quat_from_mat(flat.T_base_report.R)
             body_f.append([flat.base_mass, *flat.base_com, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2], *p_link,

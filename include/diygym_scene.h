@@ -99,7 +99,8 @@ enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_E
 
 /* ---- body table ------------------------------------------------------ */
 #define DG_BODY_FIXED 1  /* base does not move (use_fixed_base / massless root) */
-#define DG_BODY_FROZEN 2 /* fixed, no joints and never respawned: its shapes are stored in WORLD coordinates */
+#define DG_BODY_FROZEN 2 /* fixed, no joints and never respawned: its shapes are stored in WORLD coordinates,
+                            it has no per-env state (DG_BI_STATE_OFF = -1) and its pose is DG_BF_INIT_* */
 enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF, DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)

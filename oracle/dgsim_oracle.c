@@ -323,6 +323,7 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
   for (int e = 0; e < num_envs; e++) {
     double* st = env_state(w, e);
     for (int b = 0; b < w->sc.nb; b++) {
+      if (body_i(&w->sc, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue;
       double* bs = st + body_i(&w->sc, b)[DG_BI_STATE_OFF];
       const double* bf = body_f(&w->sc, b);
       for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] = bf[DG_BF_INIT_POS + k];
@@ -344,7 +345,7 @@ int32_t dgo_last_iterations(const dgo_world* w, int32_t env) { return w->last_it
 /* --------------------------------------------------------- kinematics */
 static void body_kinematics(const Scene* s, const double* st, int b, BodyWS* ws, const double* q_override) {
   const int32_t* bi = body_i(s, b);
-  const double* bs = st + bi[DG_BI_STATE_OFF];
+  const double* bs = (bi[DG_BI_FLAGS] & DG_BODY_FROZEN) ? body_f(s, b) + DG_BF_INIT_POS : st + bi[DG_BI_STATE_OFF]; /* pos3 quat4 either way */
   ws->n = bi[DG_BI_N_LINKS]; ws->first = bi[DG_BI_FIRST_LINK]; ws->fixed = bi[DG_BI_FLAGS] & DG_BODY_FIXED;
   ws->p0 = V(bs[0], bs[1], bs[2]);
   qt q0 = {bs[3], bs[4], bs[5], bs[6]}; ws->q0 = q0; ws->R0 = qmat(q0);
@@ -374,7 +375,7 @@ static void link_world(const BodyWS* ws, int local_link, m3* R, v3* p) {
 
 /* velocities (spatial, link coords) from state */
 static void body_velocities(const Scene* s, const double* st, int b, BodyWS* ws) {
-  const double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+  const double* bs = st + (ws->fixed ? 0 : body_i(s, b)[DG_BI_STATE_OFF]);
   if (ws->fixed) memset(&ws->v0, 0, sizeof ws->v0);
   else {
     v3 vw = V(bs[DG_BS_LINVEL], bs[DG_BS_LINVEL + 1], bs[DG_BS_LINVEL + 2]);
@@ -1079,7 +1080,7 @@ static void sim_step(dgo_world* w, int env) {
   Scene* s = &w->sc; double* st = env_state(w, env);
   for (int k = 0; k < s->substeps; k++) substep(w, env);
   /* external wrenches and joint torques last for one stepSimulation [R] */
-  for (int b = 0; b < s->nb; b++) { double* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
+  for (int b = 0; b < s->nb; b++) { if (body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue; double* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
   for (int l = 0; l < s->nl; l++) st[link_i(s, l)[DG_LI_STATE_OFF] + DG_LS_TORQUE] = 0.0;
 }
 

@@ -15,6 +15,8 @@ CONFIGS = {
     'ur_ik': os.path.join(ROOT, 'examples', 'ur_high_5', 'ur_high_5.yaml'),
     'ur_joint': os.path.join(ROOT, 'examples', 'ur_high_5', 'ur_high_5_joint.yaml'),
     'cart_tree': os.path.join(ROOT, 'tests', 'golden', 'cart_tree.yaml'),
+    'maze': os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml'),
+    'readme': os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml'),
 }
 
 
@@ -119,6 +121,34 @@ def test_cart_tree_every_feature_60_steps():
     gpu, cpu = make_pair('cart_tree', 37, residual_threshold=1e-13)
     w = rollout(gpu, cpu, 12)
     assert w['obs'] < 2e-3 and w['effort_rel'] < 2e-2 and w['term_mismatch'] == 0, w
+
+
+def test_r2d2_maze_40_steps():
+    # floating 8-DoF tree (wheels, prismatic gripper, head) on a plane among 119 frozen walls: LDS at 16 envs per
+    # wavefront, one-sided contact rows, generic (LDS) solver path
+    gpu, cpu = make_pair('maze', 19)
+    assert gpu.sim.lanes in (16, 32) and gpu.layout.state_dim < 100  # walls and plane carry no per-env state
+    w = rollout(gpu, cpu, 40, scale=10.0)  # the reference's example drives the wheels at +-10 rad/s (r2d2_maze.py:14)
+    assert w['term_mismatch'] == 0
+    a, b = gpu.sim.get_state(), cpu.sim.get_state()
+    so = gpu.layout.body_state_off[0]
+    # the wheel-on-plane contact problem runs into the 150-iteration cap, so fp32 and fp64 drift apart faster than in
+    # the converged scenes: 5 mm / 5e-3 quaternion units after 40 steps of hard driving
+    assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
+
+
+def test_from_the_readme_scene_and_gripper_camera():
+    # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
+    # runs from the global per-env workspace
+    gpu, cpu = make_pair('readme', 3)
+    assert gpu.sim.lanes == 0
+    w = rollout(gpu, cpu, 6)
+    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+    gpu._tick += 1; cpu._tick += 1
+    g = gpu.models['r2d2'].addons['arm_camera'].observe(); c = cpu.models['r2d2'].addons['arm_camera'].observe()
+    assert g['rgb'].shape == (3, 200, 200, 3) and g['depth'].shape == (3, 200, 200)
+    close = (g['depth'].cpu() - c['depth']).abs() < 5e-3
+    assert close.float().mean() > 0.99
 
 
 def test_frame_state_getter_matches_oracle():

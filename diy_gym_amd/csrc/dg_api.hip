@@ -116,7 +116,7 @@ struct dg_world {
 
 extern "C" {
 
-int32_t dg_version(void) { return (0 << 16) | 4; }
+int32_t dg_version(void) { return (0 << 16) | 5; }
 const char* dg_last_error(void) { return g_err.c_str(); }
 
 int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t n_f, int32_t num_envs, int32_t env_stride,
@@ -141,10 +141,12 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     if (!fx) any_float = true;
     if (B[DG_BI_FLAGS] & DG_BODY_FROZEN) PLB[b * PLB_STRIDE + PLB_R0] = -1; else { PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6; }
     PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * nv;
-    PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += nv;
     PLB[b * PLB_STRIDE + PLB_NV] = nv;
     nvmax = std::max(nvmax, nv); nmax = std::max(nmax, n);
   }
+  // velocity-change blocks of all bodies back to back, then nv_max slots of padding (branch-free contact sweeps)
+  for (int b = 0; b < nb; b++) { PLB[b * PLB_STRIDE + PLB_DV] = slot; slot += PLB[b * PLB_STRIDE + PLB_NV]; }
+  slot += nvmax + 8;  // chunked helpers read up to 7 slots past a vector
   for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 9; PLL[l * PLL_STRIDE + PLL_IAACC] = -1; }
   for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; }  // contiguous: pgs_rows_small strides through them
   const int maxc = I[DG_H_MAX_CONTACTS];
@@ -176,7 +178,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       const int n = BI[OI[op * DG_OI_STRIDE + DG_OI_BODY] * DG_BI_STRIDE + DG_BI_N_LINKS];
       tr = std::max(tr, 9 * n);
     }
-  slot += tr;
+  slot += tr + 8;  // + padding for the chunked vector helpers
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
   while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
@@ -207,11 +209,11 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   cip dI = (cip)w->d_blob_i; cfp dF = (cfp)w->d_blob_f;
   DevScene& sc = w->sc; memset(&sc, 0, sizeof sc);
   sc.BI = dI + I[DG_H_OFF_BODY_I]; sc.LI = dI + I[DG_H_OFF_LINK_I]; sc.FI = dI + I[DG_H_OFF_FRAME_I]; sc.SI = dI + I[DG_H_OFF_SHAPE_I];
-  sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
+  sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.GI = dI + I[DG_H_OFF_GROUP_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
   sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE;
-  sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.nops = I[DG_H_N_OPS];
+  sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
   sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
@@ -243,7 +245,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
   if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
   else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); SET_ATTR(pose_kernel<32>); }
-  else if (lanes == 16) { SET_ATTR((step_kernel<16, false>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
+  else if (lanes == 16) { SET_ATTR((step_kernel<16, false>)); SET_ATTR((step_kernel<16, true>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
 #undef SET_ATTR
   *out = w;
   return DG_OK;
@@ -322,8 +324,9 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
     const dim3 grid((w->num_envs + per - 1) / per), block(64); hipStream_t st = (hipStream_t)stream;
 #define STEP_ARGS w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag
     if (w->profile_cycles) {
-      if (w->lanes != 64) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 envs per wavefront only");
-      hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
+      if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
+      else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
+      else return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 and 16 envs per wavefront only");
     } else if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
     else if (w->lanes == 32) hipLaunchKernelGGL((step_kernel<32, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
     else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);

@@ -38,11 +38,11 @@ typedef const float DG_CONSTANT* cfp;
 
 // Everything wave-uniform the kernels need.  Passed by value (kernarg -> SGPRs / scalar loads).
 struct DevScene {
-  cip BI, LI, FI, SI, PI, OI, IL;
+  cip BI, LI, FI, SI, PI, GI, OI, IL;
   cfp BF, LF, FF, SF, PF, OF, FL, HF;
   cip PLB;  // per body: [R0_off, minv_off, dv_off, nv]
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
-  int32_t nb, nl, nfr, nsh, npairs, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
+  int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
   int32_t crow_tail;    // contact row: [JA nv_max][RA nv_max]([JB][RB] only if some pair has two moving bodies)[b][acc][diag]

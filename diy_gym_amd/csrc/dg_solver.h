@@ -115,7 +115,21 @@ DGD int collide(const Lane<LANES>& ln) {
     const int o = sc.tr_off + sh * SC_STRIDE;
     ln.L3set(o + SC_E0, e0); ln.L3set(o + SC_E1, e1); ln.L(o + SC_R) = w.prm0; ln.L(o + SC_BOUND) = w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
   }
-  for (int pi = 0; pi < sc.npairs; pi++) {
+  // broad phase: a group = all pairs between one moving body and one shape of the static world (or another
+  // moving body); skipped as a whole when the bounding spheres are apart in every lane of the wave
+  int cached_body = -1; V3 cpos = v3(0.f, 0.f, 0.f);
+  for (int g = 0; g < sc.ngroups; g++) {
+    cip gi = sc.GI + g * DG_GI_STRIDE; const int ba = gi[DG_GI_BODY_A], bb = gi[DG_GI_BODY_B], ss = gi[DG_GI_STATIC_SHAPE];
+    if (ba != cached_body) { cpos = ln.base_pos(ba); cached_body = ba; }
+    V3 other; float reach = sc.BF[ba * DG_BF_STRIDE + DG_BF_BOUND] + margin;
+    if (ss >= 0) {
+      cip si = sc.SI + ss * DG_SI_STRIDE; cfp sf = sc.SF + ss * DG_SF_STRIDE; const int st = si[DG_SI_TYPE];
+      reach += st == DG_SHAPE_SPHERE ? sf[DG_SF_PARAMS] : st == DG_SHAPE_BOX ? sqrtf(sf[DG_SF_PARAMS] * sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1] * sf[DG_SF_PARAMS + 1] + sf[DG_SF_PARAMS + 2] * sf[DG_SF_PARAMS + 2]) : sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1];
+      if (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) other = v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]);
+      else { WShape w; shape_world(ln, ss, w); other = w.p; }
+    } else { other = ln.base_pos(bb); reach += sc.BF[bb * DG_BF_STRIDE + DG_BF_BOUND]; }
+    { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
+  for (int pi = gi[DG_GI_FIRST]; pi < gi[DG_GI_FIRST] + gi[DG_GI_COUNT]; pi++) {
     const int sA = sc.PI[pi * DG_PI_STRIDE + DG_PI_A], sB = sc.PI[pi * DG_PI_STRIDE + DG_PI_B];
     const int tA = sc.SI[sA * DG_SI_STRIDE + DG_SI_TYPE], tB = sc.SI[sB * DG_SI_STRIDE + DG_SI_TYPE];
     // canonical order (uniform): lower type first, a box always second.  Normals are reported from
@@ -174,6 +188,7 @@ DGD int collide(const Lane<LANES>& ln) {
       }
     }
   }
+  }
   ln.L(sc.cont_off) = (float)cnt;
   return cnt;
 }
@@ -203,6 +218,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
   for (int d = 0; d < 3; d++) {
     V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
     int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
+    for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;  // rows are swept branch-free over nv_max entries: pad with zeros
     // first side = the dynamic one of (A, B); the oracle makes the same choice
     int b1 = a_dyn ? ba : bb, l1 = a_dyn ? la : lb; V3 d1 = a_dyn ? dir : -dir;
     diag += ln.point_row(b1, l1, p, d1, ro, ro + nvm); jv += ln.gen_vel_dot(b1, ro);
@@ -217,21 +233,50 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
   }
 }
 
+// ---- batched LDS vector helpers -------------------------------------------------------------------------
+// A single wave pays a full LDS round trip for every dependent access, so vectors of run-time length n are moved in
+// chunks of 8 independent accesses (reads past n stay inside the padded regions and are masked out).
+template <int LANES>
+DGD float lds_dot(const Lane<LANES>& ln, int a, int b, int n) {
+  float s = 0.f;
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    float x[8], y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x[j] = ln.L(a + k0 + j); y[j] = ln.L(b + k0 + j); }
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += (k0 + j < n) ? x[j] * y[j] : 0.f;
+  }
+  return s;
+}
+template <int LANES>
+DGD void lds_axpy(const Lane<LANES>& ln, int y, int x, float alpha, int n) {  // y[0..n) += alpha * x[0..n)
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    float xv[8], yv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { xv[j] = ln.L(x + k0 + j); yv[j] = ln.L(y + k0 + j); }
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (k0 + j < n) ln.L(y + k0 + j) = yv[j] + alpha * xv[j];
+  }
+}
+
 // one PGS update of contact row at ro; returns the squared velocity residual
 template <int LANES>
 DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, bool live, bool has) {
   if (!has) return 0.f;  // lanes without this contact slot hold no row data at all
-  const int nvm = ln.sc.nv_max, tl = ln.sc.crow_tail;
-  const int dA = (int)ln.L(co + CL_DVA), nA = (int)ln.L(co + CL_NVA), dB = (int)ln.L(co + CL_DVB), nB = (int)ln.L(co + CL_NVB);
-  float jv = 0.f;
-  for (int k = 0; k < nvm; k++) { if (k < nA) jv += ln.L(ro + k) * ln.L(dA + k); if (k < nB) jv += ln.L(ro + 2 * nvm + k) * ln.L(dB + k); }
-  float diag = ln.L(ro + tl + 2), acc = ln.L(ro + tl + 1);
+  // Branch-free over nv_max entries: Jacobians / responses are zero-padded, and reading a few slots past a body's
+  // velocity block only ever multiplies them by those zeros (the DV region ends with nv_max slots of padding).
+  const int nvm = ln.sc.nv_max, tl = ln.sc.crow_tail; const bool two = tl > 2 * nvm;
+  const int dA = (int)ln.L(co + CL_DVA), dB = (int)ln.L(co + CL_DVB), nB = (int)ln.L(co + CL_NVB);
+  float jv = lds_dot(ln, ro, dA, nvm);
+  if (two && nB > 0) jv += lds_dot(ln, ro + 2 * nvm, dB, nvm);
+  const float diag = ln.L(ro + tl + 2), acc = ln.L(ro + tl + 1);
   float delta = (ln.L(ro + tl) - jv) / diag;
-  float nacc = fminf(fmaxf(acc + delta, lo), hi);
+  const float nacc = fminf(fmaxf(acc + delta, lo), hi);
   delta = live && diag > 1e-18f ? nacc - acc : 0.f;
   ln.L(ro + tl + 1) = acc + delta;
-  for (int k = 0; k < nvm; k++) { if (k < nA) ln.L(dA + k) += ln.L(ro + nvm + k) * delta; if (k < nB) ln.L(dB + k) += ln.L(ro + 3 * nvm + k) * delta; }
-  float res = delta * diag; return res * res;
+  lds_axpy(ln, dA, ro + nvm, delta, nvm);
+  if (two && nB > 0) lds_axpy(ln, dB, ro + 3 * nvm, delta, nvm);
+  const float res = delta * diag; return res * res;
 }
 
 // ---- motor / joint-limit rows of one body, one Gauss-Seidel sweep ------------------------------------
@@ -251,7 +296,7 @@ DGD float pgs_rows_generic(const Lane<LANES>& ln, int b, bool live) {
       float delta = (ln.L(mo + MR_B) - ln.L(dvo + j)) / diag;
       float nacc = fminf(fmaxf(acc + delta, -maximp), maximp);
       delta = live ? nacc - acc : 0.f; ln.L(mo + MR_ACC) = acc + delta;
-      for (int k = 0; k < nv; k++) ln.L(dvo + k) += ln.L(col + k) * delta;
+      lds_axpy(ln, dvo, col, delta, nv);
       float res = delta * diag; maxres = fmaxf(maxres, res * res);
     } else {
       cfp f = ln.lf(gl); if (!(f[DG_LF_LOWER] <= f[DG_LF_UPPER])) continue;
@@ -263,7 +308,7 @@ DGD float pgs_rows_generic(const Lane<LANES>& ln, int b, bool live) {
         float delta = (ln.L(bo) - sg * ln.L(dvo + j)) / diag;
         float nacc = fmaxf(acc + delta, 0.f);
         delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
-        for (int k = 0; k < nv; k++) ln.L(dvo + k) += sg * ln.L(col + k) * delta;
+        lds_axpy(ln, dvo, col, sg * delta, nv);
         float res = delta * diag; maxres = fmaxf(maxres, res * res);
       }
     }

@@ -146,6 +146,37 @@ def hull_planes(points):
     return np.asarray(out, dtype=np.float64)
 
 
+def shape_bound(sh):
+    """Radius of a sphere around the shape frame origin (or the hull points' centroid frame) containing the shape."""
+    if sh.kind == SHAPE_SPHERE:
+        return float(sh.params[0])
+    if sh.kind == SHAPE_BOX:
+        return float(np.linalg.norm(sh.params))
+    if sh.kind == SHAPE_CAPSULE:
+        return float(sh.params[0] + sh.params[1])
+    return 0.0
+
+
+def body_bound(flat):
+    """Conservative radius around the base origin that contains every collision shape of the body whatever the
+    joint angles: joint offsets (and prismatic travel) add up along the chain."""
+    reach = []
+    for fl in flat.links:
+        r = (reach[fl.parent] if fl.parent >= 0 else 0.0) + float(np.linalg.norm(fl.origin.p))
+        if fl.joint_type == 1 and fl.lower <= fl.upper:
+            r += max(abs(fl.lower), abs(fl.upper))
+        reach.append(r)
+    out = 0.0
+    for sh in flat.shapes:
+        base = reach[sh.link] if sh.link >= 0 else 0.0
+        if sh.kind == SHAPE_POINTS:
+            ext = float(np.max(np.linalg.norm(np.asarray(sh.points), axis=1)))
+        else:
+            ext = float(np.linalg.norm(sh.T.p)) + shape_bound(sh)
+        out = max(out, base + ext)
+    return out
+
+
 class OpHandle:
     def __init__(self, index, kind, io_off, io_dim, state_off, slot):
         self.index = index
@@ -280,7 +311,7 @@ class SceneBuilder:
             I = flat.base_inertia
             rep_q = quat_from_mat(flat.T_base_report.R)
             body_f.append([flat.base_mass, *flat.base_com, I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2], *p_link,
-                           *q_link, *flat.T_base_report.p, *rep_q, *self.colors[b]])
+                           *q_link, *flat.T_base_report.p, *rep_q, *self.colors[b], body_bound(flat), 0.0, 0.0, 0.0])
             for i, fl in enumerate(flat.links):
                 parent = -1 if fl.parent < 0 else first + fl.parent
                 link_i.append([parent, fl.joint_type, b, state_off])
@@ -338,7 +369,7 @@ class SceneBuilder:
 
         # candidate collision pairs: different bodies, at least one of them able to move,
         # and a narrow-phase routine exists for the pair (no box-box)
-        pairs, max_contacts, static_pairs = [], 0, 0
+        cand, max_contacts, static_pairs = [], 0, 0
         for a in range(len(shape_i)):
             for c in range(a + 1, len(shape_i)):
                 if shape_i[a][1] == shape_i[c][1] or not (shape_dyn[a] or shape_dyn[c]):
@@ -348,12 +379,26 @@ class SceneBuilder:
                 ta, tc = shape_i[a][0], shape_i[c][0]
                 if ta == SHAPE_BOX and tc == SHAPE_BOX:
                     continue
-                pairs.append([a, c])
                 kinds = {ta, tc}
                 per_pair = 4 if kinds == {SHAPE_POINTS, SHAPE_BOX} else 2 if kinds == {SHAPE_CAPSULE, SHAPE_BOX} else 1
                 max_contacts += per_pair
                 if not (shape_dyn[a] and shape_dyn[c]):
                     static_pairs += per_pair
+                # broad-phase key: (moving body, static shape) or (moving body, moving body)
+                if shape_dyn[a] and shape_dyn[c]:
+                    key = (1, shape_i[a][1], shape_i[c][1], -1)
+                else:
+                    dyn, sta = (a, c) if shape_dyn[a] else (c, a)
+                    key = (0, shape_i[dyn][1], -1, sta)
+                cand.append((key, a, c))
+        cand.sort(key=lambda t: (t[0], t[1], t[2]))
+        pairs, groups = [], []
+        for key, a, c in cand:
+            if not groups or groups[-1][5] != key:
+                groups.append([len(pairs), 0, key[1], key[2], key[3], key])
+            groups[-1][1] += 1
+            pairs.append([a, c])
+        groups = [g[:5] for g in groups]
         # Contact budget per env (rows live in LDS).  Default: every contact a moving shape can have
         # with the static world, plus a small pool for moving-vs-moving contacts; `max_contacts`
         # in the env config overrides it.  Contacts beyond the budget are dropped in pair order --
@@ -373,6 +418,7 @@ class SceneBuilder:
             ('OFF_FRAME_I', arr(frame_i, K.FI_STRIDE, np.int32)),
             ('OFF_SHAPE_I', arr(shape_i, K.SI_STRIDE, np.int32)),
             ('OFF_PAIR_I', arr(pairs, K.PI_STRIDE, np.int32)),
+            ('OFF_GROUP_I', arr(groups, K.GI_STRIDE, np.int32)),
             ('OFF_CAMERA_I', arr([[c[0], c[1], c[2], c[3], c[4]] for c in self.cameras], K.CI_STRIDE, np.int32)),
             ('OFF_OP_I', arr([o[0] for o in self.ops], K.OI_STRIDE, np.int32)),
             ('OFF_ILIST', np.asarray(self.ilist, dtype=np.int32).reshape(-1, 1)),
@@ -399,6 +445,7 @@ class SceneBuilder:
         H[K.H_N_PLANES] = len(planes)
         H[K.H_N_CAMERAS] = len(self.cameras)
         H[K.H_N_PAIRS] = len(pairs)
+        H[K.H_N_GROUPS] = len(groups)
         H[K.H_N_OPS] = len(self.ops)
         H[K.H_N_ILIST] = len(self.ilist)
         H[K.H_N_FLIST] = len(self.flist)

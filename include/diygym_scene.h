@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 4
+#define DG_VERSION 5
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -32,6 +32,7 @@ enum {
   DG_H_N_PLANES,     /* convex hull face planes (ray casting only)         */
   DG_H_N_CAMERAS,
   DG_H_N_PAIRS,      /* shape pairs that may collide                       */
+  DG_H_N_GROUPS,     /* runs of consecutive pairs between the same two bodies (broad phase) */
   DG_H_N_OPS,        /* addon program length                               */
   DG_H_N_ILIST,      /* length of the op int-list pool                     */
   DG_H_N_FLIST,      /* length of the op float-list pool                   */
@@ -56,6 +57,7 @@ enum {
   DG_H_OFF_FRAME_I,
   DG_H_OFF_SHAPE_I,
   DG_H_OFF_PAIR_I,
+  DG_H_OFF_GROUP_I,
   DG_H_OFF_OP_I,
   DG_H_OFF_ILIST,
   DG_H_OFF_BODY_F,
@@ -114,7 +116,8 @@ enum {
                                           base link frame: what pybullet's
                                           getBasePositionAndOrientation reports */
   DG_BF_COLOR = 24,                     /* rgba, visual only                  */
-  DG_BF_STRIDE = 28
+  DG_BF_BOUND = 28,                     /* radius around the base origin that contains every collision shape in any joint configuration */
+  DG_BF_STRIDE = 32
 };
 
 /* ---- link table (one row per DoF, bodies contiguous, parents first) -- */
@@ -155,6 +158,9 @@ enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, 
 enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3] | capsule r, half_len (axis = local z) */,
        DG_SF_FRICTION = 15, DG_SF_STRIDE = 16 };
 enum { DG_PI_A = 0, DG_PI_B, DG_PI_STRIDE };
+/* pair groups: the pair list is ordered so that all pairs between one moving body and one shape of the static world
+ * (or between two moving bodies) are consecutive; a group is culled as a whole with bounding spheres */
+enum { DG_GI_FIRST = 0, DG_GI_COUNT, DG_GI_BODY_A /* moving */, DG_GI_BODY_B /* moving, or -1 */, DG_GI_STATIC_SHAPE /* or -1 */, DG_GI_STRIDE };
 
 /* ---- cameras (reference diy_gym/addons/sensors/camera.py:26-98) ------- */
 /* A camera is rendered by its own launch (dg_world_render), not by the step kernel. */

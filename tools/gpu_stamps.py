@@ -15,6 +15,8 @@ ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0
 for i in range(10): env.sim.step(env._all_slots, ring[i % 8])
 cyc = env.sim.enable_stamps()
 tot = torch.zeros(len(env.sim.SECTIONS), dtype=torch.float64)
+scale = float(os.environ.get('ACT_SCALE', '1'))
+ring = [r * scale for r in ring]
 n = 16
 for i in range(n):
     env.sim.step(env._all_slots, ring[i % 8]); torch.cuda.synchronize()
@@ -29,6 +31,6 @@ d = env.sim.enable_diagnostics()
 for i in range(4): env.sim.step(env._all_slots, ring[i % 8])
 torch.cuda.synchronize()
 it = d[:, 1].float()
-wave_max = it.reshape(-1, 64).max(1).values
+wave_max = it.reshape(-1, env.sim.lanes).max(1).values
 print('PGS iterations (last substep): mean %.1f  p50 %.0f  p99 %.0f  max %.0f | per-wave max: mean %.1f max %.0f | contacts max %d' % (
     it.mean(), it.median(), it.quantile(0.99), it.max(), wave_max.mean(), wave_max.max(), int(d[:, 0].max())))

@@ -156,7 +156,8 @@ class HipBackend:
         self._check(self.lib.dg_world_set_diag_buffer(self.handle, _ptr(self.diag)))
         return self.diag
 
-    SECTIONS = ['update_ops', 'kinematics', 'narrow_phase', 'aba', 'minv', 'rows', 'pgs', 'integrate', 'outputs']
+    SECTIONS = ['update_ops', 'kinematics', 'narrow_phase', 'aba', 'minv', 'rows', 'pgs_other', 'integrate', 'outputs', 'pgs_motor', 'pgs_limit',
+                'pgs_contact']
 
     def enable_stamps(self, on=True):
         """Diagnostic: per-wavefront shader cycles per section of the step (see diygym_hip.h)."""

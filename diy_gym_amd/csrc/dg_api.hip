@@ -170,7 +170,9 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   { const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
     auto moving = [&](int sh) { const int32_t* B = BI + SIh[sh * DG_SI_STRIDE + DG_SI_BODY] * DG_BI_STRIDE; return !((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0); };
     for (int p = 0; p < I[DG_H_N_PAIRS]; p++) if (moving(PIh[p * DG_PI_STRIDE + DG_PI_A]) && moving(PIh[p * DG_PI_STRIDE + DG_PI_B])) two_sided = true; }
-  const int crow_tail = (two_sided ? 4 : 2) * nvmax;
+  int nt = 0; for (int b = 0; b < nb; b++) nt += PLB[b * PLB_STRIDE + PLB_NV];
+  const bool dense = nt <= 32;  // contact rows indexed by global DoF, swept with the velocity change in registers
+  const int crow_tail = dense ? 2 * nt : (two_sided ? 4 : 2) * nvmax;
   tr = std::max(tr, 3 * maxc * (crow_tail + 3));
   if (I[DG_H_N_PAIRS] > 0) tr = std::max(tr, (int)SC_STRIDE * I[DG_H_N_SHAPES]);  // narrow-phase shape cache
   for (int op = 0; op < I[DG_H_N_OPS]; op++)
@@ -217,7 +219,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
   sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
-  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail;
+  sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail; sc.nt = nt; sc.dense = dense ? 1 : 0; sc.dv_base = nb > 0 ? PLB[PLB_DV] : 0;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   // bodies whose solver rows are held in registers by the step kernel
   sc.reg_body[0] = sc.reg_body[1] = -1;

@@ -9,7 +9,7 @@ namespace dg {
 // ---------------------------------------------------------------- in-kernel stamps
 // Diagnostic builds only (template PROF = true): wave-uniform cycle counters per section of the step.
 // The production instantiation (PROF = false) contains no stamp at all.
-enum { PS_UPDATE = 0, PS_KIN, PS_COLLIDE, PS_ABA, PS_MINV, PS_ROWS, PS_PGS, PS_INTEGRATE, PS_OUTPUT, PS_COUNT };
+enum { PS_UPDATE = 0, PS_KIN, PS_COLLIDE, PS_ABA, PS_MINV, PS_ROWS, PS_PGS, PS_INTEGRATE, PS_OUTPUT, PS_PGS_MOTOR, PS_PGS_LIMIT, PS_PGS_CONTACT, PS_COUNT };
 template <bool PROF> struct Prof;
 template <> struct Prof<false> { DGD void start() {} DGD void stamp(int) {} };
 template <> struct Prof<true> {
@@ -215,16 +215,22 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
   V3 p = ln.L3(co + CL_P), n = ln.L3(co + CL_N); float dist = ln.L(co + CL_DIST);
   V3 t1, t2; tangent_basis(n, t1, t2);
   const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
+  ln.L(co + CL_MU) = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
   for (int d = 0; d < 3; d++) {
     V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
     int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
-    for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;  // rows are swept branch-free over nv_max entries: pad with zeros
+    for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;  // rows are swept branch-free: pad with zeros
     // first side = the dynamic one of (A, B); the oracle makes the same choice
     int b1 = a_dyn ? ba : bb, l1 = a_dyn ? la : lb; V3 d1 = a_dyn ? dir : -dir;
-    diag += ln.point_row(b1, l1, p, d1, ro, ro + nvm); jv += ln.gen_vel_dot(b1, ro);
+    // dense rows (total DoF <= 32): Jacobian and response are indexed by GLOBAL DoF, [J nt][R nt]; otherwise
+    // per-body blocks [JA nv_max][RA nv_max]([JB][RB])
+    const int g1 = sc.dense ? ln.plb(b1)[PLB_DV] - sc.dv_base : 0, g2 = sc.dense ? ln.plb(bb)[PLB_DV] - sc.dv_base : 0;
+    const int j1 = ro + g1, r1 = ro + (sc.dense ? sc.nt : nvm) + g1;
+    diag += ln.point_row(b1, l1, p, d1, j1, r1); jv += ln.gen_vel_dot(b1, j1);
     ln.L(co + CL_DVA) = (float)ln.plb(b1)[PLB_DV]; ln.L(co + CL_NVA) = (float)ln.plb(b1)[PLB_NV];
     if (a_dyn && b_dyn) {
-      diag += ln.point_row(bb, lb, p, -dir, ro + 2 * nvm, ro + 3 * nvm); jv += ln.gen_vel_dot(bb, ro + 2 * nvm);
+      const int j2 = sc.dense ? ro + g2 : ro + 2 * nvm, r2 = sc.dense ? ro + sc.nt + g2 : ro + 3 * nvm;
+      diag += ln.point_row(bb, lb, p, -dir, j2, r2); jv += ln.gen_vel_dot(bb, j2);
       ln.L(co + CL_DVB) = (float)ln.plb(bb)[PLB_DV]; ln.L(co + CL_NVB) = (float)ln.plb(bb)[PLB_NV];
     } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
@@ -277,6 +283,43 @@ DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, 
   lds_axpy(ln, dA, ro + nvm, delta, nvm);
   if (two && nB > 0) lds_axpy(ln, dB, ro + 3 * nvm, delta, nvm);
   const float res = delta * diag; return res * res;
+}
+
+// Dense-row contact sweeps (total DoF of the scene <= 32): the whole velocity change lives in registers for the
+// normal and friction sweeps of one iteration; a row costs ONE batched LDS round trip (its J, R, b, acc, diag --
+// none of which depends on the running solution) instead of five dependent ones.
+template <int LANES>
+DGD float contact_sweeps_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, bool live) {
+  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; float maxres = 0.f;
+  float dv[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) dv[k] = k < nt ? ln.L(sc.dv_base + k) : 0.f;
+  auto row = [&](int ro, float lo, float hi) {
+    float J[32], R[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) { J[k] = k < nt ? ln.L(ro + k) : 0.f; R[k] = k < nt ? ln.L(ro + nt + k) : 0.f; }
+    const float b = ln.L(ro + 2 * nt), acc = ln.L(ro + 2 * nt + 1), diag = ln.L(ro + 2 * nt + 2);
+    float jv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) jv += J[k] * dv[k];
+    float delta = (b - jv) / diag;
+    const float nacc = fminf(fmaxf(acc + delta, lo), hi);
+    delta = live && diag > 1e-18f ? nacc - acc : 0.f;
+    ln.L(ro + 2 * nt + 1) = acc + delta;
+#pragma unroll
+    for (int k = 0; k < 32; k++) dv[k] += R[k] * delta;
+    const float res = delta * diag; maxres = fmaxf(maxres, res * res);
+  };
+  for (int c = 0; c < wave_max_cont; c++) if (c < ncont) row(sc.tr_off + (3 * c) * rs, 0.f, 3.0e38f);
+  for (int c = 0; c < wave_max_cont; c++) {
+    if (c < ncont) {
+      const float mu = ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU);
+      if (mu > 0.f) { const float lim = mu * ln.L(sc.tr_off + (3 * c) * rs + 2 * nt + 1); row(sc.tr_off + (3 * c + 1) * rs, -lim, lim); row(sc.tr_off + (3 * c + 2) * rs, -lim, lim); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 32; k++) if (k < nt) ln.L(sc.dv_base + k) = dv[k];
+  return maxres;
 }
 
 // ---- motor / joint-limit rows of one body, one Gauss-Seidel sweep ------------------------------------
@@ -472,6 +515,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       if (ln.fixed(b) && n <= 8) maxres = fmaxf(maxres, pgs_rows_small<LANES, 8, false>(ln, b, live));
       else maxres = fmaxf(maxres, pgs_rows_generic<LANES, false>(ln, b, live));
     }
+    prof.stamp(PS_PGS_MOTOR);
     if (limit_mask) {
       for (int b = 0; b < sc.nb; b++) {
         const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || !((limit_mask >> (b & 63)) & 1ull)) continue;
@@ -483,7 +527,10 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
         if (b == sc.reg_body[1]) lds_to_regs(1);
       }
     }
+    prof.stamp(PS_PGS_LIMIT);
     if (wave_max_cont > 0) { regs_to_lds(0); regs_to_lds(1); }
+    if (wave_max_cont > 0 && sc.dense) maxres = fmaxf(maxres, contact_sweeps_dense(ln, ncont, wave_max_cont, live));
+    else {
     for (int c = 0; c < wave_max_cont; c++) {  // contact normals
       const bool has = c < ncont;
       float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, sc.cont_off + 1 + c * CL_STRIDE, 0.f, 3.0e38f, live, has);
@@ -491,15 +538,15 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     }
     for (int c = 0; c < wave_max_cont; c++) {  // friction
       const bool has = c < ncont;
-      const int pair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : 0;
-      // per-lane pair id: shape friction is read with per-lane (vector) loads
-      const float mu = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
+      const float mu = has ? ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) : 0.f;
       const bool act = has && mu > 0.f;
       const float lim = act ? mu * ln.L(sc.tr_off + (3 * c) * rs + sc.crow_tail + 1) : 0.f;
 #pragma unroll
       for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
     }
+    }
     if (wave_max_cont > 0) { lds_to_regs(0); lds_to_regs(1); }
+    prof.stamp(PS_PGS_CONTACT);
     if (live) iters_done = it + 1;
     live = live && !(maxres <= thr && maxabs <= thr_abs);
     if (!__any(live)) break;

@@ -142,6 +142,9 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     if (B[DG_BI_FLAGS] & DG_BODY_FROZEN) PLB[b * PLB_STRIDE + PLB_R0] = -1; else { PLB[b * PLB_STRIDE + PLB_R0] = slot; slot += 6; }
     PLB[b * PLB_STRIDE + PLB_MINV] = slot; slot += nv * nv;
     PLB[b * PLB_STRIDE + PLB_NV] = nv;
+    { bool chain = fx && n >= 1 && n <= 6;
+      for (int i = 0; i < n && chain; i++) chain = LI[(B[DG_BI_FIRST_LINK] + i) * DG_LI_STRIDE + DG_LI_PARENT] == (i == 0 ? -1 : B[DG_BI_FIRST_LINK] + i - 1);
+      PLB[b * PLB_STRIDE + PLB_CHAIN] = chain ? 1 : 0; }
     nvmax = std::max(nvmax, nv); nmax = std::max(nmax, n);
   }
   // velocity-change blocks of all bodies back to back, then nv_max slots of padding (branch-free contact sweeps)

@@ -54,7 +54,7 @@ struct DevScene {
 };
 struct MotorTable { float v[DG_MAX_LINKS * 3]; };  // kp, kd, max_force (<0 raw impulse)
 
-enum { PLB_R0 = 0, PLB_MINV, PLB_DV, PLB_NV, PLB_STRIDE };
+enum { PLB_R0 = 0, PLB_MINV, PLB_DV, PLB_NV, PLB_CHAIN /* fixed-base serial chain of <= 6 joints: register-resident dynamics */, PLB_STRIDE };
 enum { PLL_POSE = 0, PLL_MROW, PLL_IAACC /* LDS accumulator for children that are not link+1, or -1 */, PLL_STRIDE };
 // transient ABA workspace per link.  Articulated inertias are NOT stored per link: along a chain
 // (parent == link - 1) the child's contribution is carried in registers; only links with a child that
@@ -385,6 +385,100 @@ struct Lane {
         float qdd = (L(o + AW_UU) - dot(L6(o + AW_U), a1)) / L(o + AW_D);
         L6set(o + AW_V, a1 + subspace(gl) * qdd);
         L(mo + col * nv + nb6 + i) = qdd;
+      }
+    }
+    prof.stamp(4 /* PS_MINV */);
+  }
+
+  // Register-resident forward dynamics + M^-1 for a fixed-base serial chain of at most N joints (every 6-axis
+  // arm): link transforms, velocities, bias forces, U = I^A S and the articulated inertia being propagated all
+  // stay in VGPRs; the only LDS traffic is the finished M^-1.  Same recursion as dynamics().
+  template <int N, class PROF_T>
+  DGD void dynamics_chain(int b, PROF_T& prof) const {
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], mo = plb(b)[PLB_MINV]; const float h = sc.h;
+    const M3 R0 = LR(plb(b)[PLB_R0]); const V3 gb = tmul(R0, v3(sc.gx, sc.gy, sc.gz));
+    const S6 zero6 = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    M3 E[N]; V3 r[N]; S6 v[N], pA[N], U[N], Sx[N]; float dinv[N], u[N], qd[N];
+    S6 vp = zero6;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      E[i] = R0; r[i] = v3(0.f, 0.f, 0.f); v[i] = zero6; pA[i] = zero6; U[i] = zero6; Sx[i] = zero6; dinv[i] = 0.f; u[i] = 0.f; qd[i] = 0.f;
+      if (i < n) {
+        const int gl = first + i, lo = li(gl)[DG_LI_STATE_OFF]; cfp f = lf(gl);
+        const float q = S(lo + DG_LS_Q); qd[i] = S(lo + DG_LS_QD);
+        M3 Rpc; joint_xform(gl, q, Rpc, r[i]); E[i] = transpose(Rpc); Sx[i] = subspace(gl);
+        v[i] = xmotion(E[i], r[i], vp) + Sx[i] * qd[i]; vp = v[i];
+        const V3 c = v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]); const Sym3 Ic = sym6(f + DG_LF_INERTIA);
+        const AI I = rigid_inertia(f[DG_LF_MASS], c, Ic);
+        pA[i] = crf(v[i], mul(I, v[i])) - damping_force(f[DG_LF_MASS], c, Ic, v[i]);
+      }
+    }
+    AI carry; bool have = false;
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+      if (i < n) {
+        const int gl = first + i, lo = li(gl)[DG_LI_STATE_OFF]; cfp f = lf(gl);
+        const float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd[i];
+        AI IA = rigid_inertia(f[DG_LF_MASS], v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]), sym6(f + DG_LF_INERTIA));
+        if (have) {
+          IA.I.xx += carry.I.xx; IA.I.xy += carry.I.xy; IA.I.xz += carry.I.xz; IA.I.yy += carry.I.yy; IA.I.yz += carry.I.yz; IA.I.zz += carry.I.zz;
+          IA.M.xx += carry.M.xx; IA.M.xy += carry.M.xy; IA.M.xz += carry.M.xz; IA.M.yy += carry.M.yy; IA.M.yz += carry.M.yz; IA.M.zz += carry.M.zz;
+#pragma unroll
+          for (int k = 0; k < 9; k++) IA.H.m[k] += carry.H.m[k];
+        }
+        U[i] = mul(IA, Sx[i]); const float d = dot(Sx[i], U[i]); dinv[i] = 1.0f / d; u[i] = tau - dot(Sx[i], pA[i]);
+        if (i > 0) {
+          const float di = dinv[i]; const S6 Ui = U[i];
+          AI Ia = IA;
+          Ia.I.xx -= Ui.a.x * Ui.a.x * di; Ia.I.xy -= Ui.a.x * Ui.a.y * di; Ia.I.xz -= Ui.a.x * Ui.a.z * di;
+          Ia.I.yy -= Ui.a.y * Ui.a.y * di; Ia.I.yz -= Ui.a.y * Ui.a.z * di; Ia.I.zz -= Ui.a.z * Ui.a.z * di;
+          Ia.M.xx -= Ui.l.x * Ui.l.x * di; Ia.M.xy -= Ui.l.x * Ui.l.y * di; Ia.M.xz -= Ui.l.x * Ui.l.z * di;
+          Ia.M.yy -= Ui.l.y * Ui.l.y * di; Ia.M.yz -= Ui.l.y * Ui.l.z * di; Ia.M.zz -= Ui.l.z * Ui.l.z * di;
+          const float ua[3] = {Ui.a.x, Ui.a.y, Ui.a.z}, ul[3] = {Ui.l.x, Ui.l.y, Ui.l.z};
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) Ia.H.m[3 * a + c2] -= ua[a] * ul[c2] * di;
+          const S6 c = crm(v[i], Sx[i] * qd[i]);
+          const S6 pa = pA[i] + mul(Ia, c) + Ui * (u[i] * di);
+          carry = to_parent(Ia, E[i], r[i]); have = true;
+          pA[i - 1] = pA[i - 1] + xforce_to_parent(E[i], r[i], pa);
+        }
+      }
+    }
+    S6 ap; ap.a = v3(0.f, 0.f, 0.f); ap.l = -gb;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (i < n) {
+        const S6 a1 = xmotion(E[i], r[i], ap) + crm(v[i], Sx[i] * qd[i]);
+        const float qdd = (u[i] - dot(U[i], a1)) * dinv[i];
+        ap = a1 + Sx[i] * qdd;
+        Sset(li(first + i)[DG_LI_STATE_OFF] + DG_LS_QD, qd[i] + h * qdd);
+      }
+    }
+    prof.stamp(3 /* PS_ABA */);
+    // M^-1: response to a unit impulse on joint `col`
+#pragma unroll
+    for (int col = 0; col < N; col++) {
+      if (col < n) {
+        S6 p[N]; float uu[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) { p[i] = zero6; uu[i] = 0.f; }
+#pragma unroll
+        for (int i = col; i >= 0; i--) {
+          uu[i] = (i == col ? 1.0f : 0.0f) - dot(Sx[i], p[i]);
+          if (i > 0) p[i - 1] = p[i - 1] + xforce_to_parent(E[i], r[i], p[i] + U[i] * (uu[i] * dinv[i]));
+        }
+        S6 a = zero6;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+          if (i < n) {
+            const S6 a1 = xmotion(E[i], r[i], a);
+            const float qdd = (uu[i] - dot(U[i], a1)) * dinv[i];
+            a = a1 + Sx[i] * qdd;
+            L(mo + col * n + i) = qdd;
+          }
+        }
       }
     }
     prof.stamp(4 /* PS_MINV */);

@@ -419,7 +419,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   prof.stamp(PS_COLLIDE);
   for (int b = 0; b < sc.nb; b++) {
     if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
-    ln.dynamics(b, prof);
+    if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
     for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }

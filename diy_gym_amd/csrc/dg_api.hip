@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,44 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
   prof.stamp(PS_UPDATE);
   sim_step(ln, diag, prof);
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+  prof.stamp(PS_OUTPUT);
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
+}
+
+// Two wavefronts per workgroup, same 64 envs, same LDS workspace: wave 1 (the helper) runs the inverse kinematics
+// and the register-resident dynamics of sc.helper_body while wave 0 does everything else.  Every global / LDS
+// hand-off between the two is separated by a __syncthreads (workgroup-scope release / acquire).
+template <bool PROF>
+__global__ __launch_bounds__(128) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
+                                                        float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
+                                                        unsigned long long* cycles) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
+  if (wave == 1) {  // ---------------- helper
+    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    __syncthreads();  // B0: wave 0 has put every pose into LDS
+    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
+    __syncthreads();  // B0'
+    for (int k = 0; k < sc.substeps; k++) helper_substep(ln);
+    return;
+  }
+  Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+  Prof<PROF> prof; prof.start();
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  __syncthreads();  // B0
+  prof.stamp(PS_KIN);
+  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body);
+  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+  __syncthreads();  // B0': the helper's motor targets are in the state
+  prof.stamp(PS_UPDATE);
+  sim_step<64, PROF, true>(ln, diag, prof);
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
@@ -110,6 +149,7 @@ struct dg_world {
   void* d_blob_i = nullptr; void* d_blob_f = nullptr; void* d_plan = nullptr; float* d_init = nullptr;
   int32_t* diag = nullptr;
   unsigned long long* profile_cycles = nullptr;
+  bool par = false;  // step runs as two wavefronts per workgroup (helper wave)
   float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
 };
@@ -230,6 +270,22 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     const int32_t* B = BI + b * DG_BI_STRIDE;
     if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) sc.reg_body[k++] = b;
   }
+  // helper wave: the LAST fixed-base chain body (so that wave 0 keeps the first arm), provided the scene has other
+  // work to overlap with and every inverse-kinematics op on that body has the register-resident form
+  sc.helper_body = -1;
+  if (lanes == 64 && !getenv("DG_NO_HELPER_WAVE")) {
+    int n_dyn = 0; for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if (!((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0)) n_dyn++; }
+    for (int b = nb - 1; b >= 0 && n_dyn >= 2; b--) {
+      if (!PLB[b * PLB_STRIDE + PLB_CHAIN]) continue;
+      bool ok = true;
+      for (int op = 0; op < I[DG_H_N_OPS]; op++) {
+        const int32_t* oi = Idev.data() + I[DG_H_OFF_OP_I] + op * DG_OI_STRIDE;
+        if (oi[DG_OI_BODY] == b && oi[DG_OI_CODE] == DG_OP_IK_CONTROL && !(oi[DG_OI_FLAGS] & DG_IK_DEV_CHAIN)) ok = false;
+      }
+      if (ok) { sc.helper_body = b; break; }
+    }
+  }
+  w->par = sc.helper_body >= 0;
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);
@@ -248,7 +304,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   if (w->ncam > 0) HIP_TRY(hipMalloc((void**)&w->d_render_table, sizeof(float) * (size_t)num_envs * (size_t)(sc.nsh * RS_STRIDE + w->ncam * RC_STRIDE)));
   // allow > 64 KiB of dynamic LDS
 #define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
-  if (lanes == 64) { SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
+  if (lanes == 64) { SET_ATTR(step_kernel_par<false>); SET_ATTR(step_kernel_par<true>); SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
   else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); SET_ATTR(pose_kernel<32>); }
   else if (lanes == 16) { SET_ATTR((step_kernel<16, false>)); SET_ATTR((step_kernel<16, true>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
 #undef SET_ATTR
@@ -328,7 +384,10 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
     const int per = w->lanes > 0 ? w->lanes : 64;
     const dim3 grid((w->num_envs + per - 1) / per), block(64); hipStream_t st = (hipStream_t)stream;
 #define STEP_ARGS w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag
-    if (w->profile_cycles) {
+    if (w->par) {
+      if (w->profile_cycles) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(128), w->lds_bytes, st, STEP_ARGS, w->profile_cycles);
+      else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(128), w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr);
+    } else if (w->profile_cycles) {
       if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
       else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
       else return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 and 16 envs per wavefront only");

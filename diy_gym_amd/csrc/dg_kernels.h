@@ -47,6 +47,7 @@ struct DevScene {
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
   int32_t nt, dv_base, dense;  // total DoF over moving bodies; LDS offset of the first velocity block; dense rows (nt <= 32)
   int32_t crow_tail;    // contact row: [JA nv_max][RA nv_max]([JB][RB] only if some pair has two moving bodies)[b][acc][diag]
+  int32_t helper_body;  // fixed-base chain body whose IK and dynamics a second wavefront of the workgroup runs (-1: none)
   int32_t reg_body[2];  // up to two fixed-base bodies with <= 6 joints whose solver rows live in registers (-1: none)
   int32_t num_envs, stride;
   uint64_t seed; int64_t env_base;

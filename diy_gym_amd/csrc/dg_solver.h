@@ -410,19 +410,24 @@ DGD float pgs_rows_small(const Lane<LANES>& ln, int b, bool live) {
 }
 
 // ---------------------------------------------------------------- substep
-template <int LANES, bool PROF>
+// PAR: this wave is the MAIN wave of a two-wave workgroup; the helper wave (helper_substep below) owns body
+// sc.helper_body -- its kinematics and its register-resident dynamics run concurrently with everything here up to
+// the second barrier.  Both waves execute exactly three __syncthreads per substep.
+template <int LANES, bool PROF, bool PAR = false>
 DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
-  const DevScene& sc = ln.sc; const float h = sc.h;
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  const DevScene& sc = ln.sc; const float h = sc.h; const int hb = PAR ? sc.helper_body : -1;
+  for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
+  if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
   const int ncont = collide(ln);
   prof.stamp(PS_COLLIDE);
   for (int b = 0; b < sc.nb; b++) {
-    if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
+    if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
     if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
     for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
+  if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
   uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
@@ -594,12 +599,25 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       ln.Sset(lo + DG_LS_QD, qd); ln.Sset(lo + DG_LS_Q, ln.S(lo + DG_LS_Q) + h * qd);
     }
   }
+  if (PAR) __syncthreads();  // B3: positions integrated; the helper may start the next substep
 }
 
-template <int LANES, bool PROF>
+// the helper wave's side of one substep
+template <int LANES>
+DGD void helper_substep(const Lane<LANES>& ln) {
+  const DevScene& sc = ln.sc; const int hb = sc.helper_body; Prof<false> none;
+  ln.kinematics(hb);
+  __syncthreads();  // B1
+  ln.template dynamics_chain<6>(hb, none);
+  { const int dvo = ln.plb(hb)[PLB_DV], nv = ln.plb(hb)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f; }
+  __syncthreads();  // B2
+  __syncthreads();  // B3
+}
+
+template <int LANES, bool PROF, bool PAR = false>
 DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc;
-  for (int k = 0; k < sc.substeps; k++) { substep(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
+  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR>(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
   for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }
@@ -824,11 +842,12 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
 
 // ------------------------------------------------------------ addon program
 template <int LANES>
-DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask) {
+DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask, int only_body = -1, int skip_body = -1) {
   const DevScene& sc = ln.sc;
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
     if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
+    if ((only_body >= 0 && oi[DG_OI_BODY] != only_body) || oi[DG_OI_BODY] == skip_body) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
     const float* a = act_row + oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST]; const int n = oi[DG_OI_N];
     if (code == DG_OP_JOINT_CONTROL) {

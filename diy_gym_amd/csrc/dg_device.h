@@ -208,6 +208,8 @@ DGD void chol6_solve(const float* L, const float* b, float* x) {
     x[i] = s * L[i * (i + 1) / 2 + i];
   }
 }
+// division through v_rcp_f32 (1 ulp) where IEEE rounding of the quotient does not matter (closest-point parameters...)
+DGD float fdiv(float a, float b) { return a * __frcp_rn(b); }
 // pins a wave-uniform value in a VGPR so that a long loop does not re-fetch it through the scalar cache
 DGD float pin(float x) { float y; asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 

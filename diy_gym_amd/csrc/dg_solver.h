@@ -58,7 +58,7 @@ DGD Hit sphere_box(V3 c, float r, const WShape& bx, float margin) {
 }
 DGD Hit sphere_sphere(V3 ca, float ra, V3 cb, float rb, float margin) {
   Hit h; V3 d = ca - cb; float len = norm(d);
-  h.hit = (len - ra - rb) < margin; h.n = len > 1e-12f ? d * (1.0f / len) : v3(0, 0, 1);
+  h.hit = (len - ra - rb) < margin; h.n = len > 1e-12f ? d * __frcp_rn(len) : v3(0, 0, 1);
   h.pa = ca - h.n * ra; h.pb = cb + h.n * rb; h.dist = len - ra - rb;
   return h;
 }
@@ -67,20 +67,20 @@ DGD void seg_ends(const WShape& c, V3& e0, V3& e1) {
 }
 DGD float clamp01(float t) { return fminf(fmaxf(t, 0.f), 1.f); }
 DGD V3 closest_on_seg(V3 a, V3 b, V3 p) {
-  V3 ab = b - a; float den = dot(ab, ab); float t = den > 0.f ? clamp01(dot(p - a, ab) / den) : 0.f; return a + ab * t;
+  V3 ab = b - a; float den = dot(ab, ab); float t = den > 0.f ? clamp01(fdiv(dot(p - a, ab), den)) : 0.f; return a + ab * t;
 }
 DGD void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
   V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2; float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), sN, tN; const float eps = 1e-12f;
   if (a <= eps && e <= eps) { c1 = p1; c2 = p2; return; }
-  if (a <= eps) { sN = 0.f; tN = clamp01(f / e); }
+  if (a <= eps) { sN = 0.f; tN = clamp01(fdiv(f, e)); }
   else {
     float c = dot(d1, r);
-    if (e <= eps) { tN = 0.f; sN = clamp01(-c / a); }
+    if (e <= eps) { tN = 0.f; sN = clamp01(fdiv(-c, a)); }
     else {
       float b = dot(d1, d2), den = a * e - b * b;
-      sN = den > eps ? clamp01((b * f - c * e) / den) : 0.f;
-      tN = (b * sN + f) / e;
-      if (tN < 0.f) { tN = 0.f; sN = clamp01(-c / a); } else if (tN > 1.f) { tN = 1.f; sN = clamp01((b - c) / a); }
+      sN = den > eps ? clamp01(fdiv(b * f - c * e, den)) : 0.f;
+      tN = fdiv(b * sN + f, e);
+      if (tN < 0.f) { tN = 0.f; sN = clamp01(fdiv(-c, a)); } else if (tN > 1.f) { tN = 1.f; sN = clamp01(fdiv(b - c, a)); }
     }
   }
   c1 = p1 + d1 * sN; c2 = p2 + d2 * tN;

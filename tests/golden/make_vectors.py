@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/vectors.npz: seeded action sequences and the resulting observations / rewards /
+terminals / states of every scene, computed by the fp64 CPU oracle.
+
+Why the oracle and not the reference: the reference's arithmetic lives in the pybullet wheel, which cannot be
+installed here, and the reference ships no numeric fixtures.  These vectors therefore pin (a) the
+oracle against accidental change and (b) the HIP path against a committed answer that does not depend on the
+oracle being rebuilt on the GPU box.  Re-run after any intended change of the algorithm:  python tests/golden/make_vectors.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+SCENES = {  # name: (config, envs, steps, action scale)
+    'marbles': ('tests/golden/basic_env_nocam.yaml', 3, 40, 1.0),
+    'drone': ('examples/drone_pilot/drone_pilot.yaml', 3, 30, 1.0),
+    'ur_ik': ('examples/ur_high_5/ur_high_5.yaml', 3, 30, 1.0),
+    'ur_joint': ('examples/ur_high_5/ur_high_5_joint.yaml', 3, 30, 1.0),
+    'cart_tree': ('tests/golden/cart_tree.yaml', 3, 12, 1.0),
+    'maze': ('examples/r2d2_maze/r2d2_maze.yaml', 2, 12, 10.0),
+}
+
+
+def actions_for(env, steps, scale, seed=123):
+    from diy_gym_amd.utils import flatten, get_bounds_for_space
+    lo = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, True)), dtype=torch.float32)
+    hi = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, False)), dtype=torch.float32)
+    gen = torch.Generator().manual_seed(seed)
+    return (lo + (hi - lo) * torch.rand((steps, env.num_envs, lo.numel()), generator=gen)) * scale
+
+
+def run(name, backend_factory=None, device=None):
+    import diy_gym_amd.examples  # noqa: F401
+    from diy_gym_amd import DIYGym
+    cfg, B, steps, scale = SCENES[name]
+    kw = dict(backend_factory=backend_factory) if backend_factory else dict(device=device)
+    env = DIYGym(os.path.join(ROOT, cfg), num_envs=B, seed=11, **kw)
+    acts = actions_for(env, steps, scale)
+    obs = []
+    for s in range(steps):
+        env.sim.step(env._all_slots, acts[s].to(env.device))
+        obs.append(env.sim.obs.detach().cpu().numpy().copy())
+    return dict(actions=acts.numpy(), obs=np.stack(obs), rew=env.sim.rew.cpu().numpy(), term=env.sim.term.cpu().numpy(),
+                state=np.asarray(env.sim.get_state(), dtype=np.float64))
+
+
+def main():
+    from oracle_backend import OracleBackend
+    out = {}
+    for name in SCENES:
+        r = run(name, backend_factory=OracleBackend)
+        for k, v in r.items():
+            out['%s/%s' % (name, k)] = v.astype(np.float32) if v.dtype == np.float64 and k != 'state' else v
+        print(name, 'obs', r['obs'].shape, 'state', r['state'].shape)
+    np.savez_compressed(os.path.join(HERE, 'vectors.npz'), **out)
+    print('wrote', os.path.join(HERE, 'vectors.npz'), os.path.getsize(os.path.join(HERE, 'vectors.npz')), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

@@ -406,8 +406,8 @@ int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* 
   if (camera < 0 || camera >= w->ncam) return fail(DG_ERR_ARG, "camera %d out of range (scene has %d)", camera, w->ncam);
   LAUNCH(pose_kernel, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table);
   const int32_t* I = w->I.data(); const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE;
-  const int npix = ci[DG_CI_WIDTH] * ci[DG_CI_HEIGHT];
-  hipLaunchKernelGGL(render_kernel, dim3((npix + 255) / 256, w->num_envs), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+  const int tiles = ((ci[DG_CI_WIDTH] + DG_TILE - 1) / DG_TILE) * ((ci[DG_CI_HEIGHT] + DG_TILE - 1) / DG_TILE);
+  hipLaunchKernelGGL(render_kernel, dim3(tiles, w->num_envs), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
                      (cfp)w->d_render_table, rgb, depth, seg);
   HIP_TRY(hipGetLastError());
   return DG_OK;

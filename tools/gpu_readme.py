@@ -23,3 +23,6 @@ px = B * 200 * 200
 print('render %.3f ms  -> %.1f GB/s of image writes (16 B/pixel), %.2f Gpixel/s' % (ms, px * 16 / ms / 1e6, px / ms / 1e6))
 d = env.sim.enable_diagnostics(); env.sim.step(env._all_slots, act); torch.cuda.synchronize()
 print('contacts mean %.1f max %d, iterations mean %.1f max %d' % (d[:, 0].float().mean(), d[:, 0].max(), d[:, 1].float().mean(), d[:, 1].max()))
+rgb, depth, seg = cam._buffers
+for name, args in (('depth only', (None, depth, None)), ('rgb only', (rgb, None, None)), ('none (no writes)', (None, None, None)), ('both', (rgb, depth, None))):
+    print('%-18s %.3f ms' % (name, t(lambda: env.sim.render(cam.camera_index, *args), 10)))

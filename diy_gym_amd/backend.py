@@ -49,7 +49,7 @@ def load_library(path=None):
     path = path or LIB_PATH
     if not os.path.isfile(path):
         raise RuntimeError('HIP library not built: %s is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
-                           '(or `make -C diy_gym_amd/csrc`).  There is no CPU fallback.' % path)
+                           '(or `make -j8 -C diy_gym_amd/csrc`).  There is no CPU fallback.' % path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

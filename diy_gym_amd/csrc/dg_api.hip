@@ -11,10 +11,16 @@
 #include <vector>
 
 #include "../../include/diygym_hip.h"
-#include "dg_solver.h"
+#include "dg_launch.h"
+#define DG_DEFINE_RENDER_KERNEL
 #include "dg_render.h"
 
 using namespace dg;
+
+namespace dg {
+extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_0;
+const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : g_launch_table_0; }
+}  // namespace dg
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -22,119 +28,6 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf; return code;
 }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
-
-// ---------------------------------------------------------------- kernels
-template <int LANES, bool PROF>
-__global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
-                                                   float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
-                                                   unsigned long long* cycles, float* gws) {
-  extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  // lanes past the batch use their own (padded) scratch column, never another env's
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
-  Prof<PROF> prof; prof.start();
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  prof.stamp(PS_KIN);
-  if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
-  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
-  prof.stamp(PS_UPDATE);
-  sim_step(ln, diag, prof);
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  prof.stamp(PS_KIN);
-  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
-                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr);
-  prof.stamp(PS_OUTPUT);
-  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
-}
-
-// Two wavefronts per workgroup, same 64 envs, same LDS workspace: wave 1 (the helper) runs the inverse kinematics
-// and the register-resident dynamics of sc.helper_body while wave 0 does everything else.  Every global / LDS
-// hand-off between the two is separated by a __syncthreads (workgroup-scope release / acquire).
-template <bool PROF>
-__global__ __launch_bounds__(128) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
-                                                        float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
-                                                        unsigned long long* cycles) {
-  extern __shared__ float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
-  if (wave == 1) {  // ---------------- helper
-    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    __syncthreads();  // B0: wave 0 has put every pose into LDS
-    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
-    __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) helper_substep(ln);
-    return;
-  }
-  Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-  Prof<PROF> prof; prof.start();
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  __syncthreads();  // B0
-  prof.stamp(PS_KIN);
-  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body);
-  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
-  __syncthreads();  // B0': the helper's motor targets are in the state
-  prof.stamp(PS_UPDATE);
-  sim_step<64, PROF, true>(ln, diag, prof);
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  prof.stamp(PS_KIN);
-  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
-                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr);
-  prof.stamp(PS_OUTPUT);
-  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
-}
-
-template <int LANES>
-__global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws) {
-  extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  // lanes past the batch use their own (padded) scratch column, never another env's
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
-  const bool doit = valid && (mask == nullptr || mask[e] != 0);
-  if (doit) {
-    ln.Sset(DG_ST_STEP, 0.0f);
-    run_reset_ops(ln);
-    Prof<false> prof;
-    for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr, prof);
-  }
-  if (obs) {
-    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-    run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr);
-  }
-}
-
-template <int LANES>
-__global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term,
-                                                      float* rew_sum, uint8_t* term_flag, float* gws) {
-  extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, false);  // never stores state
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
-                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr);
-}
-
-template <int LANES>
-__global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws) {
-  extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + env, state + env, env, false);
-  ln.kinematics(body);
-  V3 p, v, w; Q4 q; ln.frame_state(body, frame, com != 0, p, q, v, w, true);
-  float* o = out + (size_t)env * 13;
-  o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w; o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
-}
 
 __global__ void init_state_kernel(const float* init, float* state, int state_dim, int stride) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= stride) return;
@@ -302,12 +195,8 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // cameras: per-env shape/camera pose table written by pose_kernel, read by render_kernel
   w->ncam = I[DG_H_N_CAMERAS]; w->d_CI = dI + I[DG_H_OFF_CAMERA_I]; w->d_CF = dF + I[DG_H_OFF_CAMERA_F]; w->d_PLN = dF + I[DG_H_OFF_PLANE_F];
   if (w->ncam > 0) HIP_TRY(hipMalloc((void**)&w->d_render_table, sizeof(float) * (size_t)num_envs * (size_t)(sc.nsh * RS_STRIDE + w->ncam * RC_STRIDE)));
-  // allow > 64 KiB of dynamic LDS
-#define SET_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, w->lds_bytes))
-  if (lanes == 64) { SET_ATTR(step_kernel_par<false>); SET_ATTR(step_kernel_par<true>); SET_ATTR((step_kernel<64, false>)); SET_ATTR((step_kernel<64, true>)); SET_ATTR(reset_kernel<64>); SET_ATTR(observe_kernel<64>); SET_ATTR(frame_kernel<64>); SET_ATTR(pose_kernel<64>); }
-  else if (lanes == 32) { SET_ATTR((step_kernel<32, false>)); SET_ATTR(reset_kernel<32>); SET_ATTR(observe_kernel<32>); SET_ATTR(frame_kernel<32>); SET_ATTR(pose_kernel<32>); }
-  else if (lanes == 16) { SET_ATTR((step_kernel<16, false>)); SET_ATTR((step_kernel<16, true>)); SET_ATTR(reset_kernel<16>); SET_ATTR(observe_kernel<16>); SET_ATTR(frame_kernel<16>); SET_ATTR(pose_kernel<16>); }
-#undef SET_ATTR
+  // allow > 64 KiB of dynamic LDS for this mode's kernels
+  HIP_TRY(launch_table(lanes).prepare(w->lds_bytes));
   *out = w;
   return DG_OK;
 }
@@ -343,20 +232,12 @@ int32_t dg_world_init_state(dg_world* w, float* state, void* stream) {
   return DG_OK;
 }
 
-#define LAUNCH(KERNEL, ...)                                                                                                  \
-  do {                                                                                                                       \
-    const int per = w->lanes > 0 ? w->lanes : 64;                                                                            \
-    const dim3 grid((w->num_envs + per - 1) / per), block(64);                                                               \
-    if (w->lanes == 64) hipLaunchKernelGGL(KERNEL<64>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws);      \
-    else if (w->lanes == 32) hipLaunchKernelGGL(KERNEL<32>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws); \
-    else if (w->lanes == 16) hipLaunchKernelGGL(KERNEL<16>, grid, block, w->lds_bytes, (hipStream_t)stream, __VA_ARGS__, w->d_gws); \
-    else hipLaunchKernelGGL(KERNEL<0>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__, w->d_gws);                          \
-    HIP_TRY(hipGetLastError());                                                                                              \
-  } while (0)
+static dim3 grid_of(const dg_world* w) { const int per = w->lanes > 0 ? w->lanes : 64; return dim3((w->num_envs + per - 1) / per); }
 
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
-  LAUNCH(reset_kernel, w->sc, w->mt, state, mask, obs);
+  launch_table(w->lanes).reset(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, state, mask, obs, w->d_gws);
+  HIP_TRY(hipGetLastError());
   return DG_OK;
 }
 
@@ -381,21 +262,10 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
     }
   }
   {
-    const int per = w->lanes > 0 ? w->lanes : 64;
-    const dim3 grid((w->num_envs + per - 1) / per), block(64); hipStream_t st = (hipStream_t)stream;
-#define STEP_ARGS w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag
-    if (w->par) {
-      if (w->profile_cycles) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(128), w->lds_bytes, st, STEP_ARGS, w->profile_cycles);
-      else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(128), w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr);
-    } else if (w->profile_cycles) {
-      if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
-      else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, true>), grid, block, w->lds_bytes, st, STEP_ARGS, w->profile_cycles, w->d_gws);
-      else return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 and 16 envs per wavefront only");
-    } else if (w->lanes == 64) hipLaunchKernelGGL((step_kernel<64, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
-    else if (w->lanes == 32) hipLaunchKernelGGL((step_kernel<32, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
-    else if (w->lanes == 16) hipLaunchKernelGGL((step_kernel<16, false>), grid, block, w->lds_bytes, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
-    else hipLaunchKernelGGL((step_kernel<0, false>), grid, block, 0, st, STEP_ARGS, (unsigned long long*)nullptr, w->d_gws);
-#undef STEP_ARGS
+    const LaunchTable& lt = launch_table(w->lanes); const bool prof = w->profile_cycles != nullptr;
+    if (prof && !lt.has_prof) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 and 16 envs per wavefront only");
+    if (w->par) lt.step_par(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles);
+    else lt.step(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles, w->d_gws);
     HIP_TRY(hipGetLastError());
   }
   return DG_OK;
@@ -404,7 +274,8 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
 int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
   if (camera < 0 || camera >= w->ncam) return fail(DG_ERR_ARG, "camera %d out of range (scene has %d)", camera, w->ncam);
-  LAUNCH(pose_kernel, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table);
+  launch_table(w->lanes).pose(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table, w->d_gws);
+  HIP_TRY(hipGetLastError());
   const int32_t* I = w->I.data(); const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE;
   const int tiles = ((ci[DG_CI_WIDTH] + DG_TILE - 1) / DG_TILE) * ((ci[DG_CI_HEIGHT] + DG_TILE - 1) / DG_TILE);
   hipLaunchKernelGGL(render_kernel, dim3(tiles, w->num_envs), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
@@ -417,7 +288,8 @@ int32_t dg_world_set_profile_buffer(dg_world* w, uint64_t* cycles) { if (!w) ret
 
 int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
-  LAUNCH(observe_kernel, w->sc, w->mt, const_cast<float*>(state), obs, rew, term, rew_sum, term_flag);
+  launch_table(w->lanes).observe(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), obs, rew, term, rew_sum, term_flag, w->d_gws);
+  HIP_TRY(hipGetLastError());
   return DG_OK;
 }
 
@@ -431,7 +303,8 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
     for (int f = 0; f < w->sc.nfr; f++) if (FI[f * DG_FI_STRIDE + DG_FI_BODY] == body) { if (seen == frame) { gf = f; found = true; break; } seen++; }
     if (!found) return fail(DG_ERR_ARG, "body %d has no frame %d", body, frame);
   }
-  LAUNCH(frame_kernel, w->sc, w->mt, const_cast<float*>(state), body, gf, com, out);
+  launch_table(w->lanes).frame(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), body, gf, com, out, w->d_gws);
+  HIP_TRY(hipGetLastError());
   return DG_OK;
 }
 

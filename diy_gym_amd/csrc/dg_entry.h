@@ -1,0 +1,122 @@
+// dg_entry.h -- the __global__ entry points of the step path (templates on the envs-per-wavefront mode).
+// Instantiated in dg_inst.hip, one translation unit per (mode, part) so that the library builds in parallel.
+#pragma once
+#include "dg_solver.h"
+#include "dg_render.h"
+
+namespace dg {
+
+template <int LANES, bool PROF>
+__global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
+                                                   float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
+                                                   unsigned long long* cycles, float* gws) {
+  extern __shared__ float smem[];
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  // lanes past the batch use their own (padded) scratch column, never another env's
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
+  Prof<PROF> prof; prof.start();
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
+  if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
+  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+  prof.stamp(PS_UPDATE);
+  sim_step(ln, diag, prof);
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+  prof.stamp(PS_OUTPUT);
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
+}
+
+// Two wavefronts per workgroup, same 64 envs, same LDS workspace: wave 1 (the helper) runs the inverse kinematics
+// and the register-resident dynamics of sc.helper_body while wave 0 does everything else.  Every global / LDS
+// hand-off between the two is separated by a __syncthreads (workgroup-scope release / acquire).
+template <bool PROF>
+__global__ __launch_bounds__(128) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
+                                                        float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
+                                                        unsigned long long* cycles) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
+  if (wave == 1) {  // ---------------- helper
+    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    __syncthreads();  // B0: wave 0 has put every pose into LDS
+    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
+    __syncthreads();  // B0'
+    for (int k = 0; k < sc.substeps; k++) helper_substep(ln);
+    return;
+  }
+  Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+  Prof<PROF> prof; prof.start();
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  __syncthreads();  // B0
+  prof.stamp(PS_KIN);
+  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body);
+  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+  __syncthreads();  // B0': the helper's motor targets are in the state
+  prof.stamp(PS_UPDATE);
+  sim_step<64, PROF, true>(ln, diag, prof);
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  prof.stamp(PS_KIN);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+  prof.stamp(PS_OUTPUT);
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws) {
+  extern __shared__ float smem[];
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  // lanes past the batch use their own (padded) scratch column, never another env's
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
+  const bool doit = valid && (mask == nullptr || mask[e] != 0);
+  if (doit) {
+    ln.Sset(DG_ST_STEP, 0.0f);
+    run_reset_ops(ln);
+    Prof<false> prof;
+    for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr, prof);
+  }
+  if (obs) {
+    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+    run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term,
+                                                      float* rew_sum, uint8_t* term_flag, float* gws) {
+  extern __shared__ float smem[];
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, false);  // never stores state
+  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
+                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
+                 (valid && term_flag) ? term_flag + e : nullptr);
+}
+
+template <int LANES>
+__global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws) {
+  extern __shared__ float smem[];
+  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
+  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + env, state + env, env, false);
+  ln.kinematics(body);
+  V3 p, v, w; Q4 q; ln.frame_state(body, frame, com != 0, p, q, v, w, true);
+  float* o = out + (size_t)env * 13;
+  o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w; o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+}
+
+
+}  // namespace dg

@@ -101,6 +101,7 @@ DGD void ray_hull(V3 o, V3 d, const M3& Rl, V3 pl, cfp planes, int np, RayHit& h
   h.t = tn; h.n = mul(Rl, nn); h.shape = sh;
 }
 
+#ifdef DG_DEFINE_RENDER_KERNEL  // defined in exactly one translation unit (dg_api.hip)
 // One 16 x 16 pixel tile per workgroup.  Phase 1: the 256 threads cull the env's shapes against the tile's viewing
 // cone (bounding spheres) and compact the survivors IN SHAPE ORDER into an LDS list, so ties between coincident
 // surfaces resolve exactly as in a brute-force loop.  Phase 2: every pixel intersects only the listed shapes; the
@@ -185,5 +186,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
   }
   }
 }
+
+#endif  // DG_DEFINE_RENDER_KERNEL
 
 }  // namespace dg

@@ -30,9 +30,9 @@ class AddonFactory:
             from .controllers import InverseKinematicsController, JointController, ExternalForce
             from .sensors import Camera, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
-            from .misc import Respawn
-            from .unsupported import (AdmittanceController, ForceTorqueSensor, StuckJointCost, SpawnMultiple,
-                                      DrawCoords, VisualRandomizer, DynamicsRandomizer)
+            from .misc import Respawn, SpawnMultiple
+            from .unsupported import (AdmittanceController, ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer,
+                                      DynamicsRandomizer)
             # same 17 keys as reference addon.py:36-54
             self.addons = {
                 'ik_controller': InverseKinematicsController,

@@ -148,3 +148,17 @@ def test_error_conventions():
         DIYGym(Configuration.from_dict('e', {'x': {'model': 'nope.urdf'}}), backend_factory=OracleBackend)
     with pytest.raises(NotImplementedError):
         DIYGym(Configuration.from_dict('e', {'gui': {'addon': 'draw_coords'}}), backend_factory=OracleBackend)
+
+
+def test_spawn_multiple_clones_into_parent_models():
+    from diy_gym_amd.config import Configuration
+    tree = {'plane': {'model': 'grass/plane.urdf'},
+            'crowd': {'addon': 'spawn_multiple', 'num_models': 3,
+                      'ball': {'model': 'sphere2.urdf', 'scale': 0.2, 'xyz': [0, 0, 1.0],
+                               'pose': {'addon': 'object_state_sensor'}}}}
+    env = DIYGym(Configuration.from_dict('crowd_env', tree), num_envs=2, backend_factory=OracleBackend)
+    assert [k for k in env.models] == ['plane', 'ball_0', 'ball_1', 'ball_2']  # appended after the sorted models, like the reference
+    assert list(env.receptors) == ['ball_0', 'ball_1', 'ball_2', 'crowd_env', 'plane']
+    assert sorted(env.models[k].uid for k in ('ball_0', 'ball_1', 'ball_2')) == [1, 2, 3]
+    obs = env.reset()
+    assert obs['ball_1']['pose']['position'].shape == (2, 3)

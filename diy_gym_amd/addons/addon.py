@@ -27,11 +27,11 @@ class AddonFactory:
 
     class _Registry:
         def __init__(self):
-            from .controllers import InverseKinematicsController, JointController, ExternalForce
+            from .controllers import AdmittanceController, InverseKinematicsController, JointController, ExternalForce
             from .sensors import Camera, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
             from .misc import Respawn, SpawnMultiple
-            from .unsupported import (AdmittanceController, ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer,
+            from .unsupported import (ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer,
                                       DynamicsRandomizer)
             # same 17 keys as reference addon.py:36-54
             self.addons = {

@@ -154,3 +154,41 @@ class Propellor(_Controller):
 
     def observe(self):
         return self.env._obs_view(self.obs_op.io_off, 1)
+
+
+class AdmittanceController(_Controller):
+    """End-effector wrench control: joint torques = J^T [force; torque] + gravity compensation + a joint-space
+    PD towards ``target_pose`` (reference: diy_gym/addons/controllers/admittance_controller.py:8-55).
+
+    Configs: ``end_effector``, ``offset_admittance_point`` ([0,0,0], in the end-effector link's inertial frame),
+    ``p_gain`` (0.001), ``d_gain`` (0.01), ``rest_position``, ``target_pose`` (rest_position).  The joints' default
+    velocity motors are switched off at construction, as the reference does (:34).
+    """
+    def __init__(self, parent, config):
+        super().__init__(parent, config)
+        self.uid = parent.uid
+        robot = parent.robot
+        self.end_frame = parent.get_frame_id(config.get('end_effector'))
+        self.offset_admittance_point = list(config.get('offset_admittance_point', [0., 0., 0.]))
+        self.kp = config.get('p_gain', 0.001)
+        self.kd = config.get('d_gain', 0.01)
+        self.joint_ids = [j.index for j in robot.joints if j.index <= self.end_frame and j.q_index > -1]
+        self.rest_position = list(config.get('rest_position', [0] * len(self.joint_ids)))
+        self.target_pose = np.array(config.get('target_pose', self.rest_position), dtype=np.float64)
+        self.action_space = spaces.Dict(OrderedDict(force=spaces.Box(-5, 5, shape=(3, ), dtype='float32'),
+                                                    torque=spaces.Box(-1., 1., shape=(3, ), dtype='float32')))
+
+    def compile(self, builder):
+        robot = self.parent.robot
+        if self.end_frame < 0:
+            raise ValueError('admittance_controller: unknown end_effector frame')
+        if len(self.joint_ids) != robot.num_dofs:
+            # p.calculateJacobian / calculateInverseDynamics want one entry per DoF of the body (:41-49)
+            raise ValueError('admittance_controller: %d joints up to the end effector but the body has %d DoF' %
+                             (len(self.joint_ids), robot.num_dofs))
+        dofs = [builder.global_link(self.uid, robot.joints[j].q_index) for j in self.joint_ids]
+        n_reset = min(len(dofs), len(self.rest_position))
+        builder.add_op(K.OP_RESET_JOINTS, 'reset', body=self.uid, ilist=dofs[:n_reset], flist=self.rest_position[:n_reset])
+        target = (list(self.target_pose) + [0.0] * len(dofs))[:len(dofs)]
+        self.op = builder.add_op(K.OP_ADMITTANCE, 'act', body=self.uid, frame=self.end_frame, ilist=dofs, flist=target,
+                                 fparams=self.offset_admittance_point + [self.kp, self.kd], io_dim=6)

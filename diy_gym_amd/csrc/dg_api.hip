@@ -183,6 +183,10 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);
   for (int l = 0; l < nl; l++) { w->mt.v[3 * l] = 0.f; w->mt.v[3 * l + 1] = 1.f; w->mt.v[3 * l + 2] = -(float)F[DG_HF_DEFAULT_MOTOR_IMPULSE]; }
+  for (int op = 0; op < I[DG_H_N_OPS]; op++) {  // admittance_controller.py:34: its joints' velocity motors are switched off at construction
+    const int32_t* oi = OI + op * DG_OI_STRIDE;
+    if (oi[DG_OI_CODE] == DG_OP_ADMITTANCE) for (int k = 0; k < oi[DG_OI_N]; k++) w->mt.v[3 * (I[I[DG_H_OFF_ILIST] + oi[DG_OI_ILIST] + k]) + 2] = 0.f;
+  }
   // ---- load-time state vector
   std::vector<float> init((size_t)sc.state_dim, 0.f);
   const double* BF = F + I[DG_H_OFF_BODY_F];

@@ -846,7 +846,7 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
   const DevScene& sc = ln.sc;
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
-    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
+    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_ADMITTANCE) continue;
     if ((only_body >= 0 && oi[DG_OI_BODY] != only_body) || oi[DG_OI_BODY] == skip_body) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
     const float* a = act_row + oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST]; const int n = oi[DG_OI_N];
@@ -879,6 +879,31 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
         ln.Sset(lo + DG_LS_TARGET_POS, ln.L(sc.tr_off + (il[k] - ln.bi(b)[DG_BI_FIRST_LINK]))); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f);
       }
       ln.kinematics(b);  // restore POSE to the state's joint angles
+    } else if (code == DG_OP_ADMITTANCE) {
+      // J^T wrench at the end-effector point + gravity compensation + joint PD, applied as joint torques
+      // (admittance_controller.py:36-55).  World-frame Jacobian columns from the POSE region.
+      const int b = oi[DG_OI_BODY], first = ln.bi(b)[DG_BI_FIRST_LINK], nl = ln.bi(b)[DG_BI_N_LINKS];
+      V3 fp, fv, fw; Q4 fq; ln.frame_state(b, oi[DG_OI_FRAME], true, fp, fq, fv, fw, false);
+      const V3 pw = fp + mul(qmat(fq), v3(of[0], of[1], of[2]));
+      const int eel = sc.FI[oi[DG_OI_FRAME] * DG_FI_STRIDE + DG_FI_LINK];
+      const V3 F = v3(a[0], a[1], a[2]), T = v3(a[3], a[4], a[5]), g = v3(sc.gx, sc.gy, sc.gz); cfp tgt = sc.FL + oi[DG_OI_FLIST];
+      for (int k = 0; k < n; k++) {
+        const int gl = il[k], lo = ln.li(gl)[DG_LI_STATE_OFF], po = ln.pll(gl)[PLL_POSE]; cfp f = ln.lf(gl);
+        const M3 Rj = ln.LR(po); const V3 oj = ln.L3(po + 6), axw = mul(Rj, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
+        const bool rev = ln.li(gl)[DG_LI_TYPE] == 0;
+        bool anc = false; for (int i = eel; i >= 0; i = ln.li(i)[DG_LI_PARENT]) if (i == gl) anc = true;
+        float tau = 0.f;
+        if (anc) tau += rev ? dot(F, cross(axw, pw - oj)) + dot(T, axw) : dot(F, axw);
+        for (int i = first; i < first + nl; i++) {
+          bool sub = false; for (int q = i; q >= 0; q = ln.li(q)[DG_LI_PARENT]) if (q == gl) sub = true;
+          if (!sub) continue;
+          cfp fi2 = ln.lf(i); const int pi2 = ln.pll(i)[PLL_POSE];
+          const V3 cw = ln.L3(pi2 + 6) + mul(ln.LR(pi2), v3(fi2[DG_LF_COM], fi2[DG_LF_COM + 1], fi2[DG_LF_COM + 2])); const V3 w8 = g * fi2[DG_LF_MASS];
+          tau -= rev ? dot(w8, cross(axw, cw - oj)) : dot(w8, axw);
+        }
+        tau += of[3] * (tgt[k] - ln.S(lo + DG_LS_Q)) - of[4] * ln.S(lo + DG_LS_QD);
+        ln.Sset(lo + DG_LS_TORQUE, ln.S(lo + DG_LS_TORQUE) + tau);
+      }
     } else if (code == DG_OP_EXTERNAL_FORCE) {
       const int b = oi[DG_OI_BODY]; if (ln.fixed(b)) continue;
       const int eo = ln.ext_off(b); V3 f = v3(a[0], a[1], a[2]); V3 t = cross(v3(of[0], of[1], of[2]) - ln.base_pos(b), f);

@@ -181,6 +181,7 @@ enum {
   DG_OP_IK_CONTROL = 2,      /* ik_controller.py:51-80    */
   DG_OP_EXTERNAL_FORCE = 3,  /* external_force.py:21-24   */
   DG_OP_PROPELLOR = 4,       /* examples/drone_pilot/drone_pilot.py:31-37 */
+  DG_OP_ADMITTANCE = 5,      /* admittance_controller.py:36-55: J^T wrench + gravity compensation + joint PD -> torques */
   /* reset phase (reference Addon.reset, diy_gym.py:141-143) */
   DG_OP_RESPAWN = 16,        /* respawn.py:31-39 */
   DG_OP_RESET_JOINTS = 17,   /* joint_controller.py:36-38, ik_controller.py:47-49 */

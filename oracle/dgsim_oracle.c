@@ -319,6 +319,10 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
     w->mcfg[l * DG_MC_STRIDE + DG_MC_KD] = 1.0;
     w->mcfg[l * DG_MC_STRIDE + DG_MC_MAX_IMPULSE_SCALE] = -w->sc.F[DG_HF_DEFAULT_MOTOR_IMPULSE];
   }
+  for (int op = 0; op < w->sc.nops; op++) { /* admittance_controller.py:34: VELOCITY_CONTROL with forces = 0 at construction */
+    const int32_t* oi = w->sc.OI + op * DG_OI_STRIDE;
+    if (oi[DG_OI_CODE] == DG_OP_ADMITTANCE) for (int k = 0; k < oi[DG_OI_N]; k++) w->mcfg[w->sc.IL[oi[DG_OI_ILIST] + k] * DG_MC_STRIDE + DG_MC_MAX_IMPULSE_SCALE] = 0.0;
+  }
   /* initial state = load pose (reference model.py:68), joints at zero */
   for (int e = 0; e < num_envs; e++) {
     double* st = env_state(w, e);
@@ -953,7 +957,7 @@ static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t ma
   for (int op = 0; op < s->nops; op++) {
     const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
     int code = oi[DG_OI_CODE];
-    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_PROPELLOR) continue;
+    if (code < DG_OP_JOINT_CONTROL || code > DG_OP_ADMITTANCE) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ULL)) continue;
     const double* a = act + oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST]; int n = oi[DG_OI_N];
     if (code == DG_OP_JOINT_CONTROL) { /* joint_controller.py:40-58 */
@@ -973,6 +977,36 @@ static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t ma
         ls[DG_LS_TARGET_POS] = q[k]; /* joint_cmds[k] pairs with joint_ids[k] (ik_controller.py:69-74) */
         ls[DG_LS_TARGET_VEL] = 0.0; set_motor(w, gl, of[0], of[1], link_f(s, gl)[DG_LF_MAX_FORCE]);
       }
+    } else if (code == DG_OP_ADMITTANCE) { /* admittance_controller.py:36-55 */
+      /* torque_j = force . J_lin[:,j] + torque . J_ang[:,j]   (p.calculateJacobian at the end-effector link's
+       *            inertial frame + offset, :39-46, :50)
+       *          + gravity torque needed to hold the pose (p.calculateInverseDynamics with zero velocity and
+       *            acceleration, :49)  + kp (target - q) - kd qd  (:52-53), applied in TORQUE_CONTROL (:55) */
+      int b = oi[DG_OI_BODY]; BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); body_kinematics(s, st, b, ws, NULL);
+      FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 1, NULL, &f);
+      m3 Rf = qmat(f.q); v3 pw = vadd(f.p, mv(&Rf, V(of[0], of[1], of[2])));
+      const int32_t* fi = s->FI + oi[DG_OI_FRAME] * DG_FI_STRIDE; int lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
+      v3 F = V(a[0], a[1], a[2]), T = V(a[3], a[4], a[5]); const double* tgt = s->FL + oi[DG_OI_FLIST];
+      for (int k = 0; k < n; k++) {
+        int gl = il[k], j = gl - ws->first; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+        v3 aw = mv(&ws->Rw[j], ang(&ws->S[j])), lw = mv(&ws->Rw[j], lin(&ws->S[j])); int rev = link_i(s, gl)[DG_LI_TYPE] == 0;
+        /* is joint j an ancestor of (or equal to) the end-effector link? */
+        int anc = 0; for (int i = lk; i >= 0; i = ws->parent[i]) if (i == j) anc = 1;
+        double tau = 0;
+        if (anc) tau += rev ? vdot(F, vcross(aw, vsub(pw, ws->pw[j]))) + vdot(T, aw) : vdot(F, lw);
+        /* gravity: every link in the subtree of j */
+        for (int i = 0; i < ws->n; i++) {
+          int sub = 0; for (int q = i; q >= 0; q = ws->parent[q]) if (q == j) sub = 1;
+          if (!sub) continue;
+          const double* lf = link_f(s, ws->first + i);
+          v3 cw = vadd(ws->pw[i], mv(&ws->Rw[i], V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2])));
+          v3 w8 = vscale(s->g, lf[DG_LF_MASS]);
+          tau -= rev ? vdot(w8, vcross(aw, vsub(cw, ws->pw[j]))) : vdot(w8, lw);
+        }
+        tau += of[3] * (tgt[k] - ls[DG_LS_Q]) - of[4] * ls[DG_LS_QD];
+        ls[DG_LS_TORQUE] += tau;
+      }
+      free(ws);
     } else if (code == DG_OP_EXTERNAL_FORCE) { /* external_force.py:21-24: WORLD_FRAME force at a world position */
       int b = oi[DG_OI_BODY]; if (body_fixed(s, b)) continue;
       double* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; double* ex = body_ext(s, st, b);

@@ -17,6 +17,7 @@ CONFIGS = {
     'cart_tree': os.path.join(ROOT, 'tests', 'golden', 'cart_tree.yaml'),
     'maze': os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml'),
     'readme': os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml'),
+    'admittance': os.path.join(ROOT, 'tests', 'golden', 'ur_admittance.yaml'),
 }
 
 
@@ -94,6 +95,14 @@ def test_ur_high_5_ik_100_steps():
     gpu, cpu = make_pair('ur_ik', 67)
     w = rollout(gpu, cpu, 100)
     assert w['obs'] < 5e-4 and w['rew'] < 5e-4, w
+
+
+def test_admittance_controller_80_steps():
+    # torque-controlled UR5 (J^T wrench + gravity compensation + PD), velocity motors off: free dynamics, so
+    # fp32 drift grows faster than under position motors
+    gpu, cpu = make_pair('admittance', 33)
+    w = rollout(gpu, cpu, 80)
+    assert w['obs'] < 3e-3, w
 
 
 def test_drone_pilot_60_steps():

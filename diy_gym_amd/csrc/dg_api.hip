@@ -119,6 +119,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   slot += tr + 8;  // + padding for the chunked vector helpers
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
+  if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16) lanes = v; }
   while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
   if (lanes < 16) {
     // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer [slot][env_stride]

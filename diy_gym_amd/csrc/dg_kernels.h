@@ -515,10 +515,16 @@ struct Lane {
       L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
     }
     (void)n;
+    // M^-1 is symmetric: row i is contiguous, so each response entry is one batched dot product (chunks of 8
+    // independent LDS reads; the <= 7 slots read past a vector are allocated and masked out)
     float diag = 0.f;
     for (int i = 0; i < nv; i++) {
       float s = 0.f;
-      for (int j = 0; j < nv; j++) s += L(mo + j * nv + i) * L(jo + j);
+      for (int c0 = 0; c0 < nv; c0 += 8) {
+        float x[8], y[8];
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { x[j] = L(mo + i * nv + c0 + j); y[j] = L(jo + c0 + j); }
+        _Pragma("unroll") for (int j = 0; j < 8; j++) s += (c0 + j < nv) ? x[j] * y[j] : 0.f;
+      }
       L(ro + i) = s; diag += s * L(jo + i);
     }
     return diag;

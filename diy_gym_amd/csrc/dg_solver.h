@@ -409,6 +409,131 @@ DGD float pgs_rows_small(const Lane<LANES>& ln, int b, bool live) {
   return maxres;
 }
 
+// ---- every row of the scene with the velocity change in registers (total DoF <= NTB <= 32, no register-chain
+// bodies).  The whole Gauss-Seidel loop runs here: the velocity change never leaves the registers between
+// iterations, motor / joint-limit rows read their M^-1 column straight from LDS into a register vector, contact rows
+// are streamed [J | R | b acc diag] with the NEXT row's loads issued before the current row is solved (an LDS store
+// would otherwise fence them), and vectors are padded to NTB in registers by clamped-address loads times a 0/1
+// mask -- no branches inside a row.
+template <int NTB> struct DenseRow { float J[NTB], R[NTB], b, acc, diag; };
+template <int NTB> struct DenseCol { float R[NTB], b, acc, diag, lim; int mo, j; };
+
+template <int LANES, int NTB, bool PROF>
+DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
+  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; const float h = sc.h;
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
+  constexpr int T0 = NTB - 8;  // elements below T0 always exist (bucket choice)
+  float dv[NTB];
+#pragma unroll
+  for (int k = 0; k < NTB; k++) dv[k] = 0.f;
+  // v[k] = L(o + k) for k < nt, 0 beyond: every element is loaded (the <= 7 slots past the vector are allocated
+  // workspace whose contents do not matter), then the tail is cleared by a select on the uniform bound
+  auto load_vec = [&](float (&v)[NTB], int o) {
+#pragma unroll
+    for (int k = 0; k < NTB; k++) v[k] = ln.L(o + k);
+#pragma unroll
+    for (int k = T0; k < NTB; k++) v[k] = k < nt ? v[k] : 0.f;
+  };
+  auto load_row = [&](DenseRow<NTB>& r, int ro) { load_vec(r.J, ro); load_vec(r.R, ro + nt); r.b = ln.L(ro + 2 * nt); r.acc = ln.L(ro + 2 * nt + 1); r.diag = ln.L(ro + 2 * nt + 2); };
+  float maxres = 0.f; bool live = ln.valid;
+  auto solve_row = [&](const DenseRow<NTB>& r, int ro, float lo, float hi) {
+    float jv = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTB; k++) jv += r.J[k] * dv[k];
+    float delta = (r.b - jv) / r.diag;
+    const float nacc = fminf(fmaxf(r.acc + delta, lo), hi);
+    delta = live && r.diag > 1e-18f ? nacc - r.acc : 0.f;
+    ln.L(ro + 2 * nt + 1) = r.acc + delta;
+#pragma unroll
+    for (int k = 0; k < NTB; k++) dv[k] += r.R[k] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  // a motor or limit row on global DoF j of a body whose DoFs are [base, base + nv): R = column of the body's M^-1
+  auto load_col = [&](float (&v)[NTB], int col, int base, int nv) {
+    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+#pragma unroll
+    for (int k = 0; k < NTB; k++) { const int i = k - base; const bool in = i >= 0 && i < nv; v[k] = ln.L(col + min(max(i, 0), nv - 1)) * (in ? 1.f : 0.f); }
+  };
+  auto next_motor = [&](int g) { for (; g < sc.nl; g++) { const float maxf = ln.mt.v[3 * g + 2]; if ((maxf < 0.f ? -maxf : maxf * h) > 0.f) break; } return g; };
+  auto load_motor = [&](DenseCol<NTB>& r, int gl) {
+    const int b = ln.li(gl)[DG_LI_BODY], nv = ln.plb(b)[PLB_NV], base = ln.plb(b)[PLB_DV] - sc.dv_base;
+    const int jb = (ln.fixed(b) ? 0 : 6) + gl - ln.bi(b)[DG_BI_FIRST_LINK], col = ln.plb(b)[PLB_MINV] + jb * nv;
+    const float maxf = ln.mt.v[3 * gl + 2];
+    r.mo = ln.pll(gl)[PLL_MROW]; r.j = base + jb; r.lim = maxf < 0.f ? -maxf : maxf * h;
+    load_col(r.R, col, base, nv); r.b = ln.L(r.mo + MR_B); r.acc = ln.L(r.mo + MR_ACC); r.diag = ln.L(col + jb);
+  };
+  auto solve_motor = [&](const DenseCol<NTB>& r) {
+    float delta = (r.b - dv[r.j]) / r.diag;
+    const float nacc = fminf(fmaxf(r.acc + delta, -r.lim), r.lim);
+    delta = live ? nacc - r.acc : 0.f; ln.L(r.mo + MR_ACC) = r.acc + delta;
+#pragma unroll
+    for (int k = 0; k < NTB; k++) dv[k] += r.R[k] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  int iters_done = 0;
+  for (int it = 0; it < sc.iters; it++) {
+    maxres = 0.f;
+    // ---- motor rows (oracle order: link by link), loads one row ahead of the solve
+    {
+      DenseCol<NTB> A, B;
+      int g = next_motor(0);
+      if (g < sc.nl) load_motor(A, g);
+      while (g < sc.nl) {
+        const int g2 = next_motor(g + 1); if (g2 < sc.nl) load_motor(B, g2);
+        solve_motor(A);
+        if (g2 >= sc.nl) break;
+        g = next_motor(g2 + 1); if (g < sc.nl) load_motor(A, g);
+        solve_motor(B);
+      }
+    }
+    prof.stamp(PS_PGS_MOTOR);
+    // ---- joint-limit rows: only those some lane has active (the flag cannot change during the sweeps)
+    for (uint64_t m = limit_rows; m; m &= m - 1) {
+      const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1;
+      const int b = ln.li(gl)[DG_LI_BODY], nv = ln.plb(b)[PLB_NV], base = ln.plb(b)[PLB_DV] - sc.dv_base;
+      const int jb = (ln.fixed(b) ? 0 : 6) + gl - ln.bi(b)[DG_BI_FIRST_LINK], col = ln.plb(b)[PLB_MINV] + jb * nv;
+      const int bo = ln.pll(gl)[PLL_MROW] + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
+      float R[NTB]; load_col(R, col, base, nv);
+      const float diag = ln.L(col + jb), acc = ln.L(bo + 1), bb = ln.L(bo); const bool act = acc >= 0.f;
+      float delta = (bb - sg * dv[base + jb]) / diag;
+      const float nacc = fmaxf(acc + delta, 0.f);
+      delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
+      const float sd = sg * delta;
+#pragma unroll
+      for (int k = 0; k < NTB; k++) dv[k] += R[k] * sd;
+      const float res = delta * diag; maxres = fmaxf(maxres, res * res);
+    }
+    prof.stamp(PS_PGS_LIMIT);
+    // ---- contact normals, then friction pairs; two row buffers ping-pong so that loads run one row ahead
+    if (wave_max_cont > 0) {
+      DenseRow<NTB> A, B;
+      const int r0 = sc.tr_off;
+      if (0 < ncont) load_row(A, r0);
+      for (int c = 0; c < wave_max_cont; c += 2) {
+        if (c + 1 < ncont) load_row(B, r0 + 3 * (c + 1) * rs);
+        if (c < ncont) solve_row(A, r0 + 3 * c * rs, 0.f, 3.0e38f);
+        if (c + 2 < ncont) load_row(A, r0 + 3 * (c + 2) * rs);
+        if (c + 1 < ncont) solve_row(B, r0 + 3 * (c + 1) * rs, 0.f, 3.0e38f);
+      }
+      for (int c = 0; c < wave_max_cont; c++) {
+        const bool act = c < ncont && ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) > 0.f;
+        if (act) {
+          const float lim = ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) * ln.L(r0 + 3 * c * rs + 2 * nt + 1);
+          load_row(A, r0 + (3 * c + 1) * rs); load_row(B, r0 + (3 * c + 2) * rs);
+          solve_row(A, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(B, r0 + (3 * c + 2) * rs, -lim, lim);
+        }
+      }
+    }
+    prof.stamp(PS_PGS_CONTACT);
+    if (live) iters_done = it + 1;
+    live = live && !(maxres <= thr);
+    if (!__any(live)) break;
+  }
+#pragma unroll
+  for (int k = 0; k < NTB; k++) if (k < nt) ln.L(sc.dv_base + k) = dv[k];
+  return iters_done;
+}
+
 // ---------------------------------------------------------------- substep
 // PAR: this wave is the MAIN wave of a two-wave workgroup; the helper wave (helper_substep below) owns body
 // sc.helper_body -- its kinematics and its register-resident dynamics run concurrently with everything here up to
@@ -431,6 +556,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
   uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
+  uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
   for (int gl = 0; gl < sc.nl; gl++) {
     const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
     const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
@@ -443,6 +569,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
     ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
     if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
+    if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
   }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   const int wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
@@ -461,6 +588,13 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   // ---- projected Gauss-Seidel
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int rs = crow_stride(sc.crow_tail);
   bool live = ln.valid; int iters_done = 0;
+  const bool all_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
+  if (all_dense) {
+    if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else iters_done = pgs_dense<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+  } else {
   // Register-resident rows: for up to NBR fixed-base bodies with <= RN joints (every 6-axis arm) M^-1, the
   // velocity change, the motor targets and the accumulated impulses are loaded once and the sweeps below touch
   // no LDS at all -- a dependent LDS round trip per row is what bounds the generic path with one wave per SIMD.
@@ -566,6 +700,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       for (int i = 0; i < RN; i++) if (i < rn[k]) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = racc[k][i];
     }
   }
+  }  // !all_dense
   prof.stamp(PS_PGS);
   if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
   // ---- apply velocity changes and integrate positions

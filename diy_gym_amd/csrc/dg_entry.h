@@ -12,17 +12,23 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
                                                    unsigned long long* cycles, float* gws) {
   extern __shared__ float smem[];
   constexpr int ACTIVE = LANES > 0 ? LANES : 64;
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  // 16 / 32 envs per wavefront: the spare lanes stay alive and join the dense Gauss-Seidel sweeps (pgs_dense_sliced)
+  constexpr bool SLICED = LANES == 16 || LANES == 32;
+  const int lane = threadIdx.x; if (!SLICED && lane >= ACTIVE) return;
+  const bool primary = lane < ACTIVE;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = primary && env < sc.num_envs; const int e = env < sc.num_envs ? env : sc.num_envs - 1;
   // lanes past the batch use their own (padded) scratch column, never another env's
   Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
   Prof<PROF> prof; prof.start();
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-  prof.stamp(PS_KIN);
-  if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
-  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
-  prof.stamp(PS_UPDATE);
-  sim_step(ln, diag, prof);
+  if (primary) {
+    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+    prof.stamp(PS_KIN);
+    if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
+    ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+    prof.stamp(PS_UPDATE);
+  }
+  sim_step<LANES, PROF, false, SLICED, LANES == 64 || LANES == 0>(ln, diag, prof);
+  if (!primary) return;
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,

@@ -415,10 +415,46 @@ DGD float pgs_rows_small(const Lane<LANES>& ln, int b, bool live) {
 // are streamed [J | R | b acc diag] with the NEXT row's loads issued before the current row is solved (an LDS store
 // would otherwise fence them), and vectors are padded to NTB in registers by clamped-address loads times a 0/1
 // mask -- no branches inside a row.
+// Per-link row descriptors of the dense sweeps, kept in VGPRs as 64-entry wave-uniform tables (lane gl holds link
+// gl; v_readlane fetches an entry in a few cycles).  Looking them up through the scene tables instead costs a chain
+// of dependent scalar loads per row per iteration.  FULL: all 64 lanes of the wave are ACTIVE at the call (lane gl
+// must exist and execute; not so in the reset kernel, which steps under a per-env mask, nor in the early-exit
+// 16 / 32-lane kernels).
+template <int LANES, bool FULL>
+struct LinkRows {
+  int col, mo, j, base, nv; float lim; uint64_t motors;
+  const Lane<LANES>& ln;
+  DGD LinkRows(const Lane<LANES>& l) : ln(l) {
+    col = mo = j = base = nv = 0; lim = 0.f; motors = 0ull;
+    if constexpr (FULL) {
+      const int gl = threadIdx.x & 63;
+      if (gl < ln.sc.nl) fill(gl, col, mo, j, base, nv, lim);
+      motors = __ballot(lim > 0.f);
+    } else {
+      for (int gl = 0; gl < ln.sc.nl && gl < 64; gl++) { const float maxf = ln.mt.v[3 * gl + 2]; if ((maxf < 0.f ? -maxf : maxf * ln.sc.h) > 0.f) motors |= 1ull << gl; }
+    }
+  }
+  DGD void fill(int gl, int& c, int& m, int& jj, int& bs, int& n, float& lm) const {
+    const DevScene& sc = ln.sc;
+    const int b = sc.LI[gl * DG_LI_STRIDE + DG_LI_BODY]; cip B = sc.BI + b * DG_BI_STRIDE; cip P = sc.PLB + b * PLB_STRIDE;
+    n = P[PLB_NV]; bs = P[PLB_DV] - sc.dv_base;
+    const int jb = ((B[DG_BI_FLAGS] & DG_BODY_FIXED) ? 0 : 6) + gl - B[DG_BI_FIRST_LINK];
+    c = P[PLB_MINV] + jb * n; jj = bs + jb; m = sc.PLL[gl * PLL_STRIDE + PLL_MROW];
+    const float maxf = ln.mt.v[3 * gl + 2]; lm = maxf < 0.f ? -maxf : maxf * sc.h;
+  }
+  DGD void get(int gl, int& c, int& m, int& jj, int& bs, int& n, float& lm) const {
+    if constexpr (FULL) {
+      c = __builtin_amdgcn_readlane(col, gl); m = __builtin_amdgcn_readlane(mo, gl); jj = __builtin_amdgcn_readlane(j, gl);
+      bs = __builtin_amdgcn_readlane(base, gl); n = __builtin_amdgcn_readlane(nv, gl);
+      lm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lim), gl));
+    } else fill(gl, c, m, jj, bs, n, lm);
+  }
+};
+
 template <int NTB> struct DenseRow { float J[NTB], R[NTB], b, acc, diag; };
 template <int NTB> struct DenseCol { float R[NTB], b, acc, diag, lim; int mo, j; };
 
-template <int LANES, int NTB, bool PROF>
+template <int LANES, int NTB, bool PROF, bool FULLWAVE>
 DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; const float h = sc.h;
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
@@ -454,13 +490,10 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
 #pragma unroll
     for (int k = 0; k < NTB; k++) { const int i = k - base; const bool in = i >= 0 && i < nv; v[k] = ln.L(col + min(max(i, 0), nv - 1)) * (in ? 1.f : 0.f); }
   };
-  auto next_motor = [&](int g) { for (; g < sc.nl; g++) { const float maxf = ln.mt.v[3 * g + 2]; if ((maxf < 0.f ? -maxf : maxf * h) > 0.f) break; } return g; };
+  const LinkRows<LANES, FULLWAVE> rows(ln);
   auto load_motor = [&](DenseCol<NTB>& r, int gl) {
-    const int b = ln.li(gl)[DG_LI_BODY], nv = ln.plb(b)[PLB_NV], base = ln.plb(b)[PLB_DV] - sc.dv_base;
-    const int jb = (ln.fixed(b) ? 0 : 6) + gl - ln.bi(b)[DG_BI_FIRST_LINK], col = ln.plb(b)[PLB_MINV] + jb * nv;
-    const float maxf = ln.mt.v[3 * gl + 2];
-    r.mo = ln.pll(gl)[PLL_MROW]; r.j = base + jb; r.lim = maxf < 0.f ? -maxf : maxf * h;
-    load_col(r.R, col, base, nv); r.b = ln.L(r.mo + MR_B); r.acc = ln.L(r.mo + MR_ACC); r.diag = ln.L(col + jb);
+    int col, base, nv; rows.get(gl, col, r.mo, r.j, base, nv, r.lim);
+    load_col(r.R, col, base, nv); r.b = ln.L(r.mo + MR_B); r.acc = ln.L(r.mo + MR_ACC); r.diag = ln.L(col + r.j - base);
   };
   auto solve_motor = [&](const DenseCol<NTB>& r) {
     float delta = (r.b - dv[r.j]) / r.diag;
@@ -476,13 +509,13 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     // ---- motor rows (oracle order: link by link), loads one row ahead of the solve
     {
       DenseCol<NTB> A, B;
-      int g = next_motor(0);
-      if (g < sc.nl) load_motor(A, g);
-      while (g < sc.nl) {
-        const int g2 = next_motor(g + 1); if (g2 < sc.nl) load_motor(B, g2);
+      uint64_t m = rows.motors;
+      if (m) load_motor(A, __ffsll((long long)m) - 1);
+      while (m) {
+        m &= m - 1; if (m) load_motor(B, __ffsll((long long)m) - 1);
         solve_motor(A);
-        if (g2 >= sc.nl) break;
-        g = next_motor(g2 + 1); if (g < sc.nl) load_motor(A, g);
+        if (!m) break;
+        m &= m - 1; if (m) load_motor(A, __ffsll((long long)m) - 1);
         solve_motor(B);
       }
     }
@@ -490,9 +523,8 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     // ---- joint-limit rows: only those some lane has active (the flag cannot change during the sweeps)
     for (uint64_t m = limit_rows; m; m &= m - 1) {
       const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1;
-      const int b = ln.li(gl)[DG_LI_BODY], nv = ln.plb(b)[PLB_NV], base = ln.plb(b)[PLB_DV] - sc.dv_base;
-      const int jb = (ln.fixed(b) ? 0 : 6) + gl - ln.bi(b)[DG_BI_FIRST_LINK], col = ln.plb(b)[PLB_MINV] + jb * nv;
-      const int bo = ln.pll(gl)[PLL_MROW] + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
+      int col, mo, jg, base, nv; float lim_unused; rows.get(gl, col, mo, jg, base, nv, lim_unused);
+      const int jb = jg - base, bo = mo + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
       float R[NTB]; load_col(R, col, base, nv);
       const float diag = ln.L(col + jb), acc = ln.L(bo + 1), bb = ln.L(bo); const bool act = acc >= 0.f;
       float delta = (bb - sg * dv[base + jb]) / diag;
@@ -534,17 +566,153 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
   return iters_done;
 }
 
+// ---- the same sweeps with SL = 64 / LANES lanes per environment ------------------------------------------------
+// Modes with fewer than 64 envs per wavefront (LDS-heavy scenes) leave 3/4 or 1/2 of every VALU instruction idle.
+// During the Gauss-Seidel loop -- the bulk of such a step -- the idle lanes are put to work: lane l serves env
+// (l / SL) and owns the DoFs k with k % SL == l % SL.  A row costs each lane NTB / SL loads and FMAs per vector
+// plus a quad-permute DPP reduction of the partial J.dv; every lane of an env's group computes the same impulse.
+DGD float group_sum2(float x) { return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
+DGD float group_sum4(float x) { x = group_sum2(x); return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }  // then [2,3,0,1]
+
+template <int LANES, int NTB, bool PROF>
+DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
+  static_assert(LANES == 16 || LANES == 32, "sliced sweeps are for the 16 and 32 envs-per-wavefront modes");
+  constexpr int SL = 64 / LANES, LOG = SL == 4 ? 2 : 1, NS = NTB / SL;
+  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; const float h = sc.h;
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
+  const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
+  const int envq = blockIdx.x * LANES + q; const bool validq = envq < sc.num_envs; const int eq = validq ? envq : sc.num_envs - 1;
+  const Lane<LANES> lq(sc, ln.mt, ln.lds - lane + q, ln.st - ln.env + eq, eq, validq);
+  const int ncont = __shfl(ncont_primary, q);
+  float* const ls = lq.lds + sl * LANES;  // this lane's slice: slot (o + i SL) through ls is DoF i SL + sl of vector o
+  auto group_sum = [&](float x) { return SL == 4 ? group_sum4(x) : group_sum2(x); };
+  float dv[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) dv[i] = 0.f;
+  auto load_vec = [&](float (&v)[NS], int o) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) v[i] = ls[(o + i * SL) * LANES];
+#pragma unroll
+    for (int i = (NTB - 8) / SL; i < NS; i++) v[i] = (i * SL + sl) < nt ? v[i] : 0.f;
+  };
+  auto load_col = [&](float (&v)[NS], int col, int base, int nv) {
+    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+#pragma unroll
+    for (int i = 0; i < NS; i++) { const int k = i * SL + sl - base; const float x = lq.L(col + min(max(k, 0), nv - 1)); v[i] = (k >= 0 && k < nv) ? x : 0.f; }
+  };
+  // DoF j of the velocity change, known to every lane of the group
+  auto dv_at = [&](int j) { const float mine = dv[j >> LOG]; return group_sum((j & (SL - 1)) == sl ? mine : 0.f); };
+  struct Row { float J[NS], R[NS], b, acc, diag; };
+  struct Col { float R[NS], b, acc, diag, lim; int mo, j; };
+  auto load_row = [&](Row& r, int ro) { load_vec(r.J, ro); load_vec(r.R, ro + nt); r.b = lq.L(ro + 2 * nt); r.acc = lq.L(ro + 2 * nt + 1); r.diag = lq.L(ro + 2 * nt + 2); };
+  float maxres = 0.f; bool live = validq;
+  auto solve_row = [&](const Row& r, int ro, float lo, float hi) {
+    float jp = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) jp += r.J[i] * dv[i];
+    const float jv = group_sum(jp);
+    float delta = (r.b - jv) / r.diag;
+    const float nacc = fminf(fmaxf(r.acc + delta, lo), hi);
+    delta = live && r.diag > 1e-18f ? nacc - r.acc : 0.f;
+    lq.L(ro + 2 * nt + 1) = r.acc + delta;  // every lane of the group stores the same value
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += r.R[i] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  const LinkRows<LANES, true> rows(lq);
+  auto load_motor = [&](Col& r, int gl) {
+    int col, base, nv; rows.get(gl, col, r.mo, r.j, base, nv, r.lim);
+    load_col(r.R, col, base, nv); r.b = lq.L(r.mo + MR_B); r.acc = lq.L(r.mo + MR_ACC); r.diag = lq.L(col + r.j - base);
+  };
+  auto solve_motor = [&](const Col& r) {
+    float delta = (r.b - dv_at(r.j)) / r.diag;
+    const float nacc = fminf(fmaxf(r.acc + delta, -r.lim), r.lim);
+    delta = live ? nacc - r.acc : 0.f; lq.L(r.mo + MR_ACC) = r.acc + delta;
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += r.R[i] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  int iters_done = 0;
+  for (int it = 0; it < sc.iters; it++) {
+    maxres = 0.f;
+    {
+      Col A, B;
+      uint64_t m = rows.motors;
+      if (m) load_motor(A, __ffsll((long long)m) - 1);
+      while (m) {
+        m &= m - 1; if (m) load_motor(B, __ffsll((long long)m) - 1);
+        solve_motor(A);
+        if (!m) break;
+        m &= m - 1; if (m) load_motor(A, __ffsll((long long)m) - 1);
+        solve_motor(B);
+      }
+    }
+    prof.stamp(PS_PGS_MOTOR);
+    for (uint64_t m = limit_rows; m; m &= m - 1) {
+      const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1;
+      int col, mo, jg, base, nv; float lim_unused; rows.get(gl, col, mo, jg, base, nv, lim_unused);
+      const int jb = jg - base, bo = mo + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
+      float R[NS]; load_col(R, col, base, nv);
+      const float diag = lq.L(col + jb), acc = lq.L(bo + 1), bb = lq.L(bo); const bool act = acc >= 0.f;
+      float delta = (bb - sg * dv_at(base + jb)) / diag;
+      const float nacc = fmaxf(acc + delta, 0.f);
+      delta = (live && act) ? nacc - acc : 0.f; if (act) lq.L(bo + 1) = acc + delta;
+      const float sd = sg * delta;
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += R[i] * sd;
+      const float res = delta * diag; maxres = fmaxf(maxres, res * res);
+    }
+    prof.stamp(PS_PGS_LIMIT);
+    if (wave_max_cont > 0) {
+      Row A, B;
+      const int r0 = sc.tr_off;
+      if (0 < ncont) load_row(A, r0);
+      for (int c = 0; c < wave_max_cont; c += 2) {
+        if (c + 1 < ncont) load_row(B, r0 + 3 * (c + 1) * rs);
+        if (c < ncont) solve_row(A, r0 + 3 * c * rs, 0.f, 3.0e38f);
+        if (c + 2 < ncont) load_row(A, r0 + 3 * (c + 2) * rs);
+        if (c + 1 < ncont) solve_row(B, r0 + 3 * (c + 1) * rs, 0.f, 3.0e38f);
+      }
+      for (int c = 0; c < wave_max_cont; c++) {
+        const bool act = c < ncont && lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) > 0.f;
+        if (act) {
+          const float lim = lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) * lq.L(r0 + 3 * c * rs + 2 * nt + 1);
+          load_row(A, r0 + (3 * c + 1) * rs); load_row(B, r0 + (3 * c + 2) * rs);
+          solve_row(A, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(B, r0 + (3 * c + 2) * rs, -lim, lim);
+        }
+      }
+    }
+    prof.stamp(PS_PGS_CONTACT);
+    if (live) iters_done = it + 1;
+    live = live && !(maxres <= thr);
+    if (!__any(live)) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; i++) if (i * SL + sl < nt) ls[(sc.dv_base + i * SL) * LANES] = dv[i];
+  return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
+}
+
 // ---------------------------------------------------------------- substep
 // PAR: this wave is the MAIN wave of a two-wave workgroup; the helper wave (helper_substep below) owns body
 // sc.helper_body -- its kinematics and its register-resident dynamics run concurrently with everything here up to
 // the second barrier.  Both waves execute exactly three __syncthreads per substep.
-template <int LANES, bool PROF, bool PAR = false>
+// SLICED (16 / 32 envs per wavefront, step kernel only): all 64 lanes are alive; lanes >= LANES sit out everything
+// except the dense Gauss-Seidel loop, where they take a share of each env's rows (pgs_dense_sliced).
+// FULLWAVE: every lane of the wavefront is active at the call (step kernels of the 64-lane and global-workspace
+// modes; not the reset kernel, which runs the step under a per-env mask).
+template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
 DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc; const float h = sc.h; const int hb = PAR ? sc.helper_body : -1;
+  const bool primary = SLICED ? (int)threadIdx.x < LANES : true;
+  int ncont = 0, wave_max_cont = 0, iters_done = 0;
+  uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
+  uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int rs = crow_stride(sc.crow_tail);
+  if (primary) {
   for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
-  const int ncont = collide(ln);
+  ncont = collide(ln);
   prof.stamp(PS_COLLIDE);
   for (int b = 0; b < sc.nb; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
@@ -555,8 +723,6 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
-  uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
-  uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
   for (int gl = 0; gl < sc.nl; gl++) {
     const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
     const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
@@ -572,7 +738,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
   }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
-  const int wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
+  wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
     bool todo = has;
@@ -585,15 +751,27 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     }
   }
   prof.stamp(PS_ROWS);
+  }  // primary
   // ---- projected Gauss-Seidel
-  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int rs = crow_stride(sc.crow_tail);
-  bool live = ln.valid; int iters_done = 0;
   const bool all_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
+  if constexpr (SLICED) {  // wave-uniform results of the primary lanes, for every lane
+    wave_max_cont = __builtin_amdgcn_readfirstlane(wave_max_cont);
+    limit_rows = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(limit_rows >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)limit_rows);
+  }
+  if (SLICED && all_dense) {
+    if constexpr (SLICED) {
+      if (sc.nt <= 8) iters_done = pgs_dense_sliced<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      else if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      else if (sc.nt <= 24) iters_done = pgs_dense_sliced<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      else iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    }
+  } else if (primary) {
+  bool live = ln.valid;
   if (all_dense) {
-    if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else iters_done = pgs_dense<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else iters_done = pgs_dense<LANES, 32, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
   } else {
   // Register-resident rows: for up to NBR fixed-base bodies with <= RN joints (every 6-axis arm) M^-1, the
   // velocity change, the motor targets and the accumulated impulses are loaded once and the sweeps below touch
@@ -701,7 +879,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     }
   }
   }  // !all_dense
+  }  // unsliced
   prof.stamp(PS_PGS);
+  if (primary) {
   if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
   // ---- apply velocity changes and integrate positions
   const float vmax = sc.HF[DG_HF_MAX_COORD_VEL];
@@ -734,6 +914,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       ln.Sset(lo + DG_LS_QD, qd); ln.Sset(lo + DG_LS_Q, ln.S(lo + DG_LS_Q) + h * qd);
     }
   }
+  }  // primary
   if (PAR) __syncthreads();  // B3: positions integrated; the helper may start the next substep
 }
 
@@ -749,10 +930,11 @@ DGD void helper_substep(const Lane<LANES>& ln) {
   __syncthreads();  // B3
 }
 
-template <int LANES, bool PROF, bool PAR = false>
+template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
 DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
   const DevScene& sc = ln.sc;
-  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR>(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
+  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
+  if (SLICED && (int)threadIdx.x >= LANES) return;
   for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }

@@ -487,6 +487,26 @@ struct Lane {
 
   // ------------------------------------------------------------ solver rows
   // generalized velocity of body b dotted with a Jacobian stored at LDS offset jo (length nv)
+  // generalised velocity of body b (base twist in base coordinates, then joint rates) into LDS at vo
+  DGD void gen_vel_store(int b, int vo) const {
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF]; int k = 0;
+    if (!fixed(b)) {
+      M3 R0 = LR(plb(b)[PLB_R0]);
+      L3set(vo, tmul(R0, v3(S(so + DG_BS_ANGVEL), S(so + DG_BS_ANGVEL + 1), S(so + DG_BS_ANGVEL + 2))));
+      L3set(vo + 3, tmul(R0, v3(S(so + DG_BS_LINVEL), S(so + DG_BS_LINVEL + 1), S(so + DG_BS_LINVEL + 2)))); k = 6;
+    }
+    for (int i = 0; i < n; i++) L(vo + k + i) = S(li(first + i)[DG_LI_STATE_OFF] + DG_LS_QD);
+  }
+  // J . v with v stored by gen_vel_store
+  DGD float gen_vel_dot_lds(int jo, int vo, int nv) const {
+    float r = 0.f;
+    for (int c0 = 0; c0 < nv; c0 += 8) {
+      float x[8], y[8];
+      _Pragma("unroll") for (int t = 0; t < 8; t++) { x[t] = L(jo + c0 + t); y[t] = L(vo + c0 + t); }
+      _Pragma("unroll") for (int t = 0; t < 8; t++) r += (c0 + t < nv) ? x[t] * y[t] : 0.f;
+    }
+    return r;
+  }
   DGD float gen_vel_dot(int b, int jo) const {
     cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     float r = 0.f; int k = 0;
@@ -515,17 +535,29 @@ struct Lane {
       L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
     }
     (void)n;
-    // M^-1 is symmetric: row i is contiguous, so each response entry is one batched dot product (chunks of 8
-    // independent LDS reads; the <= 7 slots read past a vector are allocated and masked out)
-    float diag = 0.f;
-    for (int i = 0; i < nv; i++) {
-      float s = 0.f;
-      for (int c0 = 0; c0 < nv; c0 += 8) {
-        float x[8], y[8];
-        _Pragma("unroll") for (int j = 0; j < 8; j++) { x[j] = L(mo + i * nv + c0 + j); y[j] = L(jo + c0 + j); }
-        _Pragma("unroll") for (int j = 0; j < 8; j++) s += (c0 + j < nv) ? x[j] * y[j] : 0.f;
+    // Response M^-1 J^T, eight entries at a time: J is sparse (base + the chain above link gl) and M^-1 symmetric,
+    // so the response is a short sum of (contiguous) M^-1 rows scaled by the non-zero Jacobian entries.  Reads run
+    // <= 7 slots past a row; those are allocated and masked out at the store.
+    for (int c0 = 0; c0 < nv; c0 += 8) {
+      float acc[8];
+      _Pragma("unroll") for (int t = 0; t < 8; t++) acc[t] = 0.f;
+      if (!fixed(b)) {
+        float Jb[6], Mb[6][8];
+        _Pragma("unroll") for (int j = 0; j < 6; j++) { Jb[j] = L(jo + j); _Pragma("unroll") for (int t = 0; t < 8; t++) Mb[j][t] = L(mo + j * nv + c0 + t); }
+        _Pragma("unroll") for (int j = 0; j < 6; j++) _Pragma("unroll") for (int t = 0; t < 8; t++) acc[t] += Mb[j][t] * Jb[j];
       }
-      L(ro + i) = s; diag += s * L(jo + i);
+      for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) {
+        const int j = k0 + (k - first); const float Jj = L(jo + j); float Mr[8];
+        _Pragma("unroll") for (int t = 0; t < 8; t++) Mr[t] = L(mo + j * nv + c0 + t);
+        _Pragma("unroll") for (int t = 0; t < 8; t++) acc[t] += Mr[t] * Jj;
+      }
+      _Pragma("unroll") for (int t = 0; t < 8; t++) if (c0 + t < nv) L(ro + c0 + t) = acc[t];
+    }
+    float diag = 0.f;
+    for (int c0 = 0; c0 < nv; c0 += 8) {
+      float x[8], y[8];
+      _Pragma("unroll") for (int t = 0; t < 8; t++) { x[t] = L(ro + c0 + t); y[t] = L(jo + c0 + t); }
+      _Pragma("unroll") for (int t = 0; t < 8; t++) diag += (c0 + t < nv) ? x[t] * y[t] : 0.f;
     }
     return diag;
   }

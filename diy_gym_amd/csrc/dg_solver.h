@@ -205,7 +205,7 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
 
 // builds the three rows of contact slot c for the lanes whose contact belongs to (uniform) pair `pair`
 template <int LANES>
-DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
+DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, bool vel_in_lds) {
   const DevScene& sc = ln.sc; const int nvm = sc.nv_max, tl = sc.crow_tail, rs = crow_stride(tl);
   cip sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; cip sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
   const int ba = sa[DG_SI_BODY], la = sa[DG_SI_LINK], bb = sb[DG_SI_BODY], lb = sb[DG_SI_LINK];
@@ -226,11 +226,11 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine) {
     // per-body blocks [JA nv_max][RA nv_max]([JB][RB])
     const int g1 = sc.dense ? ln.plb(b1)[PLB_DV] - sc.dv_base : 0, g2 = sc.dense ? ln.plb(bb)[PLB_DV] - sc.dv_base : 0;
     const int j1 = ro + g1, r1 = ro + (sc.dense ? sc.nt : nvm) + g1;
-    diag += ln.point_row(b1, l1, p, d1, j1, r1); jv += ln.gen_vel_dot(b1, j1);
+    diag += ln.point_row(b1, l1, p, d1, j1, r1); jv += vel_in_lds ? ln.gen_vel_dot_lds(j1, ln.plb(b1)[PLB_DV], ln.plb(b1)[PLB_NV]) : ln.gen_vel_dot(b1, j1);
     ln.L(co + CL_DVA) = (float)ln.plb(b1)[PLB_DV]; ln.L(co + CL_NVA) = (float)ln.plb(b1)[PLB_NV];
     if (a_dyn && b_dyn) {
       const int j2 = sc.dense ? ro + g2 : ro + 2 * nvm, r2 = sc.dense ? ro + sc.nt + g2 : ro + 3 * nvm;
-      diag += ln.point_row(bb, lb, p, -dir, j2, r2); jv += ln.gen_vel_dot(bb, j2);
+      diag += ln.point_row(bb, lb, p, -dir, j2, r2); jv += vel_in_lds ? ln.gen_vel_dot_lds(j2, ln.plb(bb)[PLB_DV], ln.plb(bb)[PLB_NV]) : ln.gen_vel_dot(bb, j2);
       ln.L(co + CL_DVB) = (float)ln.plb(bb)[PLB_DV]; ln.L(co + CL_NVB) = (float)ln.plb(bb)[PLB_NV];
     } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
@@ -476,7 +476,7 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     float jv = 0.f;
 #pragma unroll
     for (int k = 0; k < NTB; k++) jv += r.J[k] * dv[k];
-    float delta = (r.b - jv) / r.diag;
+    float delta = fdiv(r.b - jv, r.diag);
     const float nacc = fminf(fmaxf(r.acc + delta, lo), hi);
     delta = live && r.diag > 1e-18f ? nacc - r.acc : 0.f;
     ln.L(ro + 2 * nt + 1) = r.acc + delta;
@@ -496,7 +496,7 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     load_col(r.R, col, base, nv); r.b = ln.L(r.mo + MR_B); r.acc = ln.L(r.mo + MR_ACC); r.diag = ln.L(col + r.j - base);
   };
   auto solve_motor = [&](const DenseCol<NTB>& r) {
-    float delta = (r.b - dv[r.j]) / r.diag;
+    float delta = fdiv(r.b - dv[r.j], r.diag);
     const float nacc = fminf(fmaxf(r.acc + delta, -r.lim), r.lim);
     delta = live ? nacc - r.acc : 0.f; ln.L(r.mo + MR_ACC) = r.acc + delta;
 #pragma unroll
@@ -527,7 +527,7 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
       const int jb = jg - base, bo = mo + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
       float R[NTB]; load_col(R, col, base, nv);
       const float diag = ln.L(col + jb), acc = ln.L(bo + 1), bb = ln.L(bo); const bool act = acc >= 0.f;
-      float delta = (bb - sg * dv[base + jb]) / diag;
+      float delta = fdiv(bb - sg * dv[base + jb], diag);
       const float nacc = fmaxf(acc + delta, 0.f);
       delta = (live && act) ? nacc - acc : 0.f; if (act) ln.L(bo + 1) = acc + delta;
       const float sd = sg * delta;
@@ -611,7 +611,7 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
 #pragma unroll
     for (int i = 0; i < NS; i++) jp += r.J[i] * dv[i];
     const float jv = group_sum(jp);
-    float delta = (r.b - jv) / r.diag;
+    float delta = fdiv(r.b - jv, r.diag);
     const float nacc = fminf(fmaxf(r.acc + delta, lo), hi);
     delta = live && r.diag > 1e-18f ? nacc - r.acc : 0.f;
     lq.L(ro + 2 * nt + 1) = r.acc + delta;  // every lane of the group stores the same value
@@ -625,7 +625,7 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
     load_col(r.R, col, base, nv); r.b = lq.L(r.mo + MR_B); r.acc = lq.L(r.mo + MR_ACC); r.diag = lq.L(col + r.j - base);
   };
   auto solve_motor = [&](const Col& r) {
-    float delta = (r.b - dv_at(r.j)) / r.diag;
+    float delta = fdiv(r.b - dv_at(r.j), r.diag);
     const float nacc = fminf(fmaxf(r.acc + delta, -r.lim), r.lim);
     delta = live ? nacc - r.acc : 0.f; lq.L(r.mo + MR_ACC) = r.acc + delta;
 #pragma unroll
@@ -654,7 +654,7 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
       const int jb = jg - base, bo = mo + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
       float R[NS]; load_col(R, col, base, nv);
       const float diag = lq.L(col + jb), acc = lq.L(bo + 1), bb = lq.L(bo); const bool act = acc >= 0.f;
-      float delta = (bb - sg * dv_at(base + jb)) / diag;
+      float delta = fdiv(bb - sg * dv_at(base + jb), diag);
       const float nacc = fmaxf(acc + delta, 0.f);
       delta = (live && act) ? nacc - acc : 0.f; if (act) lq.L(bo + 1) = acc + delta;
       const float sd = sg * delta;
@@ -738,7 +738,12 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
   }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
+  // all-dense scenes: the sweeps start from a zero velocity change held in registers, so until they finish the LDS
+  // velocity-change blocks are free -- park the generalised velocities there for the row right-hand sides
+  const bool vel_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
   wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
+  if (vel_dense && wave_max_cont > 0)
+    for (int b = 0; b < sc.nb; b++) if (!(ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) ln.gen_vel_store(b, ln.plb(b)[PLB_DV]);
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
     bool todo = has;
@@ -746,7 +751,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
       const int leader = __ffsll((long long)__ballot(todo)) - 1;
       const int pair = __shfl(mypair, leader);
       const bool mine = todo && mypair == pair;
-      build_contact_rows(ln, c, pair, mine);
+      build_contact_rows(ln, c, pair, mine, vel_dense);
       todo = todo && !mine;
     }
   }

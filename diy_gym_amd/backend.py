@@ -159,10 +159,15 @@ class HipBackend:
     SECTIONS = ['update_ops', 'kinematics', 'narrow_phase', 'aba', 'minv', 'rows', 'pgs_other', 'integrate', 'outputs', 'pgs_motor', 'pgs_limit',
                 'pgs_contact']
 
+    @property
+    def envs_per_wave(self):
+        """Envs per wavefront of the workspace mode (``lanes``: 64/32/16 LDS modes, 0 and -16 global-workspace modes)."""
+        return self.lanes if self.lanes > 0 else (-self.lanes if self.lanes < 0 else 64)
+
     def enable_stamps(self, on=True):
         """Diagnostic: per-wavefront shader cycles per section of the step (see diygym_hip.h)."""
         if on:
-            n_waves = (self.num_envs + self.lanes - 1) // self.lanes
+            n_waves = (self.num_envs + self.envs_per_wave - 1) // self.envs_per_wave
             self.cycles = torch.zeros((n_waves, len(self.SECTIONS)), dtype=torch.int64, device=self.device)
             self._check(self.lib.dg_world_set_profile_buffer(self.handle, _ptr(self.cycles)))
         else:

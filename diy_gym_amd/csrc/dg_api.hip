@@ -18,8 +18,8 @@
 using namespace dg;
 
 namespace dg {
-extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_0;
-const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : g_launch_table_0; }
+extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_0, g_launch_table_g16;
+const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : lanes == -16 ? g_launch_table_g16 : g_launch_table_0; }
 }  // namespace dg
 
 static thread_local std::string g_err;
@@ -122,12 +122,20 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16) lanes = v; }
   while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
   if (lanes < 16) {
-    // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer [slot][env_stride]
-    // (coalesced, L2-resident); same kernels, Lane<0>
+    // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer
+    // [workgroup][slot][lane] (coalesced, L2-resident); same kernels, Lane<0>
     lanes = 0;
-    HIP_TRY(hipMalloc((void**)&w->d_gws, sizeof(float) * (size_t)total * (size_t)env_stride));
+    // all-dense scenes (every row indexed by global DoF, no register-chain bodies) run 16 envs per wavefront
+    // instead, so that the other 48 lanes can share each env's solver rows; LDS then only holds the
+    // accumulated impulses of those rows
+    bool has_reg = false;
+    for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) has_reg = true; }
+    const int acc_rows = 3 * maxc + 3 * nl;
+    if (dense && nt >= 1 && !has_reg && acc_rows * 16 * 4 <= 64 * 1024 && !getenv("DG_NO_SLICED_GLOBAL")) lanes = -16;
+    { const int per = envs_per_wave(lanes); const size_t blocks = ((size_t)num_envs + per - 1) / per;  // [workgroup][slot][lane]
+      HIP_TRY(hipMalloc((void**)&w->d_gws, sizeof(float) * blocks * (size_t)total * (size_t)per)); }
   }
-  w->lanes = lanes; w->lds_bytes = total * lanes * 4;
+  w->lanes = lanes; w->lds_bytes = lanes > 0 ? total * lanes * 4 : (lanes < 0 ? (3 * maxc + 3 * nl) * 16 * 4 : 0);
   // ---- device tables (floats converted once)
   std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
   // device copy of the int tables, with device-only hints: IK ops on serial chains of <= 6 joints take the
@@ -237,7 +245,7 @@ int32_t dg_world_init_state(dg_world* w, float* state, void* stream) {
   return DG_OK;
 }
 
-static dim3 grid_of(const dg_world* w) { const int per = w->lanes > 0 ? w->lanes : 64; return dim3((w->num_envs + per - 1) / per); }
+static dim3 grid_of(const dg_world* w) { const int per = envs_per_wave(w->lanes); return dim3((w->num_envs + per - 1) / per); }
 
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");

@@ -11,14 +11,13 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
                                                    float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
                                                    unsigned long long* cycles, float* gws) {
   extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  constexpr int ACTIVE = envs_per_wave(LANES);
   // 16 / 32 envs per wavefront: the spare lanes stay alive and join the dense Gauss-Seidel sweeps (pgs_dense_sliced)
-  constexpr bool SLICED = LANES == 16 || LANES == 32;
+  constexpr bool SLICED = LANES == 16 || LANES == 32 || LANES == -16;
   const int lane = threadIdx.x; if (!SLICED && lane >= ACTIVE) return;
   const bool primary = lane < ACTIVE;
   const int env = blockIdx.x * ACTIVE + lane; const bool valid = primary && env < sc.num_envs; const int e = env < sc.num_envs ? env : sc.num_envs - 1;
-  // lanes past the batch use their own (padded) scratch column, never another env's
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, valid);
   Prof<PROF> prof; prof.start();
   if (primary) {
     for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
@@ -27,7 +26,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
     ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
     prof.stamp(PS_UPDATE);
   }
-  sim_step<LANES, PROF, false, SLICED, LANES == 64 || LANES == 0>(ln, diag, prof);
+  sim_step<LANES, PROF, false, SLICED, LANES == 64 || LANES == 0>(ln, diag, prof, smem, gws);
   if (!primary) return;
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   prof.stamp(PS_KIN);
@@ -79,11 +78,10 @@ __global__ __launch_bounds__(128) void step_kernel_par(DevScene sc, MotorTable m
 template <int LANES>
 __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws) {
   extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  constexpr int ACTIVE = envs_per_wave(LANES);
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  // lanes past the batch use their own (padded) scratch column, never another env's
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, valid);
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, valid);
   const bool doit = valid && (mask == nullptr || mask[e] != 0);
   if (doit) {
     ln.Sset(DG_ST_STEP, 0.0f);
@@ -101,10 +99,10 @@ template <int LANES>
 __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term,
                                                       float* rew_sum, uint8_t* term_flag, float* gws) {
   extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  constexpr int ACTIVE = envs_per_wave(LANES);
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + (env < sc.stride ? env : e), state + e, e, false);  // never stores state
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, false);  // never stores state
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
@@ -114,10 +112,10 @@ __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt,
 template <int LANES>
 __global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws) {
   extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  constexpr int ACTIVE = envs_per_wave(LANES);
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + env, state + env, env, false);
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + env, env, false);
   ln.kinematics(body);
   V3 p, v, w; Q4 q; ln.frame_state(body, frame, com != 0, p, q, v, w, true);
   float* o = out + (size_t)env * 13;

@@ -2,18 +2,22 @@
 //   -DDG_LANES={64,32,16,0}  -DDG_PART=0  step kernels (+ stamped build for 64 and 16)
 //                            -DDG_PART=1  reset / observe / frame / pose kernels and the mode's launch table
 //   -DDG_LANES=64            -DDG_PART=2  helper-wave step kernels
+//   -DDG_LANES=-16 -DDG_TAG=g16           the global-workspace mode with 16 envs per wavefront
 #include <hip/hip_runtime.h>
 #include "dg_launch.h"
 #include "dg_entry.h"
 
 #define DG_CAT_(a, b) a##b
 #define DG_CAT(a, b) DG_CAT_(a, b)
-#define DGL(name) DG_CAT(DG_CAT(name, _), DG_LANES)
+#ifndef DG_TAG
+#define DG_TAG DG_LANES
+#endif
+#define DGL(name) DG_CAT(DG_CAT(name, _), DG_TAG)
 
 namespace dg {
 
 constexpr int L = DG_LANES;
-constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 16);
+constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 16 || DG_LANES == -16);
 
 void DGL(l_step)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, float* gws);
 hipError_t DGL(l_prepare_step)(int lds);
@@ -57,6 +61,9 @@ static void l_pose(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable m
 }
 static hipError_t l_prepare(int lds) {
   if (L == 0) return hipSuccess;
+  if (L < 0) {  // only the step kernel uses LDS (the sliced sweeps' accumulated impulses)
+    return DGL(l_prepare_step)(lds);
+  }
   hipError_t e = DGL(l_prepare_step)(lds);
 #define DG_ATTR(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
   DG_ATTR(reset_kernel<L>); DG_ATTR(observe_kernel<L>); DG_ATTR(frame_kernel<L>); DG_ATTR(pose_kernel<L>);

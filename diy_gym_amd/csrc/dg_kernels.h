@@ -68,19 +68,33 @@ enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_DVA = 8, CL_NVA = 9, CL_
 // motor / limit row block per link: b_motor acc_motor b_lo acc_lo b_hi acc_hi
 enum { MR_B = 0, MR_ACC, MR_LO_B, MR_LO_ACC, MR_HI_B, MR_HI_ACC, MR_STRIDE };
 
+// Workspace modes (the LANES template argument everywhere):
+//   64 / 32 / 16  that many envs per wavefront, per-env scratch in LDS as ws[slot][lane]
+//   0             64 envs per wavefront, scratch in a global buffer [workgroup][slot][lane] (scene too big for LDS)
+//   -16           16 envs per wavefront, global scratch; the 48 spare lanes join the dense Gauss-Seidel sweeps
+constexpr int envs_per_wave(int lanes) { return lanes > 0 ? lanes : (lanes < 0 ? -lanes : 64); }
+
+// this lane's workspace column: LDS, or its workgroup's block of the global scratch buffer
+template <int LANES>
+DGD float* workspace_of(const DevScene& sc, float* smem, float* gws, int lane) {
+  if constexpr (LANES > 0) return smem + lane;
+  else return gws + (size_t)blockIdx.x * (size_t)sc.total_slots * envs_per_wave(LANES) + lane;
+}
+
 template <int LANES>
 struct Lane {
   const DevScene& sc;
   const MotorTable& mt;
-  float* lds;   // workspace base for this lane (already offset by lane): LDS, or -- LANES == 0 -- a per-env
-                // column of a global scratch buffer [slot][env_stride] for scenes too big for 160 KiB of LDS
+  float* lds;   // workspace base for this lane (already offset by workgroup and lane): LDS, or -- LANES <= 0 -- this
+                // workgroup's block of a global scratch buffer [workgroup][slot][lane] for scenes too big for 160 KiB of LDS
   float* st;    // state base for this env (already offset by env)
   int env;      // clamped env index
   bool valid;   // this lane owns a real env (stores allowed)
 
   DGD Lane(const DevScene& s, const MotorTable& m, float* l, float* state, int e, bool v) : sc(s), mt(m), lds(l), st(state), env(e), valid(v) {}
 
-  DGD float& L(int slot) const { if constexpr (LANES > 0) return lds[slot * LANES]; else return lds[(size_t)slot * sc.stride]; }
+  // every mode: consecutive slots are envs_per_wave floats apart (LDS: ws[slot][lane]; global: [workgroup][slot][lane])
+  DGD float& L(int slot) const { return lds[slot * envs_per_wave(LANES)]; }
   DGD float S(int k) const { return st[(size_t)k * sc.stride]; }
   DGD void Sset(int k, float v) const { if (valid) st[(size_t)k * sc.stride] = v; }
 

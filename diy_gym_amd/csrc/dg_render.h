@@ -19,10 +19,10 @@ enum { RS_R = 0, RS_P = 9, RS_C = 12, RS_BOUND = 15, RS_STRIDE = 16, RC_STRIDE =
 template <int LANES>
 __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws) {
   extern __shared__ float smem[];
-  constexpr int ACTIVE = LANES > 0 ? LANES : 64;
+  constexpr int ACTIVE = envs_per_wave(LANES);
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
-  Lane<LANES> ln(sc, mt, LANES > 0 ? smem + lane : gws + env, state + env, env, false);
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + env, env, false);
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   float* out = table + (size_t)env * (sc.nsh * RS_STRIDE + ncam * RC_STRIDE);
   for (int sh = 0; sh < sc.nsh; sh++) {

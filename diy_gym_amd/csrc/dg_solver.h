@@ -635,16 +635,17 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
-    {
-      Col A, B;
-      uint64_t m = rows.motors;
-      if (m) load_motor(A, __ffsll((long long)m) - 1);
-      while (m) {
-        m &= m - 1; if (m) load_motor(B, __ffsll((long long)m) - 1);
+    if (rows.motors) {  // loads are unconditional (a row past the end re-reads the last one) so that the
+      Col A, B;         // compiler can count the loads in flight instead of draining them at every branch
+      uint64_t m = rows.motors; int g = __ffsll((long long)m) - 1;
+      load_motor(A, g);
+      while (true) {
+        m &= m - 1; const bool more1 = m != 0; g = more1 ? __ffsll((long long)m) - 1 : g; load_motor(B, g);
         solve_motor(A);
-        if (!m) break;
-        m &= m - 1; if (m) load_motor(A, __ffsll((long long)m) - 1);
+        if (!more1) break;
+        m &= m - 1; const bool more2 = m != 0; g = more2 ? __ffsll((long long)m) - 1 : g; load_motor(A, g);
         solve_motor(B);
+        if (!more2) break;
       }
     }
     prof.stamp(PS_PGS_MOTOR);
@@ -666,11 +667,12 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
     if (wave_max_cont > 0) {
       Row A, B;
       const int r0 = sc.tr_off;
-      if (0 < ncont) load_row(A, r0);
+      const int cl = wave_max_cont - 1;  // loads are unconditional: past the end they re-read the last row
+      load_row(A, r0);
       for (int c = 0; c < wave_max_cont; c += 2) {
-        if (c + 1 < ncont) load_row(B, r0 + 3 * (c + 1) * rs);
+        load_row(B, r0 + 3 * min(c + 1, cl) * rs);
         if (c < ncont) solve_row(A, r0 + 3 * c * rs, 0.f, 3.0e38f);
-        if (c + 2 < ncont) load_row(A, r0 + 3 * (c + 2) * rs);
+        load_row(A, r0 + 3 * min(c + 2, cl) * rs);
         if (c + 1 < ncont) solve_row(B, r0 + 3 * (c + 1) * rs, 0.f, 3.0e38f);
       }
       for (int c = 0; c < wave_max_cont; c++) {
@@ -692,6 +694,163 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
   return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
 }
 
+// ---- sliced sweeps for the global-workspace mode (LANES == -16) ---------------------------------------------------
+// Rows stream from the L2-resident scratch buffer, whose latency is ~10x that of LDS: loads run D rows ahead of the
+// solves, which requires the loop to be free of global stores (vmcnt orders loads behind them) -- so the accumulated
+// impulses, the only thing a sweep writes, live in LDS: acc[row id][env of the group].  Row ids: contact (c, d) ->
+// 3 c + d, motor of link gl -> 3 maxc + gl, limit (gl, side) -> 3 maxc + nl + 2 gl + side.
+template <int LANES, int NTB, bool PROF>
+DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, int ncont_primary, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
+  static_assert(LANES == -16, "global-workspace sliced sweeps run 16 envs per wavefront");
+  constexpr int EPW = 16, SL = 4, LOG = 2, NS = NTB / SL, D = 4;
+  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3, maxc = sc.max_contacts; const float h = sc.h;
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; constexpr unsigned W = EPW;  // slot stride of the [workgroup][slot][lane] workspace
+  const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
+  const int envq = blockIdx.x * EPW + q; const bool validq = envq < sc.num_envs; const int eq = validq ? envq : sc.num_envs - 1;
+  // Workspace addressing: raw buffer loads -- resource (this workgroup's block) in SGPRs, uniform slot offset in the
+  // scalar offset operand, per-lane byte offset in one VGPR: no per-load address arithmetic on the vector ALU.
+  float* const blk = gws + (size_t)blockIdx.x * (size_t)sc.total_slots * EPW;  // this workgroup's block (uniform)
+  const unsigned colq = (unsigned)q;                                // env q's column inside the block
+  const unsigned lane_off = ((unsigned)sl * W + colq) * 4u;         // byte offset of this lane's slice of env q's vectors
+  const unsigned col_off = colq * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(blk, 0, (int)((unsigned)sc.total_slots * W * 4u), 0x00020000);
+  auto BL = [&](unsigned voff, int slot) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (unsigned)slot * W * 4u, 0)); };
+  auto G = [&](int slot) -> float { return BL(col_off, slot); };
+  const Lane<LANES> lq(sc, ln.mt, ln.lds, ln.st - ln.env + eq, eq, validq);  // tables only
+  const int ncont = __shfl(ncont_primary, q);
+  float* const acc = accl + q;  // acc[id * EPW]
+  const int n_acc = 3 * maxc + 3 * sc.nl;
+  for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = 0.f;
+  float dv[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) dv[i] = 0.f;
+  auto load_vec = [&](float (&v)[NS], int o) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) v[i] = BL(lane_off + (unsigned)(i * SL) * W * 4u, o);  // constant part folds into the instruction offset
+#pragma unroll
+    for (int i = (NTB - 8) / SL; i < NS; i++) v[i] = (i * SL + sl) < nt ? v[i] : 0.f;
+  };
+  auto load_col = [&](float (&v)[NS], int col, int base, int nv) {
+    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+#pragma unroll
+    for (int i = 0; i < NS; i++) {  // general case: the body's DoFs are [base, base + nv) of the global vector
+      const int k = i * SL + sl - base; const unsigned kc = (unsigned)min(max(k, 0), nv - 1);
+      const float x = BL((kc * W + colq) * 4u, col); v[i] = (k >= 0 && k < nv) ? x : 0.f;
+    }
+  };
+  auto dv_at = [&](int j) { const float mine = dv[j >> LOG]; return group_sum4((j & (SL - 1)) == sl ? mine : 0.f); };
+  struct Row { float J[NS], R[NS], b, diag, mu, acc, nacc; };
+  struct Col { float R[NS], b, diag, lim, acc; int id, j; };
+  auto load_row = [&](Row& r, int ro, int co, int id) { r.acc = acc[id * EPW]; r.nacc = acc[(id - id % 3) * EPW] /* its contact's normal impulse */; load_vec(r.J, ro); load_vec(r.R, ro + nt); r.b = G(ro + 2 * nt); r.diag = G(ro + 2 * nt + 2); r.mu = G(co + CL_MU); };
+  float maxres = 0.f; bool live = validq;
+  auto solve_row = [&](const Row& r, int id, float lo, float hi) {
+    float jp = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) jp += r.J[i] * dv[i];
+    const float jv = group_sum4(jp), a0 = r.acc;
+    float delta = fdiv(r.b - jv, r.diag);
+    const float nacc = fminf(fmaxf(a0 + delta, lo), hi);
+    delta = live && r.diag > 1e-18f ? nacc - a0 : 0.f;
+    acc[id * EPW] = a0 + delta;  // every lane of the group stores the same value
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += r.R[i] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  const LinkRows<LANES, true> rows(lq);
+  auto load_motor = [&](Col& r, int gl) {
+    int col, base, nv, mo; rows.get(gl, col, mo, r.j, base, nv, r.lim); r.id = 3 * maxc + gl;
+    r.acc = acc[r.id * EPW]; load_col(r.R, col, base, nv); r.b = G(mo + MR_B); r.diag = G(col + r.j - base);
+  };
+  auto solve_motor = [&](const Col& r) {
+    const float a0 = r.acc;
+    float delta = fdiv(r.b - dv_at(r.j), r.diag);
+    const float nacc = fminf(fmaxf(a0 + delta, -r.lim), r.lim);
+    delta = live ? nacc - a0 : 0.f; acc[r.id * EPW] = a0 + delta;
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += r.R[i] * delta;
+    const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
+  };
+  const int r0 = sc.tr_off, c0 = sc.cont_off + 1;
+  int iters_done = 0;
+  for (int it = 0; it < sc.iters; it++) {
+    maxres = 0.f;
+    if (rows.motors) {  // loads are unconditional (a row past the end re-reads the last one) so that the
+      Col A, B;         // compiler can count the loads in flight instead of draining them at every branch
+      uint64_t m = rows.motors; int g = __ffsll((long long)m) - 1;
+      load_motor(A, g);
+      while (true) {
+        m &= m - 1; const bool more1 = m != 0; g = more1 ? __ffsll((long long)m) - 1 : g; load_motor(B, g);
+        solve_motor(A);
+        if (!more1) break;
+        m &= m - 1; const bool more2 = m != 0; g = more2 ? __ffsll((long long)m) - 1 : g; load_motor(A, g);
+        solve_motor(B);
+        if (!more2) break;
+      }
+    }
+    prof.stamp(PS_PGS_MOTOR);
+    for (uint64_t m = limit_rows; m; m &= m - 1) {
+      const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1, id = 3 * maxc + sc.nl + bit;
+      int col, mo, jg, base, nv; float lim_unused; rows.get(gl, col, mo, jg, base, nv, lim_unused);
+      const int jb = jg - base, bo = mo + (side == 0 ? MR_LO_B : MR_HI_B); const float sg = side == 0 ? 1.f : -1.f;
+      float R[NS]; load_col(R, col, base, nv);
+      const float diag = G(col + jb), bb = G(bo); const bool act = G(bo + 1) >= 0.f;  // the flag is not rewritten here
+      const float a0 = acc[id * EPW];
+      float delta = fdiv(bb - sg * dv_at(base + jb), diag);
+      const float nacc = fmaxf(a0 + delta, 0.f);
+      delta = (live && act) ? nacc - a0 : 0.f; acc[id * EPW] = a0 + delta;
+      const float sd = sg * delta;
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += R[i] * sd;
+      const float res = delta * diag; maxres = fmaxf(maxres, res * res);
+    }
+    prof.stamp(PS_PGS_LIMIT);
+    if (wave_max_cont > 0) {
+      Row buf[D];
+      {  // normals: row t = contact t
+        const int n = wave_max_cont;
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) { const int tc = min(d, n - 1); load_row(buf[d], r0 + 3 * tc * rs, c0 + tc * CL_STRIDE, 3 * tc); }
+        for (int t0 = 0; t0 < n; t0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            const int t = t0 + d, tp = t + D - 1;
+            { const int tc = min(tp, n - 1); load_row(buf[(d + D - 1) % D], r0 + 3 * tc * rs, c0 + tc * CL_STRIDE, 3 * tc); }
+            if (t < n && t < ncont) solve_row(buf[d], 3 * t, 0.f, 3.0e38f);
+          }
+        }
+      }
+      {  // friction: row t = (contact t / 2, direction 1 + t % 2)
+        const int n = 2 * wave_max_cont;
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) { const int tc = min(d, n - 1); load_row(buf[d], r0 + (3 * (tc >> 1) + 1 + (tc & 1)) * rs, c0 + (tc >> 1) * CL_STRIDE, 3 * (tc >> 1) + 1 + (tc & 1)); }
+        for (int t0 = 0; t0 < n; t0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            const int t = t0 + d, tp = t + D - 1;
+            { const int tc = min(tp, n - 1); load_row(buf[(d + D - 1) % D], r0 + (3 * (tc >> 1) + 1 + (tc & 1)) * rs, c0 + (tc >> 1) * CL_STRIDE, 3 * (tc >> 1) + 1 + (tc & 1)); }
+            if (t < n && (t >> 1) < ncont) {
+              const float mu = buf[d].mu;
+              if (mu > 0.f) { const float lim = mu * buf[d].nacc; solve_row(buf[d], 3 * (t >> 1) + 1 + (t & 1), -lim, lim); }
+            }
+          }
+        }
+      }
+    }
+    prof.stamp(PS_PGS_CONTACT);
+    if (live) iters_done = it + 1;
+    live = live && !(maxres <= thr);
+    if (!__any(live)) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; i++) if (i * SL + sl < nt) blk[(unsigned)(sc.dv_base + i * SL) * W + (lane_off >> 2)] = dv[i];  // lane_off is in bytes
+  // motor impulses feed the applied-torque readout
+  for (uint64_t m = rows.motors; m; m &= m - 1) {
+    const int gl = __ffsll((long long)m) - 1; int col, mo, jg, base, nv; float lm; rows.get(gl, col, mo, jg, base, nv, lm);
+    blk[(unsigned)(mo + MR_ACC) * W + colq] = acc[(3 * maxc + gl) * EPW];
+  }
+  return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
+}
+
 // ---------------------------------------------------------------- substep
 // PAR: this wave is the MAIN wave of a two-wave workgroup; the helper wave (helper_substep below) owns body
 // sc.helper_body -- its kinematics and its register-resident dynamics run concurrently with everything here up to
@@ -701,9 +860,9 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
 // FULLWAVE: every lane of the wavefront is active at the call (step kernels of the 64-lane and global-workspace
 // modes; not the reset kernel, which runs the step under a per-env mask).
 template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
-DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
+DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr) {
   const DevScene& sc = ln.sc; const float h = sc.h; const int hb = PAR ? sc.helper_body : -1;
-  const bool primary = SLICED ? (int)threadIdx.x < LANES : true;
+  const bool primary = SLICED ? (int)threadIdx.x < envs_per_wave(LANES) : true;
   int ncont = 0, wave_max_cont = 0, iters_done = 0;
   uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
   uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
@@ -764,11 +923,16 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
     limit_rows = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(limit_rows >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)limit_rows);
   }
   if (SLICED && all_dense) {
-    if constexpr (SLICED) {
+    if constexpr (SLICED && LANES > 0) {
       if (sc.nt <= 8) iters_done = pgs_dense_sliced<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else if (sc.nt <= 24) iters_done = pgs_dense_sliced<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    } else if constexpr (SLICED) {
+      if (sc.nt <= 8) iters_done = pgs_dense_sliced_global<LANES, 8, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
+      else if (sc.nt <= 16) iters_done = pgs_dense_sliced_global<LANES, 16, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
+      else if (sc.nt <= 24) iters_done = pgs_dense_sliced_global<LANES, 24, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
+      else iters_done = pgs_dense_sliced_global<LANES, 32, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
     }
   } else if (primary) {
   bool live = ln.valid;
@@ -936,10 +1100,10 @@ DGD void helper_substep(const Lane<LANES>& ln) {
 }
 
 template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
-DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof) {
+DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr) {
   const DevScene& sc = ln.sc;
-  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof); prof.stamp(PS_INTEGRATE); }
-  if (SLICED && (int)threadIdx.x >= LANES) return;
+  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof, smem, gws); prof.stamp(PS_INTEGRATE); }
+  if (SLICED && (int)threadIdx.x >= envs_per_wave(LANES)) return;
   for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }

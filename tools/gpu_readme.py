@@ -16,6 +16,9 @@ def t(fn, n=5):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
 print('step   %.2f ms' % t(lambda: env.sim.step(env._all_slots, act)))
+settle = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for _ in range(settle): env.sim.step(env._all_slots, act * 0.2)
+if settle: print('step after %d settling steps  %.2f ms' % (settle, t(lambda: env.sim.step(env._all_slots, act * 0.2))))
 def render():
     env._tick += 1; cam.observe()
 ms = t(render, 10)

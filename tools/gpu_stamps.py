@@ -12,7 +12,7 @@ env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0')
 lo, hi = T.action_bounds(env)
 gen = torch.Generator().manual_seed(1)
 ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0') for _ in range(8)]
-for i in range(10): env.sim.step(env._all_slots, ring[i % 8])
+for i in range(int(os.environ.get("SETTLE", "10"))): env.sim.step(env._all_slots, ring[i % 8] * float(os.environ.get("ACT_SCALE", "1")))
 cyc = env.sim.enable_stamps()
 tot = torch.zeros(len(env.sim.SECTIONS), dtype=torch.float64)
 scale = float(os.environ.get('ACT_SCALE', '1'))
@@ -31,6 +31,6 @@ d = env.sim.enable_diagnostics()
 for i in range(4): env.sim.step(env._all_slots, ring[i % 8])
 torch.cuda.synchronize()
 it = d[:, 1].float()
-wave_max = it.reshape(-1, env.sim.lanes).max(1).values
+wave_max = it.reshape(-1, env.sim.envs_per_wave).max(1).values
 print('PGS iterations (last substep): mean %.1f  p50 %.0f  p99 %.0f  max %.0f | per-wave max: mean %.1f max %.0f | contacts max %d' % (
     it.mean(), it.median(), it.quantile(0.99), it.max(), wave_max.mean(), wave_max.max(), int(d[:, 0].max())))

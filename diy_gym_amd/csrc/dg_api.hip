@@ -66,6 +66,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   const int32_t* BI = I + I[DG_H_OFF_BODY_I]; const int32_t* LI = I + I[DG_H_OFF_LINK_I]; const int32_t* OI = I + I[DG_H_OFF_OP_I];
   // ---- LDS plan (slots per lane)
   std::vector<int32_t> plan((size_t)nb * PLB_STRIDE + (size_t)nl * PLL_STRIDE);
+  plan.reserve(plan.size() + (size_t)I[DG_H_N_PAIRS] + 1);  // pair descriptors are appended below; PLB / PLL must stay valid
   int32_t* PLB = plan.data(); int32_t* PLL = plan.data() + (size_t)nb * PLB_STRIDE;
   int slot = 0, nvmax = 0, nmax = 0; bool any_float = false;
   for (int b = 0; b < nb; b++) {
@@ -151,6 +152,17 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   }
   HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, Idev.data(), sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_blob_f, sizeof(float) * (size_t)n_f)); HIP_TRY(hipMemcpy(w->d_blob_f, Ff.data(), sizeof(float) * (size_t)n_f, hipMemcpyHostToDevice));
+  // pair descriptors in canonical order (lower shape type first, a box always second), one word per pair
+  const size_t pd_off = plan.size();
+  { const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
+    if (I[DG_H_N_SHAPES] > 4096) return fail(DG_ERR_UNSUPPORTED, "%d shapes > 4096 supported", I[DG_H_N_SHAPES]);
+    for (int p = 0; p < I[DG_H_N_PAIRS]; p++) {
+      const int sA = PIh[p * DG_PI_STRIDE + DG_PI_A], sB = PIh[p * DG_PI_STRIDE + DG_PI_B];
+      const int tA = SIh[sA * DG_SI_STRIDE + DG_SI_TYPE], tB = SIh[sB * DG_SI_STRIDE + DG_SI_TYPE];
+      const bool swap = tA == DG_SHAPE_BOX || (tB != DG_SHAPE_BOX && tA > tB);
+      const int sa = swap ? sB : sA, sb = swap ? sA : sB, ta = swap ? tB : tA, tb = swap ? tA : tB;
+      plan.push_back(sa | (sb << 12) | (ta << 24) | (tb << 26) | ((swap ? 1 : 0) << 28));
+    } }
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
   // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
   cip dI = (cip)w->d_blob_i; cfp dF = (cfp)w->d_blob_f;
@@ -159,7 +171,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.GI = dI + I[DG_H_OFF_GROUP_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
-  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE;
+  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off;
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
@@ -188,6 +200,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     }
   }
   w->par = sc.helper_body >= 0;
+  // third wavefront for the narrow phase: it uses the transient region as its shape cache while the other two run
+  // dynamics, so every moving body must have the register-resident (transient-free) dynamics
+  sc.coll_wave = 0;
+  if (w->par && I[DG_H_N_PAIRS] > 0 && !getenv("DG_NO_COLLIDE_WAVE")) {
+    bool ok = true;
+    for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; const bool stat = (B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0; if (!stat && !PLB[b * PLB_STRIDE + PLB_CHAIN]) ok = false; }
+    sc.coll_wave = ok ? 1 : 0;
+  }
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);

@@ -41,6 +41,8 @@ struct DevScene {
   cip BI, LI, FI, SI, PI, GI, OI, IL;
   cfp BF, LF, FF, SF, PF, OF, FL, HF;
   cip PLB;  // per body: [R0_off, minv_off, dv_off, nv]
+  int coll_wave;  // helper-wave step kernel: a third wavefront runs the narrow phase (every moving body has register-resident dynamics)
+  cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;

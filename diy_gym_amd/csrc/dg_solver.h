@@ -102,9 +102,14 @@ DGD void emit_contact(const Lane<LANES>& ln, int& cnt, int pair, const Hit& h, f
 // world-space segment + radius, cached in the transient LDS region (free until the dynamics pass):
 //   [e0 3][e1 3][r][bounding radius] per shape.  Pairs whose bounding spheres are apart in every lane of the
 // wave are skipped with one wave-uniform branch.
-enum { SC_E0 = 0, SC_E1 = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
+// narrow-phase cache per round shape: segment centre, half-axis (end points = centre -/+ half), radius, bounding radius
+enum { SC_C = 0, SC_H = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
 
-template <int LANES>
+// TBL > 0: at least the first TBL lanes of the wavefront are active at the call (step kernels: 64, or the envs per
+// wavefront of the sliced modes) -- pair descriptors are then fetched TBL at a time with one vector load and read
+// back with v_readlane, instead of a chain of dependent scalar loads per pair.  TBL == 0 (reset kernel, which runs
+// under a per-env mask): one scalar load per pair.
+template <int LANES, int TBL>
 DGD int collide(const Lane<LANES>& ln) {
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
   if (sc.npairs == 0) { ln.L(sc.cont_off) = 0.f; return 0; }
@@ -113,11 +118,12 @@ DGD int collide(const Lane<LANES>& ln) {
     WShape w; shape_world(ln, sh, w); V3 e0 = w.p, e1 = w.p;
     if (type != DG_SHAPE_SPHERE) seg_ends(w, e0, e1);
     const int o = sc.tr_off + sh * SC_STRIDE;
-    ln.L3set(o + SC_E0, e0); ln.L3set(o + SC_E1, e1); ln.L(o + SC_R) = w.prm0; ln.L(o + SC_BOUND) = w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
+    ln.L3set(o + SC_C, (e0 + e1) * 0.5f); ln.L3set(o + SC_H, (e1 - e0) * 0.5f); ln.L(o + SC_R) = w.prm0; ln.L(o + SC_BOUND) = w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
   }
   // broad phase: a group = all pairs between one moving body and one shape of the static world (or another
   // moving body); skipped as a whole when the bounding spheres are apart in every lane of the wave
   int cached_body = -1; V3 cpos = v3(0.f, 0.f, 0.f);
+  const int lane = threadIdx.x & 63;
   for (int g = 0; g < sc.ngroups; g++) {
     cip gi = sc.GI + g * DG_GI_STRIDE; const int ba = gi[DG_GI_BODY_A], bb = gi[DG_GI_BODY_B], ss = gi[DG_GI_STATIC_SHAPE];
     if (ba != cached_body) { cpos = ln.base_pos(ba); cached_body = ba; }
@@ -129,29 +135,37 @@ DGD int collide(const Lane<LANES>& ln) {
       else { WShape w; shape_world(ln, ss, w); other = w.p; }
     } else { other = ln.base_pos(bb); reach += sc.BF[bb * DG_BF_STRIDE + DG_BF_BOUND]; }
     { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
-  for (int pi = gi[DG_GI_FIRST]; pi < gi[DG_GI_FIRST] + gi[DG_GI_COUNT]; pi++) {
-    const int sA = sc.PI[pi * DG_PI_STRIDE + DG_PI_A], sB = sc.PI[pi * DG_PI_STRIDE + DG_PI_B];
-    const int tA = sc.SI[sA * DG_SI_STRIDE + DG_SI_TYPE], tB = sc.SI[sB * DG_SI_STRIDE + DG_SI_TYPE];
-    // canonical order (uniform): lower type first, a box always second.  Normals are reported from
-    // the pair's second shape towards its first, so flip when the roles were swapped.
-    const bool swap = tA == DG_SHAPE_BOX || (tB != DG_SHAPE_BOX && tA > tB);
-    const int sa = swap ? sB : sA, sb = swap ? sA : sB, ta = swap ? tB : tA, tb = swap ? tA : tB; const float flip = swap ? -1.f : 1.f;
+  const int first = gi[DG_GI_FIRST], count = gi[DG_GI_COUNT];
+  constexpr int CH = TBL > 0 ? TBL : 1;
+  for (int c0 = 0; c0 < count; c0 += CH) {
+    const int n = min(CH, count - c0);
+    int mydesc = 0;
+    if constexpr (TBL > 0) { if (lane < n) mydesc = sc.PD[first + c0 + lane]; }
+    auto desc_of = [&](int k) -> int { if constexpr (TBL > 0) return __builtin_amdgcn_readlane(mydesc, k); else return sc.PD[first + c0 + k]; };
+    // the bounding data of pair k + 1 is read from LDS while pair k is tested
+    struct Cull { V3 ca, cb; float reach; int desc; };
+    auto fetch = [&](int k) { Cull c; c.desc = desc_of(k); const int oa = sc.tr_off + (c.desc & 4095) * SC_STRIDE, ob = sc.tr_off + ((c.desc >> 12) & 4095) * SC_STRIDE;
+      c.ca = ln.L3(oa + SC_C); c.cb = ln.L3(ob + SC_C); c.reach = ln.L(oa + SC_BOUND) + ln.L(ob + SC_BOUND) + margin; return c; };
+    Cull nx = fetch(0);
+  for (int k = 0; k < n; k++) {
+    const Cull cu = nx; if (k + 1 < n) nx = fetch(k + 1);
+    const int pi = first + c0 + k, d = cu.desc;
+    const int sa = d & 4095, sb = (d >> 12) & 4095, ta = (d >> 24) & 3, tb = (d >> 26) & 3; const float flip = (d >> 28) & 1 ? -1.f : 1.f;
     const int oa = sc.tr_off + sa * SC_STRIDE, ob = sc.tr_off + sb * SC_STRIDE;
     if (tb != DG_SHAPE_BOX) {
       // round vs round: closest points of the two segments, then sphere-sphere
-      const V3 a0 = ln.L3(oa + SC_E0), a1 = ln.L3(oa + SC_E1), b0 = ln.L3(ob + SC_E0), b1 = ln.L3(ob + SC_E1);
-      const float ra = ln.L(oa + SC_R), rb = ln.L(ob + SC_R), reach = ln.L(oa + SC_BOUND) + ln.L(ob + SC_BOUND) + margin;
-      const V3 dc = (a0 + a1) * 0.5f - (b0 + b1) * 0.5f;
-      if (!__any(dot(dc, dc) < reach * reach)) continue;
+      { const V3 dc = cu.ca - cu.cb; if (!__any(dot(dc, dc) < cu.reach * cu.reach)) continue; }
+      const V3 ha = ln.L3(oa + SC_H), hb = ln.L3(ob + SC_H); const float ra = ln.L(oa + SC_R), rb = ln.L(ob + SC_R);
+      const V3 a0 = cu.ca - ha, a1 = cu.ca + ha, b0 = cu.cb - hb, b1 = cu.cb + hb;
       V3 ca = a0, cb = b0;
       if (ta == DG_SHAPE_SPHERE && tb != DG_SHAPE_SPHERE) cb = closest_on_seg(b0, b1, a0);
       else if (ta != DG_SHAPE_SPHERE) seg_seg(a0, a1, b0, b1, ca, cb);
       emit_contact(ln, cnt, pi, sphere_sphere(ca, ra, cb, rb, margin), flip);
     } else {
       WShape b; shape_world(ln, sb, b);
-      const V3 a0 = ln.L3(oa + SC_E0), a1 = ln.L3(oa + SC_E1); const float ra = ln.L(oa + SC_R);
+      const V3 ha = ln.L3(oa + SC_H); const V3 a0 = cu.ca - ha, a1 = cu.ca + ha; const float ra = ln.L(oa + SC_R);
       // cull with the bounding sphere of the round shape against the box
-      { Hit hb = sphere_box((a0 + a1) * 0.5f, ln.L(oa + SC_BOUND), b, margin); if (!__any(hb.hit)) continue; }
+      { Hit hb = sphere_box(cu.ca, ln.L(oa + SC_BOUND), b, margin); if (!__any(hb.hit)) continue; }
       if (ta == DG_SHAPE_SPHERE) emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
       else if (ta == DG_SHAPE_CAPSULE) {
         emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
@@ -163,8 +177,8 @@ DGD int collide(const Lane<LANES>& ln) {
         M3 Rl; V3 pl;
         if (sc.SI[sa * DG_SI_STRIDE + DG_SI_FLAGS] & DG_SHAPE_WORLD) { M3 Id = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; Rl = Id; pl = v3(0.f, 0.f, 0.f); }
         else ln.link_world(abody, alink, Rl, pl);
-        for (int k = 0; k < npts; k++) {
-          cfp pp = sc.PF + 3 * (poff + k);
+        for (int k2 = 0; k2 < npts; k2++) {
+          cfp pp = sc.PF + 3 * (poff + k2);
           Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
           if (!h.hit) continue;
           bool placed = false;
@@ -173,20 +187,21 @@ DGD int collide(const Lane<LANES>& ln) {
             if (!placed && h.dist < bd4[j]) {
 #pragma unroll
               for (int m = 3; m > j; m--) { bd4[m] = bd4[m - 1]; bi4[m] = bi4[m - 1]; }
-              bd4[j] = h.dist; bi4[j] = k; placed = true;
+              bd4[j] = h.dist; bi4[j] = k2; placed = true;
             }
           }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          int k = bi4[j] < 0 ? 0 : bi4[j];
-          cfp pp = sc.PF + 3 * (poff + k);  // per-lane index: vector load
+          int k2 = bi4[j] < 0 ? 0 : bi4[j];
+          cfp pp = sc.PF + 3 * (poff + k2);  // per-lane index: vector load
           Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
           h.hit = h.hit && bi4[j] >= 0;
           emit_contact(ln, cnt, pi, h, flip);
         }
       }
     }
+  }
   }
   }
   ln.L(sc.cont_off) = (float)cnt;
@@ -871,7 +886,8 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
-  ncont = collide(ln);
+  const bool own_collide = !(PAR && sc.coll_wave);  // else the third wavefront is doing it right now
+  if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (SLICED ? envs_per_wave(LANES) : (PAR ? 64 : 0))>(ln);
   prof.stamp(PS_COLLIDE);
   for (int b = 0; b < sc.nb; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
@@ -880,6 +896,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
+  if (!own_collide) ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront before B2
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
   for (int gl = 0; gl < sc.nl; gl++) {

@@ -294,7 +294,7 @@ class SceneBuilder:
         nb = len(self.bodies)
         body_i, body_f, link_i, link_f, frame_i, frame_f = [], [], [], [], [], []
         shape_i, shape_f, points, planes = [], [], [], []
-        shape_dyn = []
+        shape_dyn, shape_anchor = [], []
         state_off = K.ST_PREFIX
         link_state_offs = []
         gl = 0
@@ -326,6 +326,14 @@ class SceneBuilder:
                 frame_i.append([b, -1 if fr.link < 0 else first + fr.link])
                 frame_f.append([*fr.T.p, *fr.T.quat, *fr.T_com.p, *fr.T_com.quat])
             T_body = Transform.from_xyz_quat(p_link, q_link)
+            # reach of each link origin from the base origin, whatever the joint angles (as in body_bound)
+            link_reach = []
+            for fl in flat.links:
+                r = (link_reach[fl.parent] if fl.parent >= 0 else 0.0) + float(np.linalg.norm(fl.origin.p))
+                if fl.joint_type == 1:
+                    r += max(abs(fl.lower), abs(fl.upper)) if fl.lower <= fl.upper else np.inf
+                link_reach.append(r)
+            anchored = flat.fixed_base and b not in respawned  # the base never leaves its load pose
             for sh in flat.shapes:
                 kind, T, prm, pts = sh.kind, sh.T, np.zeros(3), None
                 if kind == SHAPE_SPHERE:
@@ -364,6 +372,18 @@ class SceneBuilder:
                 shape_i.append([kind, b, -1 if sh.link < 0 else first + sh.link, poff, npts, ploff, npl, wflag])
                 shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction])
                 shape_dyn.append(dynamic)
+                # bounding sphere that holds the shape in EVERY reachable configuration, or None (floating / respawned base)
+                if not anchored:
+                    shape_anchor.append(None)
+                elif frozen:
+                    c = np.asarray(T.p, dtype=np.float64)
+                    rad = float(np.max(np.linalg.norm(pts - c, axis=1))) if pts is not None else float(
+                        prm[0] if kind == SHAPE_SPHERE else np.linalg.norm(prm) if kind == SHAPE_BOX else prm[0] + prm[1])
+                    shape_anchor.append((c, rad))
+                else:
+                    ext = float(np.max(np.linalg.norm(pts, axis=1))) if pts is not None else float(np.linalg.norm(T.p)) + float(
+                        prm[0] if kind == SHAPE_SPHERE else np.linalg.norm(prm) if kind == SHAPE_BOX else prm[0] + prm[1])
+                    shape_anchor.append((np.asarray(p_link, dtype=np.float64), (link_reach[sh.link] if sh.link >= 0 else 0.0) + ext))
         addon_off = state_off
         state_dim = state_off + self.addon_state
 
@@ -379,6 +399,12 @@ class SceneBuilder:
                 ta, tc = shape_i[a][0], shape_i[c][0]
                 if ta == SHAPE_BOX and tc == SHAPE_BOX:
                     continue
+                # static pruning: two shapes whose bases are bolted down can be too far apart to ever touch
+                # (the shoulders of two arms a metre apart); such a pair can produce no contact in any backend
+                if shape_anchor[a] is not None and shape_anchor[c] is not None:
+                    (ca, ra), (cc, rc) = shape_anchor[a], shape_anchor[c]
+                    if np.linalg.norm(ca - cc) - ra - rc > self.params['contact_margin'] + 1e-3:
+                        continue
                 kinds = {ta, tc}
                 per_pair = 4 if kinds == {SHAPE_POINTS, SHAPE_BOX} else 2 if kinds == {SHAPE_CAPSULE, SHAPE_BOX} else 1
                 max_contacts += per_pair

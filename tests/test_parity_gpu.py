@@ -160,6 +160,22 @@ def test_from_the_readme_scene_and_gripper_camera():
     assert close.float().mean() > 0.99
 
 
+def test_from_the_readme_resting_contacts_60_steps():
+    # R2D2 settles on the table next to the arm: 25 contacts, every sweep of the (lane-sliced) Gauss-Seidel loop runs
+    # its full 150 iterations.  A resting scene is not chaotic, so the two stay together: 2e-3 on the state
+    # (velocities sit at the solver residual), 1e-4 on observations.
+    gpu, cpu = make_pair('readme', 3)
+    d = gpu.sim.enable_diagnostics()
+    lo, hi = action_bounds(gpu)
+    gen = torch.Generator().manual_seed(0)
+    for i in range(60):
+        act = (lo + (hi - lo) * torch.rand((3, lo.numel()), generator=gen)) * 0.2
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+    assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(3)] and int(d[:, 0].min()) >= 20
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-3
+    assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 1e-4
+
+
 def test_frame_state_getter_matches_oracle():
     gpu, cpu = make_pair('ur_ik', 5)
     rollout(gpu, cpu, 10)

@@ -58,19 +58,23 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
       __syncthreads();  // B2
       __syncthreads();  // B3
     }
+    __syncthreads();  // B4
     return;
   }
   if (wave == 1) {  // ---------------- helper
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    __syncthreads();  // B0: wave 0 has put every pose into LDS
+    ln.kinematics(sc.helper_body);
+    __syncthreads();  // B0: every pose is in LDS
     if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) helper_substep(ln);
+    ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
+    __syncthreads();  // B4
     return;
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
   Prof<PROF> prof; prof.start();
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B0
   prof.stamp(PS_KIN);
   if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body);
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
   __syncthreads();  // B0': the helper's motor targets are in the state
   prof.stamp(PS_UPDATE);
   sim_step<64, PROF, true>(ln, diag, prof);
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
+  __syncthreads();  // B4: the helper's body too
   prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,

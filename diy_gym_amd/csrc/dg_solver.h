@@ -878,6 +878,7 @@ template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULL
 DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr) {
   const DevScene& sc = ln.sc; const float h = sc.h; const int hb = PAR ? sc.helper_body : -1;
   const bool primary = SLICED ? (int)threadIdx.x < envs_per_wave(LANES) : true;
+  constexpr int LCH = 6;  // links per chunk in the per-link loops
   int ncont = 0, wave_max_cont = 0, iters_done = 0;
   uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
   uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
@@ -899,19 +900,31 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (!own_collide) ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront before B2
   // ---- motor and joint-limit rows (per link, uniform)
   const float lerp = sc.HF[DG_HF_LIMIT_ERP];
-  for (int gl = 0; gl < sc.nl; gl++) {
-    const int lo = ln.li(gl)[DG_LI_STATE_OFF], mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
-    const float q = ln.S(lo + DG_LS_Q), qd = ln.S(lo + DG_LS_QD);
-    const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
-    ln.L(mo + MR_B) = kp * (ln.S(lo + DG_LS_TARGET_POS) - q) / h + kd * (ln.S(lo + DG_LS_TARGET_VEL) - qd);
-    ln.L(mo + MR_ACC) = 0.f;
-    const bool limited = f[DG_LF_LOWER] <= f[DG_LF_UPPER];
-    const float dlo = q - f[DG_LF_LOWER], dhi = f[DG_LF_UPPER] - q;
-    // acc < 0 marks an inactive limit row
-    ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
-    ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
-    if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
-    if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
+  // links in chunks: all the state loads of a chunk are issued before the first LDS store (a link at a time would
+  // pay one global round trip per link)
+  for (int g0 = 0; g0 < sc.nl; g0 += LCH) {
+    float q_[LCH], qd_[LCH], tp_[LCH], tv_[LCH];
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int gl = min(g0 + j, sc.nl - 1), lo = ln.li(gl)[DG_LI_STATE_OFF];
+      q_[j] = ln.S(lo + DG_LS_Q); qd_[j] = ln.S(lo + DG_LS_QD); tp_[j] = ln.S(lo + DG_LS_TARGET_POS); tv_[j] = ln.S(lo + DG_LS_TARGET_VEL);
+    }
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int gl = g0 + j; if (gl >= sc.nl) break;
+      const int mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
+      const float q = q_[j], qd = qd_[j];
+      const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
+      ln.L(mo + MR_B) = kp * (tp_[j] - q) / h + kd * (tv_[j] - qd);
+      ln.L(mo + MR_ACC) = 0.f;
+      const bool limited = f[DG_LF_LOWER] <= f[DG_LF_UPPER];
+      const float dlo = q - f[DG_LF_LOWER], dhi = f[DG_LF_UPPER] - q;
+      // acc < 0 marks an inactive limit row
+      ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
+      ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
+      if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
+      if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
+    }
   }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   // all-dense scenes: the sweeps start from a zero velocity change held in registers, so until they finish the LDS
@@ -1071,10 +1084,6 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
   // ---- apply velocity changes and integrate positions
   const float vmax = sc.HF[DG_HF_MAX_COORD_VEL];
-  for (int gl = 0; gl < sc.nl; gl++) {
-    const int lo = ln.li(gl)[DG_LI_STATE_OFF]; const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
-    ln.Sset(lo + DG_LS_APPLIED, maximp > 0.f ? ln.L(ln.pll(gl)[PLL_MROW] + MR_ACC) / h : 0.f);
-  }
   for (int b = 0; b < sc.nb; b++) {
     cip B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
     const bool fx = ln.fixed(b); if (fx && n == 0) continue;
@@ -1094,10 +1103,21 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       ln.Sset(so + 3, qn.x); ln.Sset(so + 4, qn.y); ln.Sset(so + 5, qn.z); ln.Sset(so + 6, qn.w);
     }
     const int k0 = fx ? 0 : 6;
-    for (int i = 0; i < n; i++) {
-      const int lo = ln.li(first + i)[DG_LI_STATE_OFF];
-      float qd = ln.S(lo + DG_LS_QD) + ln.L(dvo + k0 + i); qd = fminf(fmaxf(qd, -vmax), vmax);
-      ln.Sset(lo + DG_LS_QD, qd); ln.Sset(lo + DG_LS_Q, ln.S(lo + DG_LS_Q) + h * qd);
+    for (int i0 = 0; i0 < n; i0 += LCH) {  // loads of a chunk first, then its stores (state loads cannot pass state stores)
+      float q_[LCH], qd_[LCH], dv_[LCH], ac_[LCH]; int lo_[LCH];
+#pragma unroll
+      for (int j = 0; j < LCH; j++) {
+        const int i = min(i0 + j, n - 1); lo_[j] = ln.li(first + i)[DG_LI_STATE_OFF];
+        q_[j] = ln.S(lo_[j] + DG_LS_Q); qd_[j] = ln.S(lo_[j] + DG_LS_QD); dv_[j] = ln.L(dvo + k0 + i); ac_[j] = ln.L(ln.pll(first + i)[PLL_MROW] + MR_ACC);
+      }
+#pragma unroll
+      for (int j = 0; j < LCH; j++) {
+        const int i = i0 + j; if (i >= n) break;
+        const float maxf = ln.mt.v[3 * (first + i) + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+        ln.Sset(lo_[j] + DG_LS_APPLIED, maximp > 0.f ? ac_[j] / h : 0.f);
+        const float qd = fminf(fmaxf(qd_[j] + dv_[j], -vmax), vmax);
+        ln.Sset(lo_[j] + DG_LS_QD, qd); ln.Sset(lo_[j] + DG_LS_Q, q_[j] + h * qd);
+      }
     }
   }
   }  // primary

@@ -29,7 +29,12 @@ DGD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 DGD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 DGD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DGD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DGD float norm(V3 a) { return sqrtf(dot(a, a)); }
+// Hardware reciprocal / reciprocal square root / square root with one Newton step where needed: a few VALU instead
+// of the 10-12 of the IEEE-rounded library expansions; <= 1 ulp on the normal-range operands of this code.
+DGD float frcp(float b) { float r = __builtin_amdgcn_rcpf(b); return fmaf(r, fmaf(-b, r, 1.0f), r); }
+DGD float frsq(float x) { float r = __builtin_amdgcn_rsqf(x); return r * fmaf(-0.5f * x * r, r, 1.5f); }
+DGD float fsqrt(float x) { return x > 0.f ? x * frsq(x) : 0.f; }
+DGD float norm(V3 a) { return fsqrt(dot(a, a)); }
 
 DGD V3 mul(const M3& A, V3 b) {
   return v3(A.m[0] * b.x + A.m[1] * b.y + A.m[2] * b.z, A.m[3] * b.x + A.m[4] * b.y + A.m[5] * b.z,
@@ -73,12 +78,12 @@ DGD Q4 qmul(Q4 a, Q4 b) {
 }
 DGD Q4 qconj(Q4 a) { Q4 r = {-a.x, -a.y, -a.z, a.w}; return r; }
 DGD Q4 qnormalize(Q4 a) {
-  float n = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  float n = frsq(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
   Q4 r = {a.x * n, a.y * n, a.z * n, a.w * n};
   return r;
 }
 DGD M3 qmat(Q4 q) {
-  float n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0.f ? 2.0f / n : 0.f;
+  float n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0.f ? 2.0f * frcp(n) : 0.f;
   float xs = q.x * s, ys = q.y * s, zs = q.z * s;
   float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs,
         zz = q.z * zs;
@@ -89,17 +94,17 @@ DGD Q4 qfrom_mat(const M3& R) {
   float tr = R.m[0] + R.m[4] + R.m[8];
   Q4 q;
   if (tr > 0.f) {
-    float s = sqrtf(tr + 1.0f) * 2.0f;
-    q.x = (R.m[7] - R.m[5]) / s; q.y = (R.m[2] - R.m[6]) / s; q.z = (R.m[3] - R.m[1]) / s; q.w = 0.25f * s;
+    float s = fsqrt(tr + 1.0f) * 2.0f; const float is = frcp(s);
+    q.x = (R.m[7] - R.m[5]) * is; q.y = (R.m[2] - R.m[6]) * is; q.z = (R.m[3] - R.m[1]) * is; q.w = 0.25f * s;
   } else if (R.m[0] > R.m[4] && R.m[0] > R.m[8]) {
-    float s = sqrtf(1.0f + R.m[0] - R.m[4] - R.m[8]) * 2.0f;
-    q.x = 0.25f * s; q.y = (R.m[1] + R.m[3]) / s; q.z = (R.m[2] + R.m[6]) / s; q.w = (R.m[7] - R.m[5]) / s;
+    float s = fsqrt(1.0f + R.m[0] - R.m[4] - R.m[8]) * 2.0f; const float is = frcp(s);
+    q.x = 0.25f * s; q.y = (R.m[1] + R.m[3]) * is; q.z = (R.m[2] + R.m[6]) * is; q.w = (R.m[7] - R.m[5]) * is;
   } else if (R.m[4] > R.m[8]) {
-    float s = sqrtf(1.0f + R.m[4] - R.m[0] - R.m[8]) * 2.0f;
-    q.x = (R.m[1] + R.m[3]) / s; q.y = 0.25f * s; q.z = (R.m[5] + R.m[7]) / s; q.w = (R.m[2] - R.m[6]) / s;
+    float s = fsqrt(1.0f + R.m[4] - R.m[0] - R.m[8]) * 2.0f; const float is = frcp(s);
+    q.x = (R.m[1] + R.m[3]) * is; q.y = 0.25f * s; q.z = (R.m[5] + R.m[7]) * is; q.w = (R.m[2] - R.m[6]) * is;
   } else {
-    float s = sqrtf(1.0f + R.m[8] - R.m[0] - R.m[4]) * 2.0f;
-    q.x = (R.m[2] + R.m[6]) / s; q.y = (R.m[5] + R.m[7]) / s; q.z = 0.25f * s; q.w = (R.m[3] - R.m[1]) / s;
+    float s = fsqrt(1.0f + R.m[8] - R.m[0] - R.m[4]) * 2.0f; const float is = frcp(s);
+    q.x = (R.m[2] + R.m[6]) * is; q.y = (R.m[5] + R.m[7]) * is; q.z = 0.25f * s; q.w = (R.m[3] - R.m[1]) * is;
   }
   return qnormalize(q);
 }
@@ -211,7 +216,7 @@ DGD void chol6_solve(const float* L, const float* b, float* x) {
 // division through v_rcp_f32 (1 ulp) where IEEE rounding of the quotient does not matter (closest-point parameters...)
 // a / b through v_rcp_f32 and one Newton step (4 VALU instead of the 12 of an IEEE division; <= 1 ulp for the
 // normal-range operands of this code: masses, inertias, solver diagonals)
-DGD float fdiv(float a, float b) { float r = __builtin_amdgcn_rcpf(b); r = fmaf(r, fmaf(-b, r, 1.0f), r); return a * r; }
+DGD float fdiv(float a, float b) { return a * frcp(b); }
 // pins a wave-uniform value in a VGPR so that a long loop does not re-fetch it through the scalar cache
 DGD float pin(float x) { float y; asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(x)); return y; }
 

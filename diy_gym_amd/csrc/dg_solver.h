@@ -1305,7 +1305,7 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
     float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
     if (use_orn) {
       Q4 dq = qmul(tq, qconj(qe)); if (dq.w < 0.f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
-      const float sn = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0f * atan2f(sn, dq.w), k = sn > 1e-12f ? an / sn : 2.0f;
+      const float sn = fsqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0f * atan2f(sn, dq.w), k = sn > 1e-12f ? fdiv(an, sn) : 2.0f;
       dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
     }
     float U[21], Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0[N];
@@ -1322,8 +1322,9 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
         if (nullsp) {
           const float lo = rest[n + i], hi = rest[2 * n + i], rg = rest[3 * n + i];
           v0[i] = g0 * (rest[i] - q[i]);
-          if (q[i] > hi) v0[i] += g1 * (hi - q[i]) / rg;
-          if (q[i] < lo) v0[i] += g1 * (lo - q[i]) / rg;
+          const float irg = frcp(rg);
+          if (q[i] > hi) v0[i] += g1 * (hi - q[i]) * irg;
+          if (q[i] < lo) v0[i] += g1 * (lo - q[i]) * irg;
         }
         if (i <= eel) {
           float col[6]; column(i, col);
@@ -1355,7 +1356,7 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
         dth[i] = nullsp ? (t + v0[i] - tz) : t; mx = fmaxf(mx, fabsf(dth[i]));
       }
     }
-    const float scl = mx > maxang ? maxang / mx : 1.0f;
+    const float scl = mx > maxang ? fdiv(maxang, mx) : 1.0f;
 #pragma unroll
     for (int i = 0; i < N; i++) if (i < n && live) q[i] += scl * dth[i];
   }

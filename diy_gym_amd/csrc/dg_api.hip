@@ -208,6 +208,17 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; const bool stat = (B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0; if (!stat && !PLB[b * PLB_STRIDE + PLB_CHAIN]) ok = false; }
     sc.coll_wave = ok ? 1 : 0;
   }
+  // The update ops of such a scene (inverse kinematics above all) only write motor targets unless one of them is a
+  // torque / force op; then the first substep's dynamics do not depend on them and can run alongside.
+  sc.early_dyn = 0;
+  if (sc.coll_wave && !getenv("DG_NO_EARLY_DYNAMICS")) {
+    bool ok = true;
+    for (int op = 0; op < I[DG_H_N_OPS]; op++) {
+      const int32_t* oi = OI + op * DG_OI_STRIDE; const int code = oi[DG_OI_CODE];
+      if (code == DG_OP_EXTERNAL_FORCE || code == DG_OP_PROPELLOR || code == DG_OP_ADMITTANCE || (code == DG_OP_JOINT_CONTROL && oi[DG_OI_FLAGS] == DG_JC_TORQUE)) ok = false;
+    }
+    sc.early_dyn = ok ? 1 : 0;
+  }
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);

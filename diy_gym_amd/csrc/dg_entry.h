@@ -51,10 +51,19 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     __syncthreads();  // B0
+    if (sc.early_dyn) {  // first substep: narrow phase and both arms' dynamics while the other two waves run the update ops
+      collide<64, 64>(ln);
+      Prof<false> none;
+      for (int b = 0; b < sc.nb; b++) {
+        if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
+        ln.template dynamics_chain<6>(b, none);  // coll_wave guarantees every moving body is such a chain
+        const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+      }
+    }
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {
       __syncthreads();  // B1: every pose is in LDS
-      if (sc.coll_wave) collide<64, 64>(ln);  // contact list + count go to LDS; the main wave reads them after B2
+      if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln);  // contact list + count go to LDS; the main wave reads them after B2
       __syncthreads();  // B2
       __syncthreads();  // B3
     }
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
     __syncthreads();  // B0: every pose is in LDS
     if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
     __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) helper_substep(ln);
+    for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0);
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
     __syncthreads();  // B4
     return;

@@ -41,6 +41,7 @@ struct DevScene {
   cip BI, LI, FI, SI, PI, GI, OI, IL;
   cfp BF, LF, FF, SF, PF, OF, FL, HF;
   cip PLB;  // per body: [R0_off, minv_off, dv_off, nv]
+  int early_dyn;  // with coll_wave: the first substep's narrow phase and dynamics run on that wavefront DURING the update ops (no op writes torques / forces)
   int coll_wave;  // helper-wave step kernel: a third wavefront runs the narrow phase (every moving body has register-resident dynamics)
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]

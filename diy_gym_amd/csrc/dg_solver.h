@@ -875,7 +875,7 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
 // FULLWAVE: every lane of the wavefront is active at the call (step kernels of the 64-lane and global-workspace
 // modes; not the reset kernel, which runs the step under a per-env mask).
 template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
-DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr) {
+DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr, int index = 0) {
   const DevScene& sc = ln.sc; const float h = sc.h; const int hb = PAR ? sc.helper_body : -1;
   const bool primary = SLICED ? (int)threadIdx.x < envs_per_wave(LANES) : true;
   constexpr int LCH = 6;  // links per chunk in the per-link loops
@@ -883,14 +883,17 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   uint64_t limit_mask = 0ull;  // bit (b & 63): some lane of this wave has an active limit row on body b
   uint64_t limit_rows = 0ull;  // bit (2 gl + side), links 0..31: some lane has that limit row active (dense sweeps)
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD]; const int rs = crow_stride(sc.crow_tail);
+  // early: the narrow-phase wavefront already ran this (first) substep's narrow phase and dynamics during the update
+  // ops; positions have not changed since the poses of the step's start were computed
+  const bool early = PAR && sc.early_dyn && index == 0;
   if (primary) {
-  for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
+  if (!early) for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
   const bool own_collide = !(PAR && sc.coll_wave);  // else the third wavefront is doing it right now
   if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (SLICED ? envs_per_wave(LANES) : (PAR ? 64 : 0))>(ln);
   prof.stamp(PS_COLLIDE);
-  for (int b = 0; b < sc.nb; b++) {
+  if (!early) for (int b = 0; b < sc.nb; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
     if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
@@ -1126,12 +1129,14 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
 
 // the helper wave's side of one substep
 template <int LANES>
-DGD void helper_substep(const Lane<LANES>& ln) {
+DGD void helper_substep(const Lane<LANES>& ln, bool early) {
   const DevScene& sc = ln.sc; const int hb = sc.helper_body; Prof<false> none;
-  ln.kinematics(hb);
+  if (!early) ln.kinematics(hb);
   __syncthreads();  // B1
-  ln.template dynamics_chain<6>(hb, none);
-  { const int dvo = ln.plb(hb)[PLB_DV], nv = ln.plb(hb)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f; }
+  if (!early) {
+    ln.template dynamics_chain<6>(hb, none);
+    const int dvo = ln.plb(hb)[PLB_DV], nv = ln.plb(hb)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+  }
   __syncthreads();  // B2
   __syncthreads();  // B3
 }
@@ -1139,7 +1144,7 @@ DGD void helper_substep(const Lane<LANES>& ln) {
 template <int LANES, bool PROF, bool PAR = false, bool SLICED = false, bool FULLWAVE = false>
 DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, float* smem = nullptr, float* gws = nullptr) {
   const DevScene& sc = ln.sc;
-  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof, smem, gws); prof.stamp(PS_INTEGRATE); }
+  for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof, smem, gws, k); prof.stamp(PS_INTEGRATE); }
   if (SLICED && (int)threadIdx.x >= envs_per_wave(LANES)) return;
   for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);

@@ -175,6 +175,7 @@ struct Lane {
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
     LRset(plb(b)[PLB_R0], R0);
+#pragma unroll 3
     for (int i = 0; i < n; i++) {
       int gl = first + i, par = li(gl)[DG_LI_PARENT];
       float q = qoff >= 0 ? L(qoff + i) : S(li(gl)[DG_LI_STATE_OFF] + DG_LS_Q);

@@ -176,6 +176,26 @@ def test_from_the_readme_resting_contacts_60_steps():
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize('name,env_var,value,lanes,steps,tol', [
+    ('cart_tree', 'DG_MAX_LANES', '16', 16, 20, 2e-2),   # two bodies with joints: general (masked) column loads of the sliced sweeps
+    ('cart_tree', 'DG_MAX_LANES', '32', 32, 20, 2e-2),
+    ('marbles', 'DG_MAX_LANES', '16', 16, 100, 2e-3),
+    ('readme', 'DG_NO_SLICED_GLOBAL', '1', 0, 30, 2e-3),  # 64 envs per wavefront from the global workspace, unsliced dense sweeps
+    ('ur_ik', 'DG_NO_HELPER_WAVE', '1', 64, 30, 5e-4),    # single-wavefront step kernel
+    ('ur_ik', 'DG_NO_EARLY_DYNAMICS', '1', 64, 30, 5e-4),
+])
+def test_alternative_workspace_modes(name, env_var, value, lanes, steps, tol):
+    # every scene normally takes ONE path through the mode selection; force the others
+    os.environ[env_var] = value
+    try:
+        gpu, cpu = make_pair(name, 9)
+    finally:
+        del os.environ[env_var]
+    assert gpu.sim.lanes == lanes
+    w = rollout(gpu, cpu, steps, scale=0.5)
+    assert w['obs'] < tol and w['term_mismatch'] == 0, w
+
+
 def test_frame_state_getter_matches_oracle():
     gpu, cpu = make_pair('ur_ik', 5)
     rollout(gpu, cpu, 10)

@@ -227,10 +227,10 @@ def main():
                        'auto_reset': auto_reset, 'launch': 'hipGraph replay of %d-step segments' % R if graph is not None else 'eager', 'episodes_finished_rank0': resets - B, 'parallelism': 'independent env shards x%d, no collective' % world,
                        'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'step_kernel', 'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_unit,
+                         'traffic': traffic, 'kernel': 'step_kernel_par' if getattr(sim, 'lanes', 0) == 64 and args.workload.startswith('ur_high_5') else 'step_kernel', 'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_unit,
                          'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
-                         'note': 'the step kernel keeps all per-env scratch in LDS; it is bound by VALU/LDS issue of one wave per CU, '
-                                 'not by HBM (DESIGN.md Measurement)'},
+                         'note': 'the step kernel keeps all per-env scratch in LDS; it is bound by instruction issue and latency of one '
+                                 'wavefront per SIMD (three per workgroup), not by HBM (DESIGN.md Measurement)'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, lo.numel(), lo, hi)

@@ -212,12 +212,13 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // torque / force op; then the first substep's dynamics do not depend on them and can run alongside.
   sc.early_dyn = 0;
   if (sc.coll_wave && !getenv("DG_NO_EARLY_DYNAMICS")) {
-    bool ok = true;
+    bool ok = true, long_update = false;  // worth it only when the update phase is long: an inverse-kinematics solve
     for (int op = 0; op < I[DG_H_N_OPS]; op++) {
       const int32_t* oi = OI + op * DG_OI_STRIDE; const int code = oi[DG_OI_CODE];
+      if (code == DG_OP_IK_CONTROL) long_update = true;
       if (code == DG_OP_EXTERNAL_FORCE || code == DG_OP_PROPELLOR || code == DG_OP_ADMITTANCE || (code == DG_OP_JOINT_CONTROL && oi[DG_OI_FLAGS] == DG_JC_TORQUE)) ok = false;
     }
-    sc.early_dyn = ok ? 1 : 0;
+    sc.early_dyn = (ok && long_update) ? 1 : 0;
   }
   sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint

@@ -25,6 +25,8 @@ SCENES = {  # name: (config, envs, steps, action scale)
     'ur_joint': ('examples/ur_high_5/ur_high_5_joint.yaml', 3, 30, 1.0),
     'cart_tree': ('tests/golden/cart_tree.yaml', 3, 12, 1.0),
     'maze': ('examples/r2d2_maze/r2d2_maze.yaml', 2, 12, 10.0),
+    'admittance': ('tests/golden/ur_admittance.yaml', 3, 30, 1.0),
+    'readme': ('examples/from_the_readme/from_the_readme.yaml', 2, 30, 0.2),   # R2D2 lands on the table: 25 contacts
 }
 
 

@@ -501,9 +501,12 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
   };
   // a motor or limit row on global DoF j of a body whose DoFs are [base, base + nv): R = column of the body's M^-1
   auto load_col = [&](float (&v)[NTB], int col, int base, int nv) {
-    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+    // the body's DoFs are [base, base + nv) of the global vector: read the column as if it started `base` slots
+    // earlier (those slots are allocated workspace -- M^-1 blocks come after the pose slots) and clear the rest
 #pragma unroll
-    for (int k = 0; k < NTB; k++) { const int i = k - base; const bool in = i >= 0 && i < nv; v[k] = ln.L(col + min(max(i, 0), nv - 1)) * (in ? 1.f : 0.f); }
+    for (int k = 0; k < NTB; k++) v[k] = ln.L(col - base + k);
+#pragma unroll
+    for (int k = 0; k < NTB; k++) v[k] = (k >= base && k < base + nv) ? v[k] : 0.f;
   };
   const LinkRows<LANES, FULLWAVE> rows(ln);
   auto load_motor = [&](DenseCol<NTB>& r, int gl) {
@@ -611,9 +614,12 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
     for (int i = (NTB - 8) / SL; i < NS; i++) v[i] = (i * SL + sl) < nt ? v[i] : 0.f;
   };
   auto load_col = [&](float (&v)[NS], int col, int base, int nv) {
-    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+    // the body's DoFs are [base, base + nv) of the global vector: read the column as if it started `base` slots
+    // earlier (allocated workspace) and clear what is not the body's
 #pragma unroll
-    for (int i = 0; i < NS; i++) { const int k = i * SL + sl - base; const float x = lq.L(col + min(max(k, 0), nv - 1)); v[i] = (k >= 0 && k < nv) ? x : 0.f; }
+    for (int i = 0; i < NS; i++) v[i] = ls[(col - base + i * SL) * LANES];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { const int k = i * SL + sl; v[i] = (k >= base && k < base + nv) ? v[i] : 0.f; }
   };
   // DoF j of the velocity change, known to every lane of the group
   auto dv_at = [&](int j) { const float mine = dv[j >> LOG]; return group_sum((j & (SL - 1)) == sl ? mine : 0.f); };
@@ -746,12 +752,12 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
     for (int i = (NTB - 8) / SL; i < NS; i++) v[i] = (i * SL + sl) < nt ? v[i] : 0.f;
   };
   auto load_col = [&](float (&v)[NS], int col, int base, int nv) {
-    if (base == 0 && nv == nt) { load_vec(v, col); return; }
+    // the body's DoFs are [base, base + nv) of the global vector: read the column as if it started `base` slots
+    // earlier (allocated workspace) and clear what is not the body's
 #pragma unroll
-    for (int i = 0; i < NS; i++) {  // general case: the body's DoFs are [base, base + nv) of the global vector
-      const int k = i * SL + sl - base; const unsigned kc = (unsigned)min(max(k, 0), nv - 1);
-      const float x = BL((kc * W + colq) * 4u, col); v[i] = (k >= 0 && k < nv) ? x : 0.f;
-    }
+    for (int i = 0; i < NS; i++) v[i] = BL(lane_off + (unsigned)(i * SL) * W * 4u, col - base);
+#pragma unroll
+    for (int i = 0; i < NS; i++) { const int k = i * SL + sl; v[i] = (k >= base && k < base + nv) ? v[i] : 0.f; }
   };
   auto dv_at = [&](int j) { const float mine = dv[j >> LOG]; return group_sum4((j & (SL - 1)) == sl ? mine : 0.f); };
   struct Row { float J[NS], R[NS], b, diag, mu, acc, nacc; };

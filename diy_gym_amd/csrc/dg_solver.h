@@ -1283,7 +1283,7 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
       for (int k = 0; k < 3; k++) { cP[i][k] = pin(f[DG_LF_POS + k]); cA[i][k] = pin(f[DG_LF_AXIS + k]); }
     }
   }
-  V3 pe; Q4 qe;
+  V3 pe; M3 Re;  // end-effector point and LINK rotation (the frame offset is folded into the target below)
   auto fk = [&]() {
     M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
 #pragma unroll
@@ -1298,11 +1298,19 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
         if (i == eel) { Rl = R; pl = p; }
       }
     }
-    pe = pl + mul(Rl, off); qe = qnormalize(qmul(qfrom_mat(Rl), qoff));
+    pe = pl + mul(Rl, off); Re = Rl;
   };
   fk();
-  const V3 tp = pe + v3(act[0], act[1], act[2]); Q4 tq = qe;
-  if (use_orn) tq = qmul(qe, qfrom_euler(act[3], act[4], act[5]));
+  const V3 tp = pe + v3(act[0], act[1], act[2]);
+  // Orientation target as a matrix, with the frame offset folded in: the error rotation is
+  // R_target (R_link R_off)^T = (R_target R_off^T) R_link^T, so each iteration needs only the trace and the
+  // antisymmetric part of Tm R_link^T (27 FMAs) instead of matrix -> quaternion -> product -> angle-axis.
+  M3 Tm = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};
+  if (use_orn) {
+    const Q4 qe0 = qnormalize(qmul(qfrom_mat(Re), qoff));
+    const Q4 tq = qmul(qe0, qfrom_euler(act[3], act[4], act[5]));
+    Tm = mul(qmat(tq), transpose(qmat(qoff)));
+  }
   // without the null-space lists pybullet solves (J^T J + d I) dq = J^T e in joint space; by the push-through
   // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d
   const float lam2 = nullsp ? sc.HF[DG_HF_IK_LAMBDA_SQ] : sc.HF[DG_HF_IK_JOINT_DAMPING], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
@@ -1315,9 +1323,15 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
     if (!__any(live)) break;
     float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
     if (use_orn) {
-      Q4 dq = qmul(tq, qconj(qe)); if (dq.w < 0.f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
-      const float sn = fsqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0f * atan2f(sn, dq.w), k = sn > 1e-12f ? fdiv(an, sn) : 2.0f;
-      dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
+      // M = Tm Re^T; rotation vector = axis * angle with axis sin = vee(M - M^T) / 2, cos = (tr M - 1) / 2
+      const float* T = Tm.m; const float* R = Re.m;
+      const float tr = T[0] * R[0] + T[1] * R[1] + T[2] * R[2] + T[3] * R[3] + T[4] * R[4] + T[5] * R[5] + T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+      const float m21 = T[3] * R[0] + T[4] * R[1] + T[5] * R[2], m12 = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+      const float m31 = T[6] * R[0] + T[7] * R[1] + T[8] * R[2], m13 = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+      const float m32 = T[6] * R[3] + T[7] * R[4] + T[8] * R[5], m23 = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+      const float sx = 0.5f * (m32 - m23), sy = 0.5f * (m13 - m31), sz = 0.5f * (m21 - m12);
+      const float sn = fsqrt(sx * sx + sy * sy + sz * sz), an = atan2f(sn, 0.5f * (tr - 1.0f)), k = sn > 1e-12f ? fdiv(an, sn) : 1.0f;
+      dS[3] = sx * k; dS[4] = sy * k; dS[5] = sz * k;
     }
     float U[21], Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0[N];
 #pragma unroll
@@ -1351,20 +1365,23 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
 #pragma unroll
     for (int r = 0; r < 6; r++) U[r * (r + 1) / 2 + r] += lam2;
     chol6(U);
-    float y[6], z[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; chol6_solve(U, dS, y);
-    if (nullsp) chol6_solve(U, Jv, z);
+    // dq = J^T A^-1 e + (I - J^T A^-1 J) v0 = J^T A^-1 (e - J v0) + v0: one solve (Jv is zero without the null space)
+    float rhs[6], y[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) rhs[r] = dS[r] - Jv[r];
+    chol6_solve(U, rhs, y);
     float dth[N], mx = 0.f;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       dth[i] = 0.f;
       if (i < n) {
-        float t = 0.f, tz = 0.f;
+        float t = 0.f;
         if (i <= eel) {
           float col[6]; column(i, col);
 #pragma unroll
-          for (int r = 0; r < 6; r++) { t += col[r] * y[r]; tz += col[r] * z[r]; }
+          for (int r = 0; r < 6; r++) t += col[r] * y[r];
         }
-        dth[i] = nullsp ? (t + v0[i] - tz) : t; mx = fmaxf(mx, fabsf(dth[i]));
+        dth[i] = t + v0[i]; mx = fmaxf(mx, fabsf(dth[i]));
       }
     }
     const float scl = mx > maxang ? fdiv(maxang, mx) : 1.0f;

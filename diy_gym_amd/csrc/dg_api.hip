@@ -208,6 +208,13 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; const bool stat = (B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0; if (!stat && !PLB[b * PLB_STRIDE + PLB_CHAIN]) ok = false; }
     sc.coll_wave = ok ? 1 : 0;
   }
+  // sweeps split between the main and the helper wave: exactly two register-chain bodies, the second is the helper's,
+  // and no other body carries joints (their rows would have to run on the main wave between the exchanges)
+  sc.split_pgs = 0;
+  if (w->par && !getenv("DG_NO_SPLIT_SWEEPS")) {
+    int jointed = 0; for (int b = 0; b < nb; b++) if (BI[b * DG_BI_STRIDE + DG_BI_N_LINKS] > 0) jointed++;
+    if (jointed == 2 && sc.reg_body[0] >= 0 && sc.reg_body[1] == sc.helper_body && sc.reg_body[0] != sc.helper_body) sc.split_pgs = 1;
+  }
   // The update ops of such a scene (inverse kinematics above all) only write motor targets unless one of them is a
   // torque / force op; then the first substep's dynamics do not depend on them and can run alongside.
   sc.early_dyn = 0;

@@ -872,6 +872,83 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
 }
 
+// Five workspace slots for the exchange (4) and the decision flag (1): the tail of the padding behind the velocity-
+// change blocks (nv_max + 8 slots; readers of that padding only ever multiply it by zero, and these values are finite).
+DGD int split_slots(const DevScene& sc) { return sc.dv_base + sc.nt + sc.nv_max; }
+
+// Main-wave side of the per-substep decision (helper-wave kernel): publish whether this substep's sweeps are split.
+// Everything it depends on is wave-uniform; the other wavefronts read the flag after the barrier.
+template <int LANES>
+DGD bool split_sweeps(const Lane<LANES>& ln, int wave_max_cont, uint64_t limit_mask) {
+  const DevScene& sc = ln.sc;
+  bool ok = sc.split_pgs && wave_max_cont == 0 && limit_mask == 0ull;
+  ln.L(split_slots(sc) + 4) = ok ? 1.f : 0.f;  // every lane stores the same value into its own column
+  __syncthreads();  // Bq
+  return ok;
+}
+template <int LANES>
+DGD bool split_sweeps_follow(const Lane<LANES>& ln) {
+  __syncthreads();  // Bq
+  return ln.L(split_slots(ln.sc) + 4) != 0.f;
+}
+
+// ---- register-chain sweeps split across the wavefronts of the helper-wave kernel -------------------------------
+// When a substep has no contact and no active joint-limit row, the rows of the two register-chain bodies share no
+// unknown: the main wave sweeps one body, the helper wave the other, and the only coupling -- the per-env residual
+// that decides the early-out -- is exchanged through LDS once per iteration (double-buffered, one __syncthreads).
+// Every wavefront of the workgroup runs this loop (b < 0: the narrow-phase wave only follows the barriers), and
+// all of them derive the same `live` flags from the same exchanged residuals, so they leave the loop together.
+// Bitwise the same impulses as the single-wave sweep: rows of different bodies were already independent chains.
+template <int LANES>
+DGD int pgs_reg_split(const Lane<LANES>& ln, int b, int slot, int xo) {
+  constexpr int RN = 6;
+  const DevScene& sc = ln.sc; const float h = sc.h; const float thr_abs = sqrtf(sc.HF[DG_HF_RESIDUAL_THRESHOLD]);
+  float rM[RN * RN], rdv[RN], rb[RN], racc[RN], rdi[RN], rdg[RN], smax[RN]; int n = 0, dvo = 0, mo0 = 0;
+#pragma unroll
+  for (int i = 0; i < RN; i++) { rdv[i] = 0.f; rb[i] = 0.f; racc[i] = 0.f; rdi[i] = 0.f; rdg[i] = 0.f; smax[i] = 0.f;
+    _Pragma("unroll") for (int c = 0; c < RN; c++) rM[i * RN + c] = 0.f; }
+  if (b >= 0) {
+    const int first = ln.bi(b)[DG_BI_FIRST_LINK], mvo = ln.plb(b)[PLB_MINV];
+    n = ln.bi(b)[DG_BI_N_LINKS]; dvo = ln.plb(b)[PLB_DV]; mo0 = ln.pll(first)[PLL_MROW];
+#pragma unroll
+    for (int i = 0; i < RN; i++) {
+      if (i < n) {
+        const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[i] = maxf < 0.f ? -maxf : maxf * h;
+        rb[i] = ln.L(mo0 + i * MR_STRIDE + MR_B); rdg[i] = ln.L(mvo + i * n + i); rdi[i] = 1.0f / rdg[i];
+      }
+#pragma unroll
+      for (int c = 0; c < RN; c++) rM[i * RN + c] = (i < n && c < n) ? ln.L(mvo + i * n + c) : 0.f;
+    }
+  }
+  bool live = ln.valid; int iters_done = 0;
+  for (int it = 0; it < sc.iters; it++) {
+    const int xb = xo + 2 * (it & 1);
+    if (b >= 0) {
+      float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < RN; i++) {
+        const float want = racc[i] + (rb[i] - rdv[i]) * rdi[i];
+        const float nacc = __builtin_amdgcn_fmed3f(want, -smax[i], smax[i]);
+        const float delta = (nacc - racc[i]) * lv; racc[i] += delta;
+#pragma unroll
+        for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
+        maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
+      }
+      ln.L(xb + slot) = maxabs;
+    }
+    __syncthreads();
+    const float m = fmaxf(ln.L(xb), ln.L(xb + 1));
+    if (live) iters_done = it + 1;
+    live = live && !(m <= thr_abs);
+    if (!__any(live)) break;
+  }
+  if (b >= 0) {
+#pragma unroll
+    for (int i = 0; i < RN; i++) if (i < n) { ln.L(dvo + i) = rdv[i]; ln.L(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }
+  }
+  return iters_done;
+}
+
 // ---------------------------------------------------------------- substep
 // PAR: this wave is the MAIN wave of a two-wave workgroup; the helper wave (helper_substep below) owns body
 // sc.helper_body -- its kinematics and its register-resident dynamics run concurrently with everything here up to
@@ -973,6 +1050,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       else if (sc.nt <= 24) iters_done = pgs_dense_sliced_global<LANES, 24, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
       else iters_done = pgs_dense_sliced_global<LANES, 32, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
     }
+  } else if (PAR && split_sweeps(ln, wave_max_cont, limit_mask)) {
+    iters_done = pgs_reg_split(ln, sc.reg_body[0], 0, split_slots(sc));
+    __syncthreads();  // Bp: the helper's velocity changes and impulses are in LDS
   } else if (primary) {
   bool live = ln.valid;
   if (all_dense) {
@@ -1144,6 +1224,7 @@ DGD void helper_substep(const Lane<LANES>& ln, bool early) {
     const int dvo = ln.plb(hb)[PLB_DV], nv = ln.plb(hb)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
   __syncthreads();  // B2
+  if (split_sweeps_follow(ln)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); __syncthreads(); /* Bp */ }
   __syncthreads();  // B3
 }
 

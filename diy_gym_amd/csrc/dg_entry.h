@@ -116,7 +116,8 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
     Prof<false> prof;
     for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr, prof);
   }
-  if (obs) {
+  // observations of the envs that were reset; a wavefront without one has nothing to refresh (its rows are current)
+  if (obs && (mask == nullptr || __any(doit))) {
     for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
     run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr);
   }

@@ -56,6 +56,26 @@ def _origin(elem):
     return Transform.from_xyz_rpy(_floats(o.get('xyz'), 3, [0, 0, 0]), _floats(o.get('rpy'), 3, [0, 0, 0]))
 
 
+def resolve_mesh(urdf_dir, filename):
+    """Path of a ``<mesh filename=...>``.  Plain names are relative to the URDF.  ``package://pkg/rest`` (ROS style,
+    used by ``ur5_2f.urdf`` / ``ur5_3f.urdf`` for the gripper meshes) is looked up like Bullet's URDF importer does
+    [RECOLLECTION]: the part after ``package://`` is tried under the URDF's directory and each of its parents; since the
+    reference's data tree has no ``robotiq/`` level (``package://robotiq/robotiq_2f/...`` lives at
+    ``data/robotiq_2f/...``) the package name is also dropped as a second attempt [decision]."""
+    if not filename.startswith('package://'):
+        return os.path.join(urdf_dir, filename)
+    rest = filename[len('package://'):]
+    tails = [rest] + ([rest.split('/', 1)[1]] if '/' in rest else [])
+    d = os.path.abspath(urdf_dir)
+    for _ in range(6):
+        for t in tails:
+            cand = os.path.join(d, t)
+            if os.path.isfile(cand):
+                return cand
+        d = os.path.dirname(d)
+    return os.path.join(urdf_dir, rest)
+
+
 class UrdfShape:
     def __init__(self, kind, origin, size=None, radius=0.0, length=0.0, mesh=None, mesh_scale=None):
         self.kind = kind  # 'sphere' | 'box' | 'cylinder' | 'capsule' | 'mesh' | 'plane'
@@ -330,7 +350,7 @@ class FlatBody:
                 elif sh.kind == 'mesh':
                     if mesh_loader is None:
                         continue
-                    pts = mesh_loader(os.path.join(robot.dir, sh.mesh), max_hull_points)
+                    pts = mesh_loader(resolve_mesh(robot.dir, sh.mesh), max_hull_points)
                     if pts is None or len(pts) == 0:
                         continue
                     pts = (pts * sh.mesh_scale[None, :] * s) @ T.R.T + T.p

@@ -71,7 +71,9 @@ int32_t dg_world_init_state(dg_world* w, float* state, void* stream);
 /* Replaces DIYGym.reset()'s addon.reset() + hot_start x p.stepSimulation +
  * observe (reference diy_gym.py:130-148; respawn.py:31-35,
  * joint_controller.py:36-38) for the envs whose `mask` byte is non-zero
- * (mask == NULL: all envs).  obs (nullable) is written for every env. */
+ * (mask == NULL: all envs).  obs (nullable) is written for the envs that were reset -- with mask == NULL that is every
+ * env; with a mask, the rows of the other envs are left as the last step / reset / observe wrote them (in units of
+ * one wavefront: rows sharing a wavefront with a reset env are recomputed, to the same values). */
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream);
 
 /* Replaces one DIYGym.step(): addon.update() for the controller addons whose

@@ -18,6 +18,7 @@ CONFIGS = {
     'maze': os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml'),
     'readme': os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml'),
     'admittance': os.path.join(ROOT, 'tests', 'golden', 'ur_admittance.yaml'),
+    'gripper': os.path.join(ROOT, 'tests', 'golden', 'ur5_gripper.yaml'),
 }
 
 
@@ -103,6 +104,14 @@ def test_admittance_controller_80_steps():
     gpu, cpu = make_pair('admittance', 33)
     w = rollout(gpu, cpu, 80)
     assert w['obs'] < 3e-3, w
+
+
+def test_ur5_with_two_finger_gripper_asset_40_steps():
+    # ur5_2f.urdf of the reference's data tree: a 12-DoF fixed-base TREE (arm + six finger joints), hull-vs-plane
+    # contacts; generic articulated-body path, all-dense sweeps
+    gpu, cpu = make_pair('gripper', 5)
+    w = rollout(gpu, cpu, 40, scale=0.5)
+    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
 
 
 def test_drone_pilot_60_steps():

@@ -52,15 +52,22 @@ class Model(Receptor):
         if full is None:
             raise ValueError('Could not find URDF: ' + urdf)  # reference model.py:63
 
-        if parent is not None:
-            raise NotImplementedError('child models (fixed constraints between bodies, reference model.py:69-77) '
-                                      'are not supported yet (SURVEY 8(f) N2)')
-
         self.robot = UrdfRobot(full)
         self.flat = FlatBody(self.robot, scale=scale, fixed_base=use_fixed_base,
                              mass_override=config.get('mass') if 'mass' in config else None,
                              mesh_loader=mesh.load_convex, max_hull_points=self.env.max_hull_points)
-        self.uid = self.env.builder.add_body(self.flat, self.position, self.orientation)
+        if parent is None:
+            self.uid = self.env.builder.add_body(self.flat, self.position, self.orientation)
+        else:
+            # Child model (reference model.py:69-77): the reference loads it as its own body and couples it to the
+            # parent with a fixed constraint whose pivot is this model's xyz / rpy in the parent frame.  Here the
+            # coupling is rigid -- the child is merged into the parent's body (FlatBody.attach) and ``uid`` is an
+            # alias the scene builder resolves to (parent body, link / frame offsets).
+            if 'child_frame' in config:
+                raise NotImplementedError('child_frame: only the base of a child model can be attached (the tree would '
+                                          'have to be re-rooted at that link)')
+            parent_frame_id = parent.get_frame_id(config.get('parent_frame')) if 'parent_frame' in config else -1
+            self.uid = self.env.builder.attach_child(parent.uid, parent_frame_id, self.flat, self.position, self.orientation)
         self.color = config.get('color') if 'color' in config else None  # visual only (camera rgb)
         if self.color is not None:
             self.env.builder.set_color(self.uid, list(self.color) + [1.0] * (4 - len(self.color)))
@@ -68,10 +75,11 @@ class Model(Receptor):
         self.addons = OrderedDict(
             sorted(((child.name, AddonFactory.build(child.get('addon'), self, child)) for child in config.find_all('addon')),
                    key=lambda kv: kv[0]))
-        children = list(config.find_all('model'))
-        if children:
-            raise NotImplementedError('child models (reference model.py:90-92) are not supported yet (SURVEY 8(f) N2)')
-        self.models = OrderedDict()
+        # child models (reference model.py:90-92).  As in the reference they are NOT receptors: their own addons are
+        # constructed but never stepped; they exist physically and can be named by the parent's sensors
+        # (``source_model`` / ``target_model``).
+        self.models = OrderedDict(sorted(((child.name, Model(child, parent=self)) for child in config.find_all('model')),
+                                         key=lambda kv: kv[0]))
 
     def get_frame_id(self, frame):
         """Joint index of the named frame, -1 when absent (reference model.py:94-96)."""
@@ -80,5 +88,9 @@ class Model(Receptor):
     def get_transform(self, frame_id=-1):
         """World pose of the URDF link frame (``getLinkState`` items 4, 5) or of the
         base (reference model.py:98-106) for every env: ``(xyz [B,3], quat [B,4])``."""
-        st = self.env.sim.frame_state(self.uid, frame_id, com=frame_id < 0)
+        body, _, foff, basef = self.env.builder.resolve(self.uid)
+        if body != self.uid:  # attached child: its frames live in the parent's body
+            st = self.env.sim.frame_state(body, basef if frame_id < 0 else foff + frame_id, com=frame_id < 0)
+        else:
+            st = self.env.sim.frame_state(self.uid, frame_id, com=frame_id < 0)
         return st[:, 0:3], st[:, 3:7]

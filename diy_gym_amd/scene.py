@@ -204,7 +204,8 @@ class SceneBuilder:
             if k not in self.params:
                 raise KeyError('unknown engine parameter: ' + k)
             self.params[k] = v
-        self.bodies = []  # (FlatBody, pos, quat)
+        self.bodies = []
+        self.aliases = {}  # (FlatBody, pos, quat)
         self.colors = []
         self.cameras = []  # (body, frame, width, height, flags, Transform, fov, near, far)
         self.ops = []
@@ -216,6 +217,21 @@ class SceneBuilder:
         self.term_groups = []
 
     # -- bodies ---------------------------------------------------------
+    ALIAS_BASE = 10000  # uids of attached child models (they own no body of their own)
+
+    def resolve(self, uid):
+        """``uid`` -> (body index, link offset, frame offset, frame that stands for the base or -1)."""
+        return self.aliases[uid] if uid in self.aliases else (uid, 0, 0, -1)
+
+    def attach_child(self, parent_uid, parent_frame, child_flat, pos, quat):
+        """Child model (reference model.py:69-77): merged rigidly into the parent's body (FlatBody.attach)."""
+        body, _, foff, basef = self.resolve(parent_uid)
+        pf = (basef if parent_frame < 0 else foff + parent_frame)
+        link_off, frame_off, base_frame = self.bodies[body][0].attach(child_flat, pf, Transform.from_xyz_quat(pos, quat))
+        uid = self.ALIAS_BASE + len(self.aliases)
+        self.aliases[uid] = (body, link_off, frame_off, base_frame)
+        return uid
+
     def add_body(self, flat, pos, quat):
         """``pos``/``quat``: pose of the root inertial frame, as passed to
         ``p.resetBasePositionAndOrientation`` (reference model.py:68)."""
@@ -227,10 +243,12 @@ class SceneBuilder:
         return len(self.bodies) - 1
 
     def set_color(self, body, rgba):
+        if body in self.aliases:
+            return  # colours are per body; an attached child keeps its parent's
         self.colors[body] = [float(v) for v in rgba]
 
     def add_camera(self, body, frame, width, height, flags, T_parent_cam, fov, near, far):
-        self.cameras.append((body, self.global_frame(body, frame) if body >= 0 else -1, int(width), int(height), int(flags),
+        self.cameras.append((self.resolve(body)[0] if body >= 0 else body, self.global_frame(body, frame) if body >= 0 else -1, int(width), int(height), int(flags),
                              T_parent_cam, float(fov), float(near), float(far)))
         return len(self.cameras) - 1
 
@@ -241,10 +259,14 @@ class SceneBuilder:
         return sum(len(b[0].frames) for b in self.bodies[:body])
 
     def global_link(self, body, dof):
-        return self.link_base(body) + dof
+        b, loff, _, _ = self.resolve(body)
+        return self.link_base(b) + loff + dof
 
     def global_frame(self, body, frame_id):
-        return -1 if frame_id < 0 else self.frame_base(body) + frame_id
+        b, _, foff, basef = self.resolve(body)
+        if frame_id < 0:
+            return -1 if basef < 0 else self.frame_base(b) + basef
+        return self.frame_base(b) + foff + frame_id
 
     # -- ops --------------------------------------------------------------
     def add_op(self, code, kind, body=-1, frame=-1, body2=-1, frame2=-1, flags=0, ilist=(), flist=(), fparams=(),
@@ -275,9 +297,11 @@ class SceneBuilder:
         fp = fp + [0.0] * (K.OF_STRIDE - len(fp))
         row = [0] * K.OI_STRIDE
         row[K.OI_CODE] = code
-        row[K.OI_BODY] = body
+        if body in self.aliases and code in (K.OP_RESPAWN, K.OP_EXTERNAL_FORCE, K.OP_PROPELLOR, K.OP_REW_ELECTRICITY, K.OP_TERM_TILT):
+            raise NotImplementedError('this addon acts on a whole body; an attached child model has none of its own')
+        row[K.OI_BODY] = self.resolve(body)[0] if body >= 0 else body
         row[K.OI_FRAME] = self.global_frame(body, frame) if body >= 0 else -1
-        row[K.OI_BODY2] = body2
+        row[K.OI_BODY2] = self.resolve(body2)[0] if body2 >= 0 else body2
         row[K.OI_FRAME2] = self.global_frame(body2, frame2) if body2 >= 0 else -1
         row[K.OI_FLAGS] = flags
         row[K.OI_N] = len(ilist) if n is None else int(n)

@@ -412,6 +412,63 @@ class FlatBody:
         self.joint_to_dof = [j.q_index for j in robot.joints]
         self.dof_to_joint = [fl.joint_index for fl in self.links]
 
+    def attach(self, child, parent_frame, T_rel):
+        """Bolt another flattened body onto this one (child models, reference model.py:69-77, where pybullet
+        couples the two with ``createConstraint(JOINT_FIXED)``).  [decision] The coupling is made rigid: the child's
+        base becomes part of the link that carries ``parent_frame`` (the base when negative), its joints, frames and
+        shapes are appended to this body.  ``T_rel`` is the pose of the child's base INERTIAL frame in the parent
+        link's INERTIAL frame -- the two frames ``createConstraint`` takes its pivots in [RECOLLECTION].
+
+        Returns ``(link_offset, frame_offset, base_frame)``: where the child's joints / frames start in this body and
+        the index of a new frame that stands for the child's base."""
+        import copy
+        if parent_frame >= 0:
+            anchor, T_anchor_pf = self.frames[parent_frame].link, self.frames[parent_frame].T_com
+        else:
+            anchor, T_anchor_pf = -1, self.T_base_report
+        T_attach = T_anchor_pf * T_rel * child.T_base_report.inverse()  # anchor link frame -> child's root link frame
+        link_off, frame_off = len(self.links), len(self.frames)
+
+        # inertia of the child's base joins the anchor link's
+        def combine(m1, c1, I1, m2, c2, I2):
+            m = m1 + m2
+            if m <= 0.0:
+                return 0.0, np.zeros(3), np.zeros((3, 3))
+            c = (m1 * c1 + m2 * c2) / m
+            shift = lambda mm, cc: mm * (np.dot(cc - c, cc - c) * np.eye(3) - np.outer(cc - c, cc - c))
+            return m, c, I1 + shift(m1, c1) + I2 + shift(m2, c2)
+        m2, c2 = child.base_mass, T_attach.apply(child.base_com)
+        I2 = T_attach.R @ child.base_inertia @ T_attach.R.T
+        if anchor >= 0:
+            fl = self.links[anchor]
+            fl.mass, fl.com, fl.inertia = combine(fl.mass, fl.com, fl.inertia, m2, c2, I2)
+        elif not self.fixed_base:
+            self.base_mass, self.base_com, self.base_inertia = combine(self.base_mass, self.base_com, self.base_inertia, m2, c2, I2)
+        for sh in child.shapes:
+            sh2 = copy.copy(sh)
+            if sh.link < 0:
+                sh2.link = anchor
+                sh2.T = T_attach * sh.T
+                if sh.points is not None:
+                    sh2.points = np.asarray(sh.points) @ T_attach.R.T + T_attach.p
+            else:
+                sh2.link = sh.link + link_off
+            self.shapes.append(sh2)
+        for fl in child.links:
+            fl2 = copy.copy(fl)
+            if fl.parent < 0:
+                fl2.parent, fl2.origin = anchor, T_attach * fl.origin
+            else:
+                fl2.parent = fl.parent + link_off
+            self.links.append(fl2)
+        for fr in child.frames:
+            if fr.link < 0:
+                self.frames.append(FlatFrame(fr.name, anchor, T_attach * fr.T, T_attach * fr.T_com))
+            else:
+                self.frames.append(FlatFrame(fr.name, fr.link + link_off, fr.T, fr.T_com))
+        self.frames.append(FlatFrame(child.base_name + '__attached_base', anchor, T_attach, T_attach * child.T_base_report))
+        return link_off, frame_off, len(self.frames) - 1
+
     @property
     def num_dofs(self):
         return len(self.links)

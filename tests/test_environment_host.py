@@ -162,3 +162,37 @@ def test_spawn_multiple_clones_into_parent_models():
     assert sorted(env.models[k].uid for k in ('ball_0', 'ball_1', 'ball_2')) == [1, 2, 3]
     obs = env.reset()
     assert obs['ball_1']['pose']['position'].shape == (2, 3)
+
+
+def test_child_model_is_bolted_to_the_parent_frame():
+    """Child models (reference model.py:69-77): physically present, attached at ``parent_frame`` with the child's
+    ``xyz`` / ``rpy`` as the pivot, not a receptor of their own (diy_gym.py:92 only lists top-level models)."""
+    from diy_gym_amd.mathx import Transform, mat_from_quat
+    env = DIYGym(os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'), num_envs=2, backend_factory=OracleBackend)
+    arm = env.models['arm']; grip = arm.models['gripper']
+    assert list(env.receptors) == ['arm', 'ur5_child_gripper'] or 'gripper' not in env.receptors
+    assert env.layout.n_bodies == 1 and env.layout.n_links == 6 + 6          # merged into the arm's body
+    assert grip.uid >= env.builder.ALIAS_BASE and env.builder.resolve(grip.uid)[0] == arm.uid
+    assert env.action_space['arm']['controller'].shape == (6, )                # the parent's addons see the arm only
+    for _ in range(25):
+        env.step(env.action_space.sample())
+    body, _, _, basef = env.builder.resolve(grip.uid)
+    pe = env.sim.frame_state64(arm.uid, arm.get_frame_id('ee_fixed_joint'), com=True)
+    pg = env.sim.frame_state64(body, basef, com=True)
+    for e in range(2):
+        Te = Transform(mat_from_quat(pe[e][3:7]), pe[e][:3]); Tg = Transform(mat_from_quat(pg[e][3:7]), pg[e][:3])
+        rel = Te.inverse() * Tg
+        assert np.allclose(rel.p, [0.0, 0.0, 0.02], atol=1e-9)
+        assert np.allclose(rel.R, [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-5)   # rpy = (0, pi/2, 0)
+    xyz, quat = grip.get_transform()
+    assert xyz.shape == (2, 3) and torch.isfinite(xyz).all() and torch.isfinite(quat).all()
+
+
+def test_child_frame_attachment_is_rejected_with_a_reason(tmp_path):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml')))
+    cfg['arm']['gripper']['child_frame'] = 'finger_joint'
+    path = tmp_path / 'c.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'))
+    with pytest.raises(NotImplementedError):
+        DIYGym(str(path), num_envs=1, backend_factory=OracleBackend)

@@ -19,6 +19,7 @@ CONFIGS = {
     'readme': os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml'),
     'admittance': os.path.join(ROOT, 'tests', 'golden', 'ur_admittance.yaml'),
     'gripper': os.path.join(ROOT, 'tests', 'golden', 'ur5_gripper.yaml'),
+    'child': os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'),
 }
 
 
@@ -112,6 +113,13 @@ def test_ur5_with_two_finger_gripper_asset_40_steps():
     gpu, cpu = make_pair('gripper', 5)
     w = rollout(gpu, cpu, 40, scale=0.5)
     assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+
+
+def test_child_model_gripper_40_steps():
+    # robotiq_2f attached as a child model to the UR5's flange: one 12-DoF tree, no contacts
+    gpu, cpu = make_pair('child', 5)
+    w = rollout(gpu, cpu, 40)
+    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
 
 
 def test_drone_pilot_60_steps():

@@ -196,3 +196,40 @@ def test_child_frame_attachment_is_rejected_with_a_reason(tmp_path):
     yaml.safe_dump(cfg, open(path, 'w'))
     with pytest.raises(NotImplementedError):
         DIYGym(str(path), num_envs=1, backend_factory=OracleBackend)
+
+
+def test_child_model_on_a_floating_parent_merges_inertia(tmp_path):
+    """Two 10 kg spheres bolted one metre apart fall as ONE body of 20 kg with its centre of mass half way."""
+    import yaml
+    from diy_gym_amd.scene import K
+    cfg = {'render': False,
+           'a': {'model': 'sphere2.urdf', 'xyz': [0.0, 0.0, 5.0],
+                 'state': {'addon': 'object_state_sensor', 'include_velocity': True},
+                 'b': {'model': 'sphere2.urdf', 'xyz': [1.0, 0.0, 0.0]}}}
+    path = tmp_path / 'pair.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'))
+    env = DIYGym(str(path), num_envs=1, backend_factory=OracleBackend, engine=dict(linear_damping=0.0, angular_damping=0.0))
+    L = env.layout
+    bf = L.F[L.I[K.H_OFF_BODY_F]:L.I[K.H_OFF_BODY_F] + K.BF_STRIDE]
+    assert L.n_bodies == 1 and abs(bf[K.BF_MASS] - 20.0) < 1e-12
+    assert np.allclose(bf[K.BF_COM:K.BF_COM + 3], [0.5, 0.0, 0.0], atol=1e-12)
+    # inertia about the common centre: 2 x (1 about own centre) + 2 x 10 kg x (0.5 m)^2 about y and z
+    assert np.allclose([bf[K.BF_INERTIA], bf[K.BF_INERTIA + 3], bf[K.BF_INERTIA + 5]], [2.0, 7.0, 7.0], atol=1e-12)
+    for _ in range(24):
+        o, _, _, _ = env.step({})
+    v = o['a']['state']['velocity'][0].numpy()
+    assert abs(v[2] + 9.81 * 25 / 240.0) < 1e-6 and abs(v[0]) < 1e-9 and abs(v[1]) < 1e-9   # free fall (24 + 1 hot-start step), no spin-up
+
+
+def test_three_finger_gripper_asset_loads_and_steps():
+    import yaml, tempfile
+    cfg = {'render': False, 'arm': {'model': 'ur5/ur5_3f.urdf', 'use_fixed_base': True,
+                                    'joints': {'addon': 'joint_state_sensor'}}}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'g3.yaml')
+        yaml.safe_dump(cfg, open(path, 'w'))
+        env = DIYGym(path, num_envs=1, backend_factory=OracleBackend)
+        assert env.layout.n_links == 17
+        for _ in range(10):
+            o, _, _, _ = env.step({})
+        assert torch.isfinite(o['arm']['joints']['position']).all()

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
       __syncthreads();  // B1: every pose is in LDS
       if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln);  // contact list + count go to LDS; the main wave reads them after B2
       __syncthreads();  // B2
-      if (split_sweeps_follow(ln)) { pgs_reg_split(ln, -1, 0, split_slots(sc)); __syncthreads(); /* Bp */ }
+      if (split_decide_follow(ln, false, false)) pgs_reg_split(ln, -1, 0, split_slots(sc));
       __syncthreads();  // B3
     }
     __syncthreads();  // B4

@@ -872,24 +872,103 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
 }
 
-// Five workspace slots for the exchange (4) and the decision flag (1): the tail of the padding behind the velocity-
-// change blocks (nv_max + 8 slots; readers of that padding only ever multiply it by zero, and these values are finite).
+// ---- motor and joint-limit rows of the links [g0, g1) ---------------------------------------------------------------
+// Links in chunks: all the state loads of a chunk are issued before the first LDS store (a link at a time would pay
+// one global round trip per link).
+template <int LANES>
+DGD void setup_link_rows(const Lane<LANES>& ln, int g0, int g1, uint64_t& limit_mask, uint64_t& limit_rows) {
+  const DevScene& sc = ln.sc; const float h = sc.h, lerp = sc.HF[DG_HF_LIMIT_ERP];
+  constexpr int LCH = 6;
+  for (int gc = g0; gc < g1; gc += LCH) {
+    float q_[LCH], qd_[LCH], tp_[LCH], tv_[LCH];
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int gl = min(gc + j, g1 - 1), lo = ln.li(gl)[DG_LI_STATE_OFF];
+      q_[j] = ln.S(lo + DG_LS_Q); qd_[j] = ln.S(lo + DG_LS_QD); tp_[j] = ln.S(lo + DG_LS_TARGET_POS); tv_[j] = ln.S(lo + DG_LS_TARGET_VEL);
+    }
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int gl = gc + j; if (gl >= g1) break;
+      const int mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
+      const float q = q_[j], qd = qd_[j];
+      const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
+      ln.L(mo + MR_B) = kp * (tp_[j] - q) / h + kd * (tv_[j] - qd);
+      ln.L(mo + MR_ACC) = 0.f;
+      const bool limited = f[DG_LF_LOWER] <= f[DG_LF_UPPER];
+      const float dlo = q - f[DG_LF_LOWER], dhi = f[DG_LF_UPPER] - q;
+      // acc < 0 marks an inactive limit row
+      ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
+      ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
+      if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
+      if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
+    }
+  }
+}
+
+// ---- apply the velocity change of body b and integrate its positions ---------------------------------------------------
+template <int LANES>
+DGD void integrate_body(const Lane<LANES>& ln, int b) {
+  const DevScene& sc = ln.sc; const float h = sc.h, vmax = sc.HF[DG_HF_MAX_COORD_VEL];
+  constexpr int LCH = 6;
+  cip B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
+  const bool fx = ln.fixed(b); if (fx && n == 0) return;
+  const int dvo = ln.plb(b)[PLB_DV];
+  if (!fx) {
+    M3 R0 = ln.LR(ln.plb(b)[PLB_R0]);
+    V3 dw = mul(R0, ln.L3(dvo)), dl = mul(R0, ln.L3(dvo + 3));
+    V3 w = v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2)) + dw;
+    V3 v = v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)) + dl;
+    ln.Sset(so + DG_BS_ANGVEL, w.x); ln.Sset(so + DG_BS_ANGVEL + 1, w.y); ln.Sset(so + DG_BS_ANGVEL + 2, w.z);
+    ln.Sset(so + DG_BS_LINVEL, v.x); ln.Sset(so + DG_BS_LINVEL + 1, v.y); ln.Sset(so + DG_BS_LINVEL + 2, v.z);
+    ln.Sset(so, ln.S(so) + h * v.x); ln.Sset(so + 1, ln.S(so + 1) + h * v.y); ln.Sset(so + 2, ln.S(so + 2) + h * v.z);
+    float wn = norm(w), th = wn * h; Q4 dq;
+    if (th > 1e-12f) { float sn, cs; sincosf(0.5f * th, &sn, &cs); sn /= wn; dq.x = w.x * sn; dq.y = w.y * sn; dq.z = w.z * sn; dq.w = cs; }
+    else { dq.x = 0.5f * h * w.x; dq.y = 0.5f * h * w.y; dq.z = 0.5f * h * w.z; dq.w = 1.f; }
+    Q4 qn = qnormalize(qmul(dq, ln.base_quat(b)));
+    ln.Sset(so + 3, qn.x); ln.Sset(so + 4, qn.y); ln.Sset(so + 5, qn.z); ln.Sset(so + 6, qn.w);
+  }
+  const int k0 = fx ? 0 : 6;
+  for (int i0 = 0; i0 < n; i0 += LCH) {  // loads of a chunk first, then its stores (state loads cannot pass state stores)
+    float q_[LCH], qd_[LCH], dv_[LCH], ac_[LCH]; int lo_[LCH];
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int i = min(i0 + j, n - 1); lo_[j] = ln.li(first + i)[DG_LI_STATE_OFF];
+      q_[j] = ln.S(lo_[j] + DG_LS_Q); qd_[j] = ln.S(lo_[j] + DG_LS_QD); dv_[j] = ln.L(dvo + k0 + i); ac_[j] = ln.L(ln.pll(first + i)[PLL_MROW] + MR_ACC);
+    }
+#pragma unroll
+    for (int j = 0; j < LCH; j++) {
+      const int i = i0 + j; if (i >= n) break;
+      const float maxf = ln.mt.v[3 * (first + i) + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+      ln.Sset(lo_[j] + DG_LS_APPLIED, maximp > 0.f ? ac_[j] / h : 0.f);
+      const float qd = fminf(fmaxf(qd_[j] + dv_[j], -vmax), vmax);
+      ln.Sset(lo_[j] + DG_LS_QD, qd); ln.Sset(lo_[j] + DG_LS_Q, q_[j] + h * qd);
+    }
+  }
+}
+
+// Six workspace slots for the residual exchange (4) and the two decision flags: the tail of the padding behind the
+// velocity-change blocks (nv_max + 8 slots; readers of that padding only ever multiply it by zero, and these values
+// are finite).
 DGD int split_slots(const DevScene& sc) { return sc.dv_base + sc.nt + sc.nv_max; }
 
-// Main-wave side of the per-substep decision (helper-wave kernel): publish whether this substep's sweeps are split.
-// Everything it depends on is wave-uniform; the other wavefronts read the flag after the barrier.
+// Per-substep decision of the helper-wave kernel: are this substep's sweeps split?  The main wave publishes "no
+// contact and no active limit row on my bodies", the helper "no active limit row on my body" (it has just set up its
+// own rows); after one barrier every wavefront of the workgroup reads both and reaches the same verdict.
 template <int LANES>
-DGD bool split_sweeps(const Lane<LANES>& ln, int wave_max_cont, uint64_t limit_mask) {
-  const DevScene& sc = ln.sc;
-  bool ok = sc.split_pgs && wave_max_cont == 0 && limit_mask == 0ull;
-  ln.L(split_slots(sc) + 4) = ok ? 1.f : 0.f;  // every lane stores the same value into its own column
+DGD bool split_decide_main(const Lane<LANES>& ln, int wave_max_cont, uint64_t& limit_mask) {
+  const DevScene& sc = ln.sc; const int xo = split_slots(sc);
+  ln.L(xo + 4) = (sc.split_pgs && wave_max_cont == 0 && limit_mask == 0ull) ? 1.f : 0.f;  // same value in every lane's column
   __syncthreads();  // Bq
-  return ok;
+  const bool helper_limit = ln.L(xo + 5) != 0.f;
+  if (helper_limit) limit_mask |= 1ull << (sc.helper_body & 63);  // the single-wave sweeps handle those rows
+  return ln.L(xo + 4) != 0.f && !helper_limit;
 }
 template <int LANES>
-DGD bool split_sweeps_follow(const Lane<LANES>& ln) {
+DGD bool split_decide_follow(const Lane<LANES>& ln, bool my_limit_rows_active, bool i_am_helper) {
+  const DevScene& sc = ln.sc; const int xo = split_slots(sc);
+  if (i_am_helper) ln.L(xo + 5) = my_limit_rows_active ? 1.f : 0.f;
   __syncthreads();  // Bq
-  return ln.L(split_slots(ln.sc) + 4) != 0.f;
+  return ln.L(xo + 4) != 0.f && ln.L(xo + 5) == 0.f;
 }
 
 // ---- register-chain sweeps split across the wavefronts of the helper-wave kernel -------------------------------
@@ -985,33 +1064,12 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
   if (!own_collide) ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront before B2
   // ---- motor and joint-limit rows (per link, uniform)
-  const float lerp = sc.HF[DG_HF_LIMIT_ERP];
-  // links in chunks: all the state loads of a chunk are issued before the first LDS store (a link at a time would
-  // pay one global round trip per link)
-  for (int g0 = 0; g0 < sc.nl; g0 += LCH) {
-    float q_[LCH], qd_[LCH], tp_[LCH], tv_[LCH];
-#pragma unroll
-    for (int j = 0; j < LCH; j++) {
-      const int gl = min(g0 + j, sc.nl - 1), lo = ln.li(gl)[DG_LI_STATE_OFF];
-      q_[j] = ln.S(lo + DG_LS_Q); qd_[j] = ln.S(lo + DG_LS_QD); tp_[j] = ln.S(lo + DG_LS_TARGET_POS); tv_[j] = ln.S(lo + DG_LS_TARGET_VEL);
-    }
-#pragma unroll
-    for (int j = 0; j < LCH; j++) {
-      const int gl = g0 + j; if (gl >= sc.nl) break;
-      const int mo = ln.pll(gl)[PLL_MROW]; cfp f = ln.lf(gl);
-      const float q = q_[j], qd = qd_[j];
-      const float kp = ln.mt.v[3 * gl], kd = ln.mt.v[3 * gl + 1];
-      ln.L(mo + MR_B) = kp * (tp_[j] - q) / h + kd * (tv_[j] - qd);
-      ln.L(mo + MR_ACC) = 0.f;
-      const bool limited = f[DG_LF_LOWER] <= f[DG_LF_UPPER];
-      const float dlo = q - f[DG_LF_LOWER], dhi = f[DG_LF_UPPER] - q;
-      // acc < 0 marks an inactive limit row
-      ln.L(mo + MR_LO_B) = -qd + (dlo > 0.f ? -dlo / h : -dlo * lerp / h); ln.L(mo + MR_LO_ACC) = (limited && dlo < 0.25f) ? 0.f : -1.f;
-      ln.L(mo + MR_HI_B) = qd + (dhi > 0.f ? -dhi / h : -dhi * lerp / h); ln.L(mo + MR_HI_ACC) = (limited && dhi < 0.25f) ? 0.f : -1.f;
-      if (__any(limited && (dlo < 0.25f || dhi < 0.25f))) limit_mask |= 1ull << (ln.li(gl)[DG_LI_BODY] & 63);
-      if (gl < 32) { if (__any(limited && dlo < 0.25f)) limit_rows |= 1ull << (2 * gl); if (__any(limited && dhi < 0.25f)) limit_rows |= 2ull << (2 * gl); }
-    }
-  }
+  // (the helper wave sets up the rows of its own body when the sweeps can be split)
+  const bool helper_rows = PAR && sc.split_pgs;
+  if (helper_rows) {
+    const int hf = ln.bi(hb)[DG_BI_FIRST_LINK], hn = ln.bi(hb)[DG_BI_N_LINKS];
+    setup_link_rows(ln, 0, hf, limit_mask, limit_rows); setup_link_rows(ln, hf + hn, sc.nl, limit_mask, limit_rows);
+  } else setup_link_rows(ln, 0, sc.nl, limit_mask, limit_rows);
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   // all-dense scenes: the sweeps start from a zero velocity change held in registers, so until they finish the LDS
   // velocity-change blocks are free -- park the generalised velocities there for the row right-hand sides
@@ -1033,6 +1091,8 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   prof.stamp(PS_ROWS);
   }  // primary
   // ---- projected Gauss-Seidel
+  bool split_now = false;
+  if constexpr (PAR) split_now = split_decide_main(ln, wave_max_cont, limit_mask);
   const bool all_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
   if constexpr (SLICED) {  // wave-uniform results of the primary lanes, for every lane
     wave_max_cont = __builtin_amdgcn_readfirstlane(wave_max_cont);
@@ -1050,9 +1110,8 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       else if (sc.nt <= 24) iters_done = pgs_dense_sliced_global<LANES, 24, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
       else iters_done = pgs_dense_sliced_global<LANES, 32, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
     }
-  } else if (PAR && split_sweeps(ln, wave_max_cont, limit_mask)) {
+  } else if (PAR && split_now) {
     iters_done = pgs_reg_split(ln, sc.reg_body[0], 0, split_slots(sc));
-    __syncthreads();  // Bp: the helper's velocity changes and impulses are in LDS
   } else if (primary) {
   bool live = ln.valid;
   if (all_dense) {
@@ -1172,43 +1231,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (primary) {
   if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
   // ---- apply velocity changes and integrate positions
-  const float vmax = sc.HF[DG_HF_MAX_COORD_VEL];
-  for (int b = 0; b < sc.nb; b++) {
-    cip B = ln.bi(b); const int n = B[DG_BI_N_LINKS], first = B[DG_BI_FIRST_LINK], so = B[DG_BI_STATE_OFF];
-    const bool fx = ln.fixed(b); if (fx && n == 0) continue;
-    const int dvo = ln.plb(b)[PLB_DV];
-    if (!fx) {
-      M3 R0 = ln.LR(ln.plb(b)[PLB_R0]);
-      V3 dw = mul(R0, ln.L3(dvo)), dl = mul(R0, ln.L3(dvo + 3));
-      V3 w = v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2)) + dw;
-      V3 v = v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)) + dl;
-      ln.Sset(so + DG_BS_ANGVEL, w.x); ln.Sset(so + DG_BS_ANGVEL + 1, w.y); ln.Sset(so + DG_BS_ANGVEL + 2, w.z);
-      ln.Sset(so + DG_BS_LINVEL, v.x); ln.Sset(so + DG_BS_LINVEL + 1, v.y); ln.Sset(so + DG_BS_LINVEL + 2, v.z);
-      ln.Sset(so, ln.S(so) + h * v.x); ln.Sset(so + 1, ln.S(so + 1) + h * v.y); ln.Sset(so + 2, ln.S(so + 2) + h * v.z);
-      float wn = norm(w), th = wn * h; Q4 dq;
-      if (th > 1e-12f) { float sn, cs; sincosf(0.5f * th, &sn, &cs); sn /= wn; dq.x = w.x * sn; dq.y = w.y * sn; dq.z = w.z * sn; dq.w = cs; }
-      else { dq.x = 0.5f * h * w.x; dq.y = 0.5f * h * w.y; dq.z = 0.5f * h * w.z; dq.w = 1.f; }
-      Q4 qn = qnormalize(qmul(dq, ln.base_quat(b)));
-      ln.Sset(so + 3, qn.x); ln.Sset(so + 4, qn.y); ln.Sset(so + 5, qn.z); ln.Sset(so + 6, qn.w);
-    }
-    const int k0 = fx ? 0 : 6;
-    for (int i0 = 0; i0 < n; i0 += LCH) {  // loads of a chunk first, then its stores (state loads cannot pass state stores)
-      float q_[LCH], qd_[LCH], dv_[LCH], ac_[LCH]; int lo_[LCH];
-#pragma unroll
-      for (int j = 0; j < LCH; j++) {
-        const int i = min(i0 + j, n - 1); lo_[j] = ln.li(first + i)[DG_LI_STATE_OFF];
-        q_[j] = ln.S(lo_[j] + DG_LS_Q); qd_[j] = ln.S(lo_[j] + DG_LS_QD); dv_[j] = ln.L(dvo + k0 + i); ac_[j] = ln.L(ln.pll(first + i)[PLL_MROW] + MR_ACC);
-      }
-#pragma unroll
-      for (int j = 0; j < LCH; j++) {
-        const int i = i0 + j; if (i >= n) break;
-        const float maxf = ln.mt.v[3 * (first + i) + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
-        ln.Sset(lo_[j] + DG_LS_APPLIED, maximp > 0.f ? ac_[j] / h : 0.f);
-        const float qd = fminf(fmaxf(qd_[j] + dv_[j], -vmax), vmax);
-        ln.Sset(lo_[j] + DG_LS_QD, qd); ln.Sset(lo_[j] + DG_LS_Q, q_[j] + h * qd);
-      }
-    }
-  }
+  for (int b = 0; b < sc.nb; b++) if (!(split_now && b == hb)) integrate_body(ln, b);  // split sweeps: the helper integrates its own body
   }  // primary
   if (PAR) __syncthreads();  // B3: positions integrated; the helper may start the next substep
 }
@@ -1224,7 +1247,9 @@ DGD void helper_substep(const Lane<LANES>& ln, bool early) {
     const int dvo = ln.plb(hb)[PLB_DV], nv = ln.plb(hb)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
   __syncthreads();  // B2
-  if (split_sweeps_follow(ln)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); __syncthreads(); /* Bp */ }
+  uint64_t lm = 0ull, lr = 0ull;
+  if (sc.split_pgs) { const int hf = ln.bi(hb)[DG_BI_FIRST_LINK]; setup_link_rows(ln, hf, hf + ln.bi(hb)[DG_BI_N_LINKS], lm, lr); }
+  if (split_decide_follow(ln, lm != 0ull, true)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); integrate_body(ln, hb); }
   __syncthreads();  // B3
 }
 

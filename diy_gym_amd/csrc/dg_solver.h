@@ -1623,15 +1623,37 @@ DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
 template <int LANES>
 DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag) {
   const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
+  // a reach_target addon emits a reward op and a terminal op on the same pair of frames: the distance is computed once
+  int rk_a = -2, rk_b = -2, rk_c = -2, rk_d = -2; float rk_dist = 0.f;
+  auto reach = [&](cip oi) {
+    if (oi[DG_OI_BODY] != rk_a || oi[DG_OI_FRAME] != rk_b || oi[DG_OI_BODY2] != rk_c || oi[DG_OI_FRAME2] != rk_d) {
+      rk_dist = reach_dist(ln, oi); rk_a = oi[DG_OI_BODY]; rk_b = oi[DG_OI_FRAME]; rk_c = oi[DG_OI_BODY2]; rk_d = oi[DG_OI_FRAME2];
+    }
+    return rk_dist;
+  };
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE;
     const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST];
     if (code == DG_OP_OBS_JOINT_STATE) {
       const int n = oi[DG_OI_N]; int k2 = n;
       if (obs) {
-        for (int k = 0; k < n; k++) obs[io + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_Q);
-        if (oi[DG_OI_FLAGS] & DG_JS_VELOCITY) { for (int k = 0; k < n; k++) obs[io + k2 + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_QD); k2 += n; }
-        if (oi[DG_OI_FLAGS] & DG_JS_EFFORT) for (int k = 0; k < n; k++) obs[io + k2 + k] = ln.S(ln.li(il[k])[DG_LI_STATE_OFF] + DG_LS_APPLIED);
+        // six joints at a time, every state load before the first store (the compiler must assume that a store to
+        // `obs` may alias the state, so a load-store-load chain would pay one global round trip per value)
+        const bool wv = oi[DG_OI_FLAGS] & DG_JS_VELOCITY, we = oi[DG_OI_FLAGS] & DG_JS_EFFORT;
+        const int ov = n, oe = wv ? 2 * n : n; (void)k2;
+        for (int k0 = 0; k0 < n; k0 += 6) {
+          float q_[6], v_[6], e_[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const int lo = ln.li(il[min(k0 + j, n - 1)])[DG_LI_STATE_OFF];
+            q_[j] = ln.S(lo + DG_LS_Q); v_[j] = wv ? ln.S(lo + DG_LS_QD) : 0.f; e_[j] = we ? ln.S(lo + DG_LS_APPLIED) : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            const int k = k0 + j; if (k >= n) break;
+            obs[io + k] = q_[j]; if (wv) obs[io + ov + k] = v_[j]; if (we) obs[io + oe + k] = e_[j];
+          }
+        }
       }
     } else if (code == DG_OP_OBS_OBJECT_STATE) {
       V3 p, v, w; Q4 q; const bool wv = oi[DG_OI_FLAGS] & DG_OS_VELOCITY;
@@ -1648,7 +1670,7 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
       }
     } else if (code == DG_OP_OBS_ADDON_STATE) {
       if (obs) for (int k = 0; k < oi[DG_OI_N]; k++) obs[io + k] = ln.S(sc.addon_off + oi[DG_OI_STATE_OFF] + k);
-    } else if (code == DG_OP_REW_REACH) { float r = -reach_dist(ln, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
+    } else if (code == DG_OP_REW_REACH) { float r = -reach(oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
     else if (code == DG_OP_REW_ELECTRICITY) {
       cip B = ln.bi(oi[DG_OI_BODY]); float acc = 0.f;
       for (int i = 0; i < B[DG_BI_N_LINKS]; i++) { const int lo = ln.li(B[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabsf(ln.S(lo + DG_LS_APPLIED) * ln.S(lo + DG_LS_QD)); }
@@ -1656,7 +1678,7 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
     } else if (code == DG_OP_REW_CONST) { if (rew) rew[io] = of[0]; rsum += of[0]; }
     else if (code == DG_OP_TERM_REACH || code == DG_OP_TERM_TILT || code == DG_OP_TERM_TIMER) {
       bool t;
-      if (code == DG_OP_TERM_REACH) t = reach_dist(ln, oi) < of[1];
+      if (code == DG_OP_TERM_REACH) t = reach(oi) < of[1];
       else if (code == DG_OP_TERM_TILT) {
         V3 p, v, w; Q4 q; ln.frame_state(oi[DG_OI_BODY], -1, true, p, q, v, w, false);
         t = 2.0f * atan2f(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z), fabsf(q.w)) > of[0];

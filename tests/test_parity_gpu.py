@@ -200,6 +200,8 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('readme', 'DG_NO_SLICED_GLOBAL', '1', 0, 30, 2e-3),  # 64 envs per wavefront from the global workspace, unsliced dense sweeps
     ('ur_ik', 'DG_NO_HELPER_WAVE', '1', 64, 30, 5e-4),    # single-wavefront step kernel
     ('ur_ik', 'DG_NO_EARLY_DYNAMICS', '1', 64, 30, 5e-4),
+    ('ur_ik', 'DG_NO_COLLIDE_WAVE', '1', 64, 30, 5e-4),    # main wave runs the narrow phase itself
+    ('ur_ik', 'DG_NO_SPLIT_SWEEPS', '1', 64, 30, 5e-4),    # main wave sweeps both arms
 ])
 def test_alternative_workspace_modes(name, env_var, value, lanes, steps, tol):
     # every scene normally takes ONE path through the mode selection; force the others

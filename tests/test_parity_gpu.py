@@ -20,6 +20,7 @@ CONFIGS = {
     'admittance': os.path.join(ROOT, 'tests', 'golden', 'ur_admittance.yaml'),
     'gripper': os.path.join(ROOT, 'tests', 'golden', 'ur5_gripper.yaml'),
     'child': os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'),
+    'touching': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching.yaml'),
 }
 
 
@@ -120,6 +121,17 @@ def test_child_model_gripper_40_steps():
     gpu, cpu = make_pair('child', 5)
     w = rollout(gpu, cpu, 40)
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+
+
+def test_arms_in_contact_30_steps():
+    # the two arms start with crossed forearms: contacts between two register-chain bodies, so the three-wavefront
+    # kernel takes its single-wave sweeps with dense contact rows (and switches to split sweeps once they separate)
+    gpu, cpu = make_pair('touching', 37)
+    d = gpu.sim.enable_diagnostics()
+    gpu.sim.step(gpu._all_slots, torch.zeros((37, 12), device=gpu.device)); cpu.sim.step(cpu._all_slots, torch.zeros((37, 12)))
+    assert int(d[:, 0].max()) >= 1 and d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(37)]
+    w = rollout(gpu, cpu, 30, scale=0.3)
+    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
 
 
 def test_drone_pilot_60_steps():

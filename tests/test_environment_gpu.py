@@ -56,6 +56,19 @@ def test_full_size_ur_high_5_is_deterministic_and_finite():
     assert float(q.abs().max()) < 2 * np.pi
 
 
+@pytest.mark.parametrize('cfg,B,steps', [
+    (os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml'), 4096, 30),              # BASELINE config 2 at its size
+    (os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml'), 1024, 30),   # config 5 (contacts by step ~15)
+    (os.path.join(ROOT, 'examples', 'drone_pilot', 'drone_pilot.yaml'), 16384, 20),          # config 4, one GPU's shard
+])
+def test_full_size_configs_are_deterministic_and_finite(cfg, B, steps):
+    # size-independent properties at the BASELINE sizes: bitwise repeatability and finite state / outputs
+    a = run(cfg, B, steps)
+    b = run(cfg, B, steps)
+    assert torch.equal(a.sim.state, b.sim.state) and torch.equal(a.sim.obs, b.sim.obs)
+    assert bool(torch.isfinite(a.sim.state[:, :B]).all()) and bool(torch.isfinite(a.sim.obs).all())
+
+
 def test_shards_equal_whole_batch():
     whole = run(DRONE, 512, 15).sim.get_state()
     parts = [run(DRONE, 256, 15, base=b, total=512).sim.get_state() for b in (0, 256)]

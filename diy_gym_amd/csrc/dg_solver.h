@@ -1389,6 +1389,14 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
       for (int k = 0; k < 3; k++) { cP[i][k] = pin(f[DG_LF_POS + k]); cA[i][k] = pin(f[DG_LF_AXIS + k]); }
     }
   }
+  // null-space constants per joint, pinned like the chain constants (the loop would otherwise re-fetch 24 scalars
+  // through the scalar cache every iteration)
+  float nRest[N], nLo[N], nHi[N], nIrg[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    nRest[i] = 0.f; nLo[i] = -3.0e38f; nHi[i] = 3.0e38f; nIrg[i] = 0.f;
+    if (nullsp && i < n) { nRest[i] = pin(rest[i]); nLo[i] = pin(rest[n + i]); nHi[i] = pin(rest[2 * n + i]); nIrg[i] = pin(frcp(rest[3 * n + i])); }
+  }
   V3 pe; M3 Re;  // end-effector point and LINK rotation (the frame offset is folded into the target below)
   auto fk = [&]() {
     M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
@@ -1451,11 +1459,9 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
       v0[i] = 0.f;
       if (i < n) {
         if (nullsp) {
-          const float lo = rest[n + i], hi = rest[2 * n + i], rg = rest[3 * n + i];
-          v0[i] = g0 * (rest[i] - q[i]);
-          const float irg = frcp(rg);
-          if (q[i] > hi) v0[i] += g1 * (hi - q[i]) * irg;
-          if (q[i] < lo) v0[i] += g1 * (lo - q[i]) * irg;
+          v0[i] = g0 * (nRest[i] - q[i]);
+          if (q[i] > nHi[i]) v0[i] += g1 * (nHi[i] - q[i]) * nIrg[i];
+          if (q[i] < nLo[i]) v0[i] += g1 * (nLo[i] - q[i]) * nIrg[i];
         }
         if (i <= eel) {
           float col[6]; column(i, col);

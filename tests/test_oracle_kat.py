@@ -354,3 +354,29 @@ def test_joint_limit_stops_a_falling_link():
     for qi, lo, up in lim:
         q = st[link_q(env, list(env.models).index('cart'), qi)]
         assert lo - 2e-3 <= q <= up + 2e-3, (qi, q, lo, up)
+
+
+def test_head_on_collision_is_inelastic_and_conserves_momentum(tmp_path):
+    """No gravity, no plane: a 10 kg sphere pushed to 1 m/s runs into an identical sphere at rest.  The contact row
+    removes the approach velocity and never pulls (restitution 0, impulse >= 0): afterwards both move at v/2 and the
+    total momentum is what the push put in."""
+    import yaml
+    cfg = {'render': False, 'gravity': [0.0, 0.0, 0.0],
+           'a': {'model': 'sphere2.urdf', 'xyz': [-1.0, 0.0, 0.0], 'push': {'addon': 'external_force', 'xyz': [-1.0, 0.0, 0.0]},
+                 'state': {'addon': 'object_state_sensor', 'include_velocity': True}},
+           'b': {'model': 'sphere2.urdf', 'xyz': [0.6, 0.0, 0.0],
+                 'state': {'addon': 'object_state_sensor', 'include_velocity': True}}}
+    path = tmp_path / 'hit.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'))
+    env = make(str(path), **NODAMP)
+    # 24 steps of 100 N on 10 kg: 1 m/s (the push point is a world point: the ball has moved only 5 cm, and a force
+    # along x through a point on the x axis exerts no torque anyway)
+    for _ in range(24):
+        o, _, _, _ = env.step({'a': {'push': torch.tensor([[100.0, 0.0, 0.0]])}})
+    va = float(o['a']['state']['velocity'][0, 0]); assert abs(va - 1.0) < 1e-6
+    for _ in range(240):
+        o, _, _, _ = env.step({'a': {'push': torch.zeros(1, 3)}})
+    va, vb = float(o['a']['state']['velocity'][0, 0]), float(o['b']['state']['velocity'][0, 0])
+    assert abs((va + vb) - 1.0) < 1e-6                      # momentum (equal masses)
+    assert abs(va - 0.5) < 2e-3 and abs(vb - 0.5) < 2e-3    # perfectly inelastic: common velocity
+    assert vb >= va - 1e-6                                  # separating or together, never interpenetrating further

@@ -300,43 +300,6 @@ DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, 
   const float res = delta * diag; return res * res;
 }
 
-// Dense-row contact sweeps (total DoF of the scene <= 32): the whole velocity change lives in registers for the
-// normal and friction sweeps of one iteration; a row costs ONE batched LDS round trip (its J, R, b, acc, diag --
-// none of which depends on the running solution) instead of five dependent ones.
-template <int LANES>
-DGD float contact_sweeps_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, bool live) {
-  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; float maxres = 0.f;
-  float dv[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) dv[k] = k < nt ? ln.L(sc.dv_base + k) : 0.f;
-  auto row = [&](int ro, float lo, float hi) {
-    float J[32], R[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) { J[k] = k < nt ? ln.L(ro + k) : 0.f; R[k] = k < nt ? ln.L(ro + nt + k) : 0.f; }
-    const float b = ln.L(ro + 2 * nt), acc = ln.L(ro + 2 * nt + 1), diag = ln.L(ro + 2 * nt + 2);
-    float jv = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; k++) jv += J[k] * dv[k];
-    float delta = (b - jv) / diag;
-    const float nacc = fminf(fmaxf(acc + delta, lo), hi);
-    delta = live && diag > 1e-18f ? nacc - acc : 0.f;
-    ln.L(ro + 2 * nt + 1) = acc + delta;
-#pragma unroll
-    for (int k = 0; k < 32; k++) dv[k] += R[k] * delta;
-    const float res = delta * diag; maxres = fmaxf(maxres, res * res);
-  };
-  for (int c = 0; c < wave_max_cont; c++) if (c < ncont) row(sc.tr_off + (3 * c) * rs, 0.f, 3.0e38f);
-  for (int c = 0; c < wave_max_cont; c++) {
-    if (c < ncont) {
-      const float mu = ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU);
-      if (mu > 0.f) { const float lim = mu * ln.L(sc.tr_off + (3 * c) * rs + 2 * nt + 1); row(sc.tr_off + (3 * c + 1) * rs, -lim, lim); row(sc.tr_off + (3 * c + 2) * rs, -lim, lim); }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 32; k++) if (k < nt) ln.L(sc.dv_base + k) = dv[k];
-  return maxres;
-}
-
 // ---- motor / joint-limit rows of one body, one Gauss-Seidel sweep ------------------------------------
 // generic version: any body, everything through LDS
 template <int LANES, bool LIMITS>
@@ -955,20 +918,22 @@ DGD int split_slots(const DevScene& sc) { return sc.dv_base + sc.nt + sc.nv_max;
 // contact and no active limit row on my bodies", the helper "no active limit row on my body" (it has just set up its
 // own rows); after one barrier every wavefront of the workgroup reads both and reaches the same verdict.
 template <int LANES>
-DGD bool split_decide_main(const Lane<LANES>& ln, int wave_max_cont, uint64_t& limit_mask) {
+DGD bool split_decide_main(const Lane<LANES>& ln, int wave_max_cont, uint64_t& limit_mask, uint64_t& limit_rows) {
   const DevScene& sc = ln.sc; const int xo = split_slots(sc);
-  ln.L(xo + 4) = (sc.split_pgs && wave_max_cont == 0 && limit_mask == 0ull) ? 1.f : 0.f;  // same value in every lane's column
+  ln.L(xo + 4) = (sc.split_pgs && wave_max_cont == 0) ? 1.f : 0.f;  // same value in every lane's column (limit rows are swept in registers too)
   __syncthreads();  // Bq
-  const bool helper_limit = ln.L(xo + 5) != 0.f;
-  if (helper_limit) limit_mask |= 1ull << (sc.helper_body & 63);  // the single-wave sweeps handle those rows
-  return ln.L(xo + 4) != 0.f && !helper_limit;
+  // the helper's active limit rows (2 bits per joint of its body, as a small integer), for the single-wave sweeps
+  // that run when contacts couple the bodies
+  const unsigned hbits = (unsigned)ln.L(xo + 5);
+  if (hbits) { limit_mask |= 1ull << (sc.helper_body & 63); limit_rows |= (uint64_t)hbits << (2 * ln.bi(sc.helper_body)[DG_BI_FIRST_LINK]); }
+  return ln.L(xo + 4) != 0.f;
 }
 template <int LANES>
-DGD bool split_decide_follow(const Lane<LANES>& ln, bool my_limit_rows_active, bool i_am_helper) {
+DGD bool split_decide_follow(const Lane<LANES>& ln, unsigned my_limit_bits, bool i_am_helper) {
   const DevScene& sc = ln.sc; const int xo = split_slots(sc);
-  if (i_am_helper) ln.L(xo + 5) = my_limit_rows_active ? 1.f : 0.f;
+  if (i_am_helper) ln.L(xo + 5) = (float)my_limit_bits;  // <= 12 bits: exact
   __syncthreads();  // Bq
-  return ln.L(xo + 4) != 0.f && ln.L(xo + 5) == 0.f;
+  return ln.L(xo + 4) != 0.f;
 }
 
 // ---- register-chain sweeps split across the wavefronts of the helper-wave kernel -------------------------------
@@ -983,8 +948,12 @@ DGD int pgs_reg_split(const Lane<LANES>& ln, int b, int slot, int xo) {
   constexpr int RN = 6;
   const DevScene& sc = ln.sc; const float h = sc.h; const float thr_abs = sqrtf(sc.HF[DG_HF_RESIDUAL_THRESHOLD]);
   float rM[RN * RN], rdv[RN], rb[RN], racc[RN], rdi[RN], rdg[RN], smax[RN]; int n = 0, dvo = 0, mo0 = 0;
+  // joint-limit rows of the body (lower, upper per joint): right-hand side and accumulated impulse; an impulse < 0
+  // marks a row that is inactive in this lane (the flag set up with the rows; it cannot change during the sweeps)
+  float lb[2][RN], la[2][RN]; bool any_limit = false;
 #pragma unroll
   for (int i = 0; i < RN; i++) { rdv[i] = 0.f; rb[i] = 0.f; racc[i] = 0.f; rdi[i] = 0.f; rdg[i] = 0.f; smax[i] = 0.f;
+    lb[0][i] = lb[1][i] = 0.f; la[0][i] = la[1][i] = -1.f;
     _Pragma("unroll") for (int c = 0; c < RN; c++) rM[i * RN + c] = 0.f; }
   if (b >= 0) {
     const int first = ln.bi(b)[DG_BI_FIRST_LINK], mvo = ln.plb(b)[PLB_MINV];
@@ -994,11 +963,15 @@ DGD int pgs_reg_split(const Lane<LANES>& ln, int b, int slot, int xo) {
       if (i < n) {
         const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[i] = maxf < 0.f ? -maxf : maxf * h;
         rb[i] = ln.L(mo0 + i * MR_STRIDE + MR_B); rdg[i] = ln.L(mvo + i * n + i); rdi[i] = 1.0f / rdg[i];
+        lb[0][i] = ln.L(mo0 + i * MR_STRIDE + MR_LO_B); la[0][i] = ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC);
+        lb[1][i] = ln.L(mo0 + i * MR_STRIDE + MR_HI_B); la[1][i] = ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC);
+        any_limit = any_limit || la[0][i] >= 0.f || la[1][i] >= 0.f;
       }
 #pragma unroll
       for (int c = 0; c < RN; c++) rM[i * RN + c] = (i < n && c < n) ? ln.L(mvo + i * n + c) : 0.f;
     }
   }
+  const bool wave_limit = __any(any_limit);  // no lane near a limit: the limit block is skipped altogether
   bool live = ln.valid; int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     const int xb = xo + 2 * (it & 1);
@@ -1012,6 +985,21 @@ DGD int pgs_reg_split(const Lane<LANES>& ln, int b, int slot, int xo) {
 #pragma unroll
         for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
         maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
+      }
+      if (wave_limit) {  // after the body's motor rows, as in the single-wave order
+#pragma unroll
+        for (int i = 0; i < RN; i++) {
+#pragma unroll
+          for (int side = 0; side < 2; side++) {
+            const float sg = side == 0 ? 1.f : -1.f; const bool act = la[side][i] >= 0.f;
+            const float nacc = fmaxf(la[side][i] + (lb[side][i] - sg * rdv[i]) * rdi[i], 0.f);
+            const float delta = act ? (nacc - la[side][i]) * lv : 0.f; la[side][i] += delta;
+            const float sd = sg * delta;
+#pragma unroll
+            for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * sd;
+            maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
+          }
+        }
       }
       ln.L(xb + slot) = maxabs;
     }
@@ -1092,7 +1080,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   }  // primary
   // ---- projected Gauss-Seidel
   bool split_now = false;
-  if constexpr (PAR) split_now = split_decide_main(ln, wave_max_cont, limit_mask);
+  if constexpr (PAR) split_now = split_decide_main(ln, wave_max_cont, limit_mask, limit_rows);
   const bool all_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
   if constexpr (SLICED) {  // wave-uniform results of the primary lanes, for every lane
     wave_max_cont = __builtin_amdgcn_readfirstlane(wave_max_cont);
@@ -1114,11 +1102,14 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     iters_done = pgs_reg_split(ln, sc.reg_body[0], 0, split_slots(sc));
   } else if (primary) {
   bool live = ln.valid;
-  if (all_dense) {
-    if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
-    else iters_done = pgs_dense<LANES, 32, PROF, FULLWAVE>(ln, ncont, wave_max_cont, limit_rows, prof);
+  // register-chain bodies in contact: their rows are coupled, the register sweeps no longer apply -- every row
+  // (motors and limits included) goes through the dense streaming sweeps instead
+  constexpr bool FW = FULLWAVE || PAR;
+  if (all_dense || (sc.dense && wave_max_cont > 0 && sc.nl <= 32)) {
+    if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
+    else iters_done = pgs_dense<LANES, 32, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
   } else {
   // Register-resident rows: for up to NBR fixed-base bodies with <= RN joints (every 6-axis arm) M^-1, the
   // velocity change, the motor targets and the accumulated impulses are loaded once and the sweeps below touch
@@ -1193,8 +1184,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     }
     prof.stamp(PS_PGS_LIMIT);
     if (wave_max_cont > 0) { regs_to_lds(0); regs_to_lds(1); }
-    if (wave_max_cont > 0 && sc.dense) maxres = fmaxf(maxres, contact_sweeps_dense(ln, ncont, wave_max_cont, live));
-    else {
+    {  // (dense scenes with contacts never get here: they take pgs_dense above)
     for (int c = 0; c < wave_max_cont; c++) {  // contact normals
       const bool has = c < ncont;
       float r = solve_crow(ln, sc.tr_off + (3 * c) * rs, sc.cont_off + 1 + c * CL_STRIDE, 0.f, 3.0e38f, live, has);
@@ -1249,7 +1239,8 @@ DGD void helper_substep(const Lane<LANES>& ln, bool early) {
   __syncthreads();  // B2
   uint64_t lm = 0ull, lr = 0ull;
   if (sc.split_pgs) { const int hf = ln.bi(hb)[DG_BI_FIRST_LINK]; setup_link_rows(ln, hf, hf + ln.bi(hb)[DG_BI_N_LINKS], lm, lr); }
-  if (split_decide_follow(ln, lm != 0ull, true)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); integrate_body(ln, hb); }
+  const int hf0 = ln.bi(hb)[DG_BI_FIRST_LINK];
+  if (split_decide_follow(ln, hf0 + 6 <= 32 ? (unsigned)((lr >> (2 * hf0)) & 0xFFFull) : 0u, true)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); integrate_body(ln, hb); }
   __syncthreads();  // B3
 }
 

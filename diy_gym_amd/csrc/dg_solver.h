@@ -1105,7 +1105,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   // register-chain bodies in contact: their rows are coupled, the register sweeps no longer apply -- every row
   // (motors and limits included) goes through the dense streaming sweeps instead
   constexpr bool FW = FULLWAVE || PAR;
-  if (all_dense || (sc.dense && wave_max_cont > 0 && sc.nl <= 32)) {
+  if (all_dense || (sc.dense && (wave_max_cont > 0 || limit_mask != 0ull) && sc.nl <= 32)) {  // (active limit rows: streamed too -- the register sweeps of this path carry motor rows only)
     if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
     else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
     else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);

@@ -134,6 +134,28 @@ def test_arms_in_contact_30_steps():
     assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
 
 
+@pytest.mark.parametrize('env_var', [None, 'DG_NO_HELPER_WAVE', 'DG_NO_SPLIT_SWEEPS'])
+def test_arms_driven_into_their_joint_limits(env_var):
+    # a constant maximal position increment walks every joint to its limit (elbow: +-pi after ~8 steps of 0.5 rad...):
+    # active limit rows in the split register sweeps, in the single-wave register path and in the streamed sweeps
+    if env_var:
+        os.environ[env_var] = '1'
+    try:
+        gpu, cpu = make_pair('ur_joint', 67)
+    finally:
+        if env_var:
+            del os.environ[env_var]
+    lo, hi = action_bounds(gpu)
+    act = hi[None].repeat(67, 1)
+    worst = 0.0
+    for _ in range(150):
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        worst = max(worst, float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()))
+    q = cpu.sim.obs[:, 0:12]
+    assert float(q.abs().max()) > 3.0            # limits were reached
+    assert worst < 2e-3, worst
+
+
 def test_drone_pilot_60_steps():
     gpu, cpu = make_pair('drone', 33)
     w = rollout(gpu, cpu, 60)

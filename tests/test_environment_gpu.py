@@ -124,6 +124,28 @@ def test_many_bodies_take_the_lds_row_path(tmp_path):
     assert cpu.sim.contacts(0) >= 7
 
 
+def test_many_bodies_with_a_large_contact_budget_run_from_the_global_workspace(tmp_path):
+    """10 marbles = 60 DoF (not dense) with a 32-contact budget: the per-env scratch no longer fits LDS even at 16 envs
+    per wavefront, so the generic per-body rows live in the [workgroup][slot][lane] device buffer (mode 0)."""
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    lines = ['max_contacts: 32', 'plane: {model: grass/plane.urdf}']
+    for i in range(10):
+        lines.append('m%d:\n  model: sphere2.urdf\n  scale: 0.3\n  xyz: [%g, %g, 0.16]\n  push: {addon: external_force}\n  respawn: {addon: respawn}'
+                     % (i, 0.32 * (i % 4), 0.33 * (i // 4)))
+    cfg = tmp_path / 'many10.yaml'
+    cfg.write_text('\n'.join(lines) + '\n')
+    gpu = DIYGym(str(cfg), num_envs=70, device='cuda:0')     # two workgroups, the second one ragged
+    cpu = DIYGym(str(cfg), num_envs=70, backend_factory=OracleBackend)
+    assert gpu.sim.lanes == 0
+    gen = torch.Generator().manual_seed(4)
+    for _ in range(20):
+        act = torch.rand((70, 30), generator=gen) * 6 - 3
+        gpu.sim.step(gpu._all_slots, act.to('cuda:0')); cpu.sim.step(cpu._all_slots, act)
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    assert cpu.sim.contacts(0) >= 10
+
+
 def test_step_and_masked_reset_are_graph_capturable():
     """No entry point allocates or synchronises: a step + auto-reset pair can be captured once and replayed."""
     import diy_gym_amd.examples  # noqa: F401

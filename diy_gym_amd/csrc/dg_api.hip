@@ -18,8 +18,8 @@
 using namespace dg;
 
 namespace dg {
-extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_0, g_launch_table_g16;
-const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : lanes == -16 ? g_launch_table_g16 : g_launch_table_0; }
+extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_8, g_launch_table_4, g_launch_table_0, g_launch_table_g16;
+const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : lanes == 8 ? g_launch_table_8 : lanes == 4 ? g_launch_table_4 : lanes == -16 ? g_launch_table_g16 : g_launch_table_0; }
 }  // namespace dg
 
 static thread_local std::string g_err;
@@ -120,17 +120,27 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   slot += tr + 8;  // + padding for the chunked vector helpers
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
-  if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16) lanes = v; }
-  while (lanes >= 16 && total * lanes * 4 > LDS_MAX) lanes >>= 1;
-  if (lanes < 16) {
+  if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16 || v == 8 || v == 4) lanes = v; }
+  // all-dense scenes (every row indexed by global DoF, no register-chain body) can put spare lanes to work in the
+  // Gauss-Seidel sweeps, so for them 8 and 4 envs per wavefront are worth having; other scenes stop at 16
+  bool has_reg = false;
+  for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) has_reg = true; }
+  const bool sliceable = dense && nt >= 1 && !has_reg;
+  const int min_lanes = (sliceable && !getenv("DG_NO_NARROW_MODES")) ? 4 : 16;
+  while (lanes >= min_lanes && total * lanes * 4 > LDS_MAX) lanes >>= 1;
+  // Latency: a big batch of a sliceable scene that still leaves most SIMDs without a wavefront (fewer than two
+  // workgroups per CU) is cut into smaller workgroups -- the sweeps get more lanes per env, the rest loses nothing.
+  if (sliceable && lanes >= min_lanes && num_envs >= 2048 && !getenv("DG_MAX_LANES") && !getenv("DG_NO_NARROW_MODES")) {
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+    while (lanes > 8 && (num_envs + lanes - 1) / lanes < 2 * prop.multiProcessorCount) lanes >>= 1;
+  }
+  if (lanes < min_lanes) {
     // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer
     // [workgroup][slot][lane] (coalesced, L2-resident); same kernels, Lane<0>
     lanes = 0;
     // all-dense scenes (every row indexed by global DoF, no register-chain bodies) run 16 envs per wavefront
     // instead, so that the other 48 lanes can share each env's solver rows; LDS then only holds the
     // accumulated impulses of those rows
-    bool has_reg = false;
-    for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) has_reg = true; }
     const int acc_rows = 3 * maxc + 3 * nl;
     if (dense && nt >= 1 && !has_reg && acc_rows * 16 * 4 <= 64 * 1024 && !getenv("DG_NO_SLICED_GLOBAL")) lanes = -16;
     { const int per = envs_per_wave(lanes); const size_t blocks = ((size_t)num_envs + per - 1) / per;  // [workgroup][slot][lane]

@@ -73,7 +73,8 @@ enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_DVA = 8, CL_NVA = 9, CL_
 enum { MR_B = 0, MR_ACC, MR_LO_B, MR_LO_ACC, MR_HI_B, MR_HI_ACC, MR_STRIDE };
 
 // Workspace modes (the LANES template argument everywhere):
-//   64 / 32 / 16  that many envs per wavefront, per-env scratch in LDS as ws[slot][lane]
+//   64 / 32 / 16 / 8 / 4  that many envs per wavefront, per-env scratch in LDS as ws[slot][lane]; below 64 the
+//                 spare lanes join the dense Gauss-Seidel sweeps (8 and 4 only exist for scenes that can use them)
 //   0             64 envs per wavefront, scratch in a global buffer [workgroup][slot][lane] (scene too big for LDS)
 //   -16           16 envs per wavefront, global scratch; the 48 spare lanes join the dense Gauss-Seidel sweeps
 constexpr int envs_per_wave(int lanes) { return lanes > 0 ? lanes : (lanes < 0 ? -lanes : 64); }

@@ -17,6 +17,6 @@ struct LaunchTable {
   void (*frame)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws);
   void (*pose)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws);
 };
-const LaunchTable& launch_table(int lanes);  // lanes in {64, 32, 16, 0, -16}
+const LaunchTable& launch_table(int lanes);  // lanes in {64, 32, 16, 8, 4, 0, -16}
 
 }  // namespace dg

@@ -551,14 +551,18 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
 // Modes with fewer than 64 envs per wavefront (LDS-heavy scenes) leave 3/4 or 1/2 of every VALU instruction idle.
 // During the Gauss-Seidel loop -- the bulk of such a step -- the idle lanes are put to work: lane l serves env
 // (l / SL) and owns the DoFs k with k % SL == l % SL.  A row costs each lane NTB / SL loads and FMAs per vector
-// plus a quad-permute DPP reduction of the partial J.dv; every lane of an env's group computes the same impulse.
+// plus a DPP reduction of the partial J.dv over the group (quad permutes, then row_half_mirror / row_mirror for
+// groups of 8 / 16); every lane of an env's group computes the same impulse.
 DGD float group_sum2(float x) { return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
 DGD float group_sum4(float x) { x = group_sum2(x); return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }  // then [2,3,0,1]
+DGD float group_sum8(float x) { x = group_sum4(x); return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true)); }   // then row_half_mirror
+DGD float group_sum16(float x) { x = group_sum8(x); return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true)); }  // then row_mirror
 
 template <int LANES, int NTB, bool PROF>
 DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
-  static_assert(LANES == 16 || LANES == 32, "sliced sweeps are for the 16 and 32 envs-per-wavefront modes");
-  constexpr int SL = 64 / LANES, LOG = SL == 4 ? 2 : 1, NS = NTB / SL;
+  static_assert(LANES == 32 || LANES == 16 || LANES == 8 || LANES == 4, "sliced sweeps are for the modes with fewer than 64 envs per wavefront");
+  constexpr int SL = 64 / LANES, LOG = SL == 16 ? 4 : SL == 8 ? 3 : SL == 4 ? 2 : 1, NS = NTB / SL;
+  static_assert(NTB % SL == 0 && NS >= 1, "the padded DoF count must be a multiple of the lanes per env");
   const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3; const float h = sc.h;
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
   const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
@@ -566,7 +570,7 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
   const Lane<LANES> lq(sc, ln.mt, ln.lds - lane + q, ln.st - ln.env + eq, eq, validq);
   const int ncont = __shfl(ncont_primary, q);
   float* const ls = lq.lds + sl * LANES;  // this lane's slice: slot (o + i SL) through ls is DoF i SL + sl of vector o
-  auto group_sum = [&](float x) { return SL == 4 ? group_sum4(x) : group_sum2(x); };
+  auto group_sum = [&](float x) { return SL == 16 ? group_sum16(x) : SL == 8 ? group_sum8(x) : SL == 4 ? group_sum4(x) : group_sum2(x); };
   float dv[NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) dv[i] = 0.f;
@@ -1087,7 +1091,10 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     limit_rows = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(limit_rows >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)limit_rows);
   }
   if (SLICED && all_dense) {
-    if constexpr (SLICED && LANES > 0) {
+    if constexpr (SLICED && LANES == 4) {  // 16 lanes per env: the padded DoF count is 16 or 32
+      if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      else iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+    } else if constexpr (SLICED && LANES > 0) {
       if (sc.nt <= 8) iters_done = pgs_dense_sliced<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else if (sc.nt <= 24) iters_done = pgs_dense_sliced<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);

@@ -53,7 +53,7 @@ int32_t dg_world_create(const int32_t* idata, int64_t n_i, const double* fdata, 
 void dg_world_destroy(dg_world* w);
 
 /* dims[0..7] = state_dim, act_dim, obs_dim, rew_dim, term_dim, n_links,
- * lds_bytes_per_workgroup, workspace mode.  Mode: 64 / 32 / 16 = that many envs per wavefront with the per-env
+ * lds_bytes_per_workgroup, workspace mode.  Mode: 64 / 32 / 16 / 8 / 4 = that many envs per wavefront with the per-env
  * scratch in LDS; 0 = 64 envs per wavefront, scratch in a device buffer the world owns; -16 = 16 envs per
  * wavefront, scratch in that buffer (chosen by dg_world_create from the scene's scratch footprint). */
 int32_t dg_world_dims(const dg_world* w, int32_t dims[8]);

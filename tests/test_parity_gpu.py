@@ -199,9 +199,9 @@ def test_r2d2_maze_40_steps():
 
 def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
-    # runs from the global per-env workspace (16 envs per wavefront, the spare lanes share the solver rows)
+    # too big for 16 envs per wavefront in LDS
     gpu, cpu = make_pair('readme', 3)
-    assert gpu.sim.lanes in (0, -16)
+    assert gpu.sim.lanes == 4   # 4 envs per wavefront in LDS, 16 lanes share each env's rows
     w = rollout(gpu, cpu, 6)
     assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
     gpu._tick += 1; cpu._tick += 1
@@ -227,23 +227,29 @@ def test_from_the_readme_resting_contacts_60_steps():
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize('name,env_var,value,lanes,steps,tol', [
-    ('cart_tree', 'DG_MAX_LANES', '16', 16, 20, 2e-2),   # two bodies with joints: general (masked) column loads of the sliced sweeps
-    ('cart_tree', 'DG_MAX_LANES', '32', 32, 20, 2e-2),
-    ('marbles', 'DG_MAX_LANES', '16', 16, 100, 2e-3),
-    ('readme', 'DG_NO_SLICED_GLOBAL', '1', 0, 30, 2e-3),  # 64 envs per wavefront from the global workspace, unsliced dense sweeps
-    ('ur_ik', 'DG_NO_HELPER_WAVE', '1', 64, 30, 5e-4),    # single-wavefront step kernel
-    ('ur_ik', 'DG_NO_EARLY_DYNAMICS', '1', 64, 30, 5e-4),
-    ('ur_ik', 'DG_NO_COLLIDE_WAVE', '1', 64, 30, 5e-4),    # main wave runs the narrow phase itself
-    ('ur_ik', 'DG_NO_SPLIT_SWEEPS', '1', 64, 30, 5e-4),    # main wave sweeps both arms
+@pytest.mark.parametrize('name,env_vars,lanes,steps,tol', [
+    ('cart_tree', {'DG_MAX_LANES': '16'}, 16, 20, 2e-2),   # two bodies with joints: general (masked) column loads of the sliced sweeps
+    ('cart_tree', {'DG_MAX_LANES': '32'}, 32, 20, 2e-2),
+    ('cart_tree', {'DG_MAX_LANES': '8'}, 8, 20, 2e-2),     # 8 lanes per env (row_half_mirror reduction)
+    ('cart_tree', {'DG_MAX_LANES': '4'}, 4, 20, 2e-2),     # 16 lanes per env (row_mirror reduction)
+    ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3),
+    ('marbles', {'DG_MAX_LANES': '8'}, 8, 100, 2e-3),
+    ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
+    ('readme', {'DG_NO_NARROW_MODES': '1'}, -16, 30, 2e-3),                              # global workspace, sliced
+    ('readme', {'DG_NO_NARROW_MODES': '1', 'DG_NO_SLICED_GLOBAL': '1'}, 0, 30, 2e-3),    # global workspace, 64 envs per wavefront
+    ('ur_ik', {'DG_NO_HELPER_WAVE': '1'}, 64, 30, 5e-4),    # single-wavefront step kernel
+    ('ur_ik', {'DG_NO_EARLY_DYNAMICS': '1'}, 64, 30, 5e-4),
+    ('ur_ik', {'DG_NO_COLLIDE_WAVE': '1'}, 64, 30, 5e-4),    # main wave runs the narrow phase itself
+    ('ur_ik', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-4),    # main wave sweeps both arms
 ])
-def test_alternative_workspace_modes(name, env_var, value, lanes, steps, tol):
+def test_alternative_workspace_modes(name, env_vars, lanes, steps, tol):
     # every scene normally takes ONE path through the mode selection; force the others
-    os.environ[env_var] = value
+    os.environ.update(env_vars)
     try:
         gpu, cpu = make_pair(name, 9)
     finally:
-        del os.environ[env_var]
+        for k in env_vars:
+            del os.environ[k]
     assert gpu.sim.lanes == lanes
     w = rollout(gpu, cpu, steps, scale=0.5)
     assert w['obs'] < tol and w['term_mismatch'] == 0, w

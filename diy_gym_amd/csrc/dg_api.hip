@@ -325,7 +325,7 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
   }
   {
     const LaunchTable& lt = launch_table(w->lanes); const bool prof = w->profile_cycles != nullptr;
-    if (prof && !lt.has_prof) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are built for 64 and 16 envs per wavefront only");
+    if (prof && !lt.has_prof) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are not built for this workspace mode");
     if (w->par) lt.step_par(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles);
     else lt.step(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles, w->d_gws);
     HIP_TRY(hipGetLastError());

@@ -520,7 +520,7 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     // ---- contact normals, then friction pairs; two row buffers ping-pong so that loads run one row ahead
     if (wave_max_cont > 0) {
       DenseRow<NTB> A, B;
-      const int r0 = sc.tr_off;
+      const int r0 = sc.tr_off, cl = wave_max_cont - 1;
       if (0 < ncont) load_row(A, r0);
       for (int c = 0; c < wave_max_cont; c += 2) {
         if (c + 1 < ncont) load_row(B, r0 + 3 * (c + 1) * rs);
@@ -528,12 +528,23 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
         if (c + 2 < ncont) load_row(A, r0 + 3 * (c + 2) * rs);
         if (c + 1 < ncont) solve_row(B, r0 + 3 * (c + 1) * rs, 0.f, 3.0e38f);
       }
-      for (int c = 0; c < wave_max_cont; c++) {
-        const bool act = c < ncont && ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) > 0.f;
-        if (act) {
-          const float lim = ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) * ln.L(r0 + 3 * c * rs + 2 * nt + 1);
-          load_row(A, r0 + (3 * c + 1) * rs); load_row(B, r0 + (3 * c + 2) * rs);
-          solve_row(A, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(B, r0 + (3 * c + 2) * rs, -lim, lim);
+      {  // friction pairs: the two rows, the friction coefficient and the normal impulse of contact c + 1 are read
+         // (unconditionally: past the end they re-read the last contact) while contact c is solved
+        DenseRow<NTB> A2, B2; float muA, muB, naA, naB;
+        auto fetch = [&](DenseRow<NTB>& r1, DenseRow<NTB>& r2, float& mu, float& na, int c) {
+          const int cc = min(c, cl);
+          load_row(r1, r0 + (3 * cc + 1) * rs); load_row(r2, r0 + (3 * cc + 2) * rs);
+          mu = ln.L(sc.cont_off + 1 + cc * CL_STRIDE + CL_MU); na = ln.L(r0 + 3 * cc * rs + 2 * nt + 1);
+        };
+        auto pair = [&](const DenseRow<NTB>& r1, const DenseRow<NTB>& r2, float mu, float na, int c) {
+          if (c < ncont && mu > 0.f) { const float lim = mu * na; solve_row(r1, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(r2, r0 + (3 * c + 2) * rs, -lim, lim); }
+        };
+        fetch(A, A2, muA, naA, 0);
+        for (int c = 0; c < wave_max_cont; c += 2) {
+          fetch(B, B2, muB, naB, c + 1);
+          pair(A, A2, muA, naA, c);
+          fetch(A, A2, muA, naA, c + 2);
+          if (c + 1 < wave_max_cont) pair(B, B2, muB, naB, c + 1);
         }
       }
     }
@@ -663,12 +674,23 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
         load_row(A, r0 + 3 * min(c + 2, cl) * rs);
         if (c + 1 < ncont) solve_row(B, r0 + 3 * (c + 1) * rs, 0.f, 3.0e38f);
       }
-      for (int c = 0; c < wave_max_cont; c++) {
-        const bool act = c < ncont && lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) > 0.f;
-        if (act) {
-          const float lim = lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_MU) * lq.L(r0 + 3 * c * rs + 2 * nt + 1);
-          load_row(A, r0 + (3 * c + 1) * rs); load_row(B, r0 + (3 * c + 2) * rs);
-          solve_row(A, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(B, r0 + (3 * c + 2) * rs, -lim, lim);
+      {  // friction pairs: the two rows, the friction coefficient and the normal impulse of contact c + 1 are read
+         // (unconditionally: past the end they re-read the last contact) while contact c is solved
+        Row A2, B2; float muA, muB, naA, naB;
+        auto fetch = [&](Row& r1, Row& r2, float& mu, float& na, int c) {
+          const int cc = min(c, cl);
+          load_row(r1, r0 + (3 * cc + 1) * rs); load_row(r2, r0 + (3 * cc + 2) * rs);
+          mu = lq.L(sc.cont_off + 1 + cc * CL_STRIDE + CL_MU); na = lq.L(r0 + 3 * cc * rs + 2 * nt + 1);
+        };
+        auto pair = [&](const Row& r1, const Row& r2, float mu, float na, int c) {
+          if (c < ncont && mu > 0.f) { const float lim = mu * na; solve_row(r1, r0 + (3 * c + 1) * rs, -lim, lim); solve_row(r2, r0 + (3 * c + 2) * rs, -lim, lim); }
+        };
+        fetch(A, A2, muA, naA, 0);
+        for (int c = 0; c < wave_max_cont; c += 2) {
+          fetch(B, B2, muB, naB, c + 1);
+          pair(A, A2, muA, naA, c);
+          fetch(A, A2, muA, naA, c + 2);
+          if (c + 1 < wave_max_cont) pair(B, B2, muB, naB, c + 1);
         }
       }
     }

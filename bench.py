@@ -116,7 +116,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--workload', default='ur_high_5', choices=sorted(WORKLOADS))
-    ap.add_argument('--envs-per-gpu', type=int, default=16384)
+    ap.add_argument('--envs-per-gpu', type=int, default=None, help='default: the size BASELINE.json quotes for the workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-auto-reset', action='store_true')
     ap.add_argument('--eager', action='store_true', help='time the eager launch loop instead of a replayed hipGraph')
@@ -138,7 +138,7 @@ def main():
     from diy_gym_amd import DIYGym
     cfg_rel, cfg_desc = WORKLOADS[args.workload]
     cfg = os.path.join(ROOT, cfg_rel)
-    B = args.envs_per_gpu
+    B = args.envs_per_gpu or {'r2d2_maze': 4096, 'from_the_readme': 1024}.get(args.workload, 16384)
     env = DIYGym(cfg, num_envs=B, device=device, seed=1234, env_index_base=rank * B)
     lo, hi = action_bounds(env)
     gen = torch.Generator().manual_seed(1234 + rank)

@@ -1391,24 +1391,36 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   const Q4 qoff = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
   const M3 R0 = ln.LR(ln.plb(b)[PLB_R0]); const V3 p0 = ln.base_pos(b);
   float q[N]; V3 ow[N], aw[N];
-  // chain constants pinned in VGPRs for the whole solve (the loop is too long for them to stay in SGPRs, and
-  // re-fetching them through the scalar cache every iteration costs a memory round trip per link)
-  float cR[N][9], cP[N][3], cA[N][3]; bool rev[N];
+  // Chain constants, held in VGPRs for the whole solve (the loop is too long for them to stay in SGPRs, and
+  // re-fetching them through the scalar cache every iteration costs a memory round trip per link).
+  // Every link frame is re-parameterised by a constant rotation Q_i whose third column is the joint axis:
+  // with R'_i = R_i Q_i the recursion becomes R'_i = R'_{i-1} (Q_{i-1}^T RT_i Q_i) Rz(q_i), so whatever the axis the
+  // joint rotation only mixes the first two columns of a matrix product, the world axis is the third column for
+  // free, and offsets turn into Q_{i-1}^T p_i.  The constants below are those primed quantities.
+  float cR[N][9], cP[N][3]; bool rev[N];
+  M3 Qprev = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}, Qee = Qprev;  // Q of the parent link; of the end-effector link
 #pragma unroll
   for (int i = 0; i < N; i++) {
     q[i] = 0.f; rev[i] = true;
 #pragma unroll
     for (int k = 0; k < 9; k++) cR[i][k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { cP[i][k] = 0.f; cA[i][k] = 0.f; }
+    for (int k = 0; k < 3; k++) cP[i][k] = 0.f;
     if (i < n) {
       cfp f = ln.lf(first + i); q[i] = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q); rev[i] = ln.li(first + i)[DG_LI_TYPE] == 0;
+      M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = pin(f[DG_LF_ROT + k]);
+      const V3 pT = v3(pin(f[DG_LF_POS]), pin(f[DG_LF_POS + 1]), pin(f[DG_LF_POS + 2]));
+      const V3 ax = v3(pin(f[DG_LF_AXIS]), pin(f[DG_LF_AXIS + 1]), pin(f[DG_LF_AXIS + 2]));
+      V3 u, v; tangent_basis(ax, u, v);  // right-handed (u, v, axis)
+      const M3 Qi = {{u.x, v.x, ax.x, u.y, v.y, ax.y, u.z, v.z, ax.z}};
+      const M3 RTp = mul(transpose(Qprev), mul(RT, Qi)); const V3 pTp = tmul(Qprev, pT);
 #pragma unroll
-      for (int k = 0; k < 9; k++) cR[i][k] = pin(f[DG_LF_ROT + k]);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { cP[i][k] = pin(f[DG_LF_POS + k]); cA[i][k] = pin(f[DG_LF_AXIS + k]); }
+      for (int k = 0; k < 9; k++) cR[i][k] = RTp.m[k];
+      cP[i][0] = pTp.x; cP[i][1] = pTp.y; cP[i][2] = pTp.z;
+      Qprev = Qi; if (i == eel) Qee = Qi;
     }
   }
+  const V3 offp = tmul(Qee, off);  // frame offset in the primed end-effector frame
   // null-space constants per joint, pinned like the chain constants (the loop would otherwise re-fetch 24 scalars
   // through the scalar cache every iteration)
   float nRest[N], nLo[N], nHi[N], nIrg[N];
@@ -1417,22 +1429,26 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
     nRest[i] = 0.f; nLo[i] = -3.0e38f; nHi[i] = 3.0e38f; nIrg[i] = 0.f;
     if (nullsp && i < n) { nRest[i] = pin(rest[i]); nLo[i] = pin(rest[n + i]); nHi[i] = pin(rest[2 * n + i]); nIrg[i] = pin(frcp(rest[3 * n + i])); }
   }
-  V3 pe; M3 Re;  // end-effector point and LINK rotation (the frame offset is folded into the target below)
+  V3 pe; M3 Re;  // end-effector point and PRIMED link rotation R_ee Q_ee (Q and the frame offset are folded into the target)
   auto fk = [&]() {
     M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       if (i < n) {
         M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = cR[i][k];
-        const V3 pT = v3(cP[i][0], cP[i][1], cP[i][2]), ax = v3(cA[i][0], cA[i][1], cA[i][2]);
-        M3 Rpc; V3 r;
-        if (rev[i]) { Rpc = mul(RT, rot_axis(ax, q[i])); r = pT; } else { Rpc = RT; r = pT + mul(RT, ax * q[i]); }
-        p = p + mul(R, r); R = mul(R, Rpc);
-        ow[i] = p; aw[i] = mul(R, ax);
+        p = p + mul(R, v3(cP[i][0], cP[i][1], cP[i][2]));
+        const M3 C = mul(R, RT);
+        const V3 c0 = v3(C.m[0], C.m[3], C.m[6]), c1 = v3(C.m[1], C.m[4], C.m[7]), c2 = v3(C.m[2], C.m[5], C.m[8]);
+        if (rev[i]) {
+          const float sn = __sinf(q[i]), cs = __cosf(q[i]);
+          const V3 n0 = c0 * cs + c1 * sn, n1 = c1 * cs - c0 * sn;
+          const M3 Rn = {{n0.x, n1.x, c2.x, n0.y, n1.y, c2.y, n0.z, n1.z, c2.z}}; R = Rn;
+        } else { R = C; p = p + c2 * q[i]; }
+        ow[i] = p; aw[i] = c2;
         if (i == eel) { Rl = R; pl = p; }
       }
     }
-    pe = pl + mul(Rl, off); Re = Rl;
+    pe = pl + mul(Rl, offp); Re = Rl;
   };
   fk();
   const V3 tp = pe + v3(act[0], act[1], act[2]);
@@ -1441,9 +1457,9 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   // antisymmetric part of Tm R_link^T (27 FMAs) instead of matrix -> quaternion -> product -> angle-axis.
   M3 Tm = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};
   if (use_orn) {
-    const Q4 qe0 = qnormalize(qmul(qfrom_mat(Re), qoff));
+    const Q4 qe0 = qnormalize(qmul(qfrom_mat(mul(Re, transpose(Qee))), qoff));  // the true link rotation is R' Q^T
     const Q4 tq = qmul(qe0, qfrom_euler(act[3], act[4], act[5]));
-    Tm = mul(qmat(tq), transpose(qmat(qoff)));
+    Tm = mul(mul(qmat(tq), transpose(qmat(qoff))), Qee);  // error rotation = Tm_true (R' Q^T)^T = (Tm_true Q) R'^T
   }
   // without the null-space lists pybullet solves (J^T J + d I) dq = J^T e in joint space; by the push-through
   // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d

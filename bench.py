@@ -218,6 +218,16 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload)
             except Exception:
                 traffic = None
+        # informative: share of the chip's VALU issue slots the kernel used (wave-instructions from the committed PMC
+        # pass of the same command x 4 cycles each, over 256 CUs x 4 SIMDs x the live kernel time at 2.4 GHz)
+        valu_frac = None
+        pmc_sq = os.path.join(ROOT, 'profiles', 'r1_ur_high_5_16384_pmc_step_kernel.json')
+        if args.workload == 'ur_high_5' and B == 16384 and os.path.isfile(pmc_sq):
+            try:
+                valu = json.load(open(pmc_sq))['per_launch_means'].get('SQ_INSTS_VALU')
+                valu_frac = valu * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9) if valu else None
+            except Exception:
+                valu_frac = None
         out = {
             'metric': 'env steps/sec (whole node)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -229,6 +239,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'step_kernel_par' if getattr(sim, 'lanes', 0) == 64 and args.workload.startswith('ur_high_5') else 'step_kernel', 'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_unit,
                          'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
+                         'valu_issue_frac': valu_frac,
                          'note': 'the step kernel keeps all per-env scratch in LDS; it is bound by instruction issue and latency of one '
                                  'wavefront per SIMD (three per workgroup), not by HBM (DESIGN.md Measurement)'},
         }

@@ -225,6 +225,15 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     int jointed = 0; for (int b = 0; b < nb; b++) if (BI[b * DG_BI_STRIDE + DG_BI_N_LINKS] > 0) jointed++;
     if (jointed == 2 && sc.reg_body[0] >= 0 && sc.reg_body[1] == sc.helper_body && sc.reg_body[0] != sc.helper_body) sc.split_pgs = 1;
   }
+  // a fourth wavefront for the second half of the pair table, if its contact list still fits LDS
+  sc.coll_split = 0; sc.cont2_off = 0;
+  if (sc.coll_wave && lanes == 64 && I[DG_H_N_PAIRS] >= 8 && !getenv("DG_NO_COLLIDE_SPLIT")) {
+    const int extra = 1 + maxc * CL_STRIDE;
+    if ((sc.total_slots + extra) * 64 * 4 <= 160 * 1024) {
+      sc.cont2_off = sc.total_slots; sc.total_slots += extra; sc.coll_split = 1;
+      w->lds_bytes = sc.total_slots * 64 * 4;
+    }
+  }
   // The update ops of such a scene (inverse kinematics above all) only write motor targets unless one of them is a
   // torque / force op; then the first substep's dynamics do not depend on them and can run alongside.
   sc.early_dyn = 0;

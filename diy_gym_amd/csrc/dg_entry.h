@@ -37,17 +37,32 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
 }
 
-// Three wavefronts per workgroup, same 64 envs, same LDS workspace: wave 1 (the helper) runs the inverse kinematics
+// Four wavefronts per workgroup, same 64 envs, same LDS workspace (wave 3 takes half of the narrow phase in substeps
+// where it is on the critical path): wave 1 (the helper) runs the inverse kinematics
 // and the register-resident dynamics of sc.helper_body, wave 2 the narrow phase (when sc.coll_wave), wave 0 everything else.  Every global / LDS
 // hand-off between the two is separated by a __syncthreads (workgroup-scope release / acquire).
 template <bool PROF>
-__global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
+__global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
                                                         float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
                                                         unsigned long long* cycles) {
   extern __shared__ float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
   const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
+  if (wave == 3) {  // ---------------- second half of the narrow phase (substeps whose narrow phase is on the critical path)
+    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    __syncthreads();  // B0
+    __syncthreads();  // B0'
+    for (int k = 0; k < sc.substeps; k++) {
+      __syncthreads();  // B1
+      if (sc.coll_split && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, sc.npairs / 2, 0x7fffffff, sc.cont2_off);
+      __syncthreads();  // B2
+      if (split_decide_follow(ln, 0u, false)) pgs_reg_split(ln, -1, 0, split_slots(sc));
+      __syncthreads();  // B3
+    }
+    __syncthreads();  // B4
+    return;
+  }
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     __syncthreads();  // B0
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(192) void step_kernel_par(DevScene sc, MotorTable m
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {
       __syncthreads();  // B1: every pose is in LDS
-      if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln);  // contact list + count go to LDS; the main wave reads them after B2
+      if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, 0, sc.coll_split ? sc.npairs / 2 : 0x7fffffff);  // contact list + count go to LDS; the main wave reads them after B2
       __syncthreads();  // B2
       if (split_decide_follow(ln, false, false)) pgs_reg_split(ln, -1, 0, split_slots(sc));
       __syncthreads();  // B3

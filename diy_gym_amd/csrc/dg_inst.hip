@@ -38,8 +38,8 @@ hipError_t DGL(l_prepare_step)(int lds) {
 }
 #elif DG_PART == 2
 void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS) {
-  if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(192), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles);
-  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(192), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr);
+  if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles);
+  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr);
 }
 hipError_t l_prepare_par_64(int lds) {
   hipError_t e = hipFuncSetAttribute((const void*)step_kernel_par<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -43,6 +43,7 @@ struct DevScene {
   cip PLB;  // per body: [R0_off, minv_off, dv_off, nv]
   int split_pgs;  // helper-wave kernel: the two register-chain bodies are (main wave: reg_body[0], helper: helper_body) and no other body has joints
   int early_dyn;  // with coll_wave: the first substep's narrow phase and dynamics run on that wavefront DURING the update ops (no op writes torques / forces)
+  int coll_split, cont2_off;  // with coll_wave: a fourth wavefront tests the second half of the pair table into its own contact list at cont2_off
   int coll_wave;  // helper-wave step kernel: a third wavefront runs the narrow phase (every moving body has register-resident dynamics)
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]

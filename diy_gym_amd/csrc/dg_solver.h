@@ -88,9 +88,9 @@ DGD void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
 
 // contact list lives at sc.cont_off: slot 0 = count, then max_contacts entries of CL_STRIDE
 template <int LANES>
-DGD void emit_contact(const Lane<LANES>& ln, int& cnt, int pair, const Hit& h, float flip) {
+DGD void emit_contact(const Lane<LANES>& ln, int list, int& cnt, int pair, const Hit& h, float flip) {
   if (!h.hit || cnt >= ln.sc.max_contacts) return;
-  int o = ln.sc.cont_off + 1 + cnt * CL_STRIDE;
+  int o = list + 1 + cnt * CL_STRIDE;
   ln.L(o + CL_PAIR) = (float)pair;
   ln.L3set(o + CL_P, (h.pa + h.pb) * 0.5f);
   ln.L3set(o + CL_N, h.n * flip);
@@ -109,10 +109,14 @@ enum { SC_C = 0, SC_H = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
 // wavefront of the sliced modes) -- pair descriptors are then fetched TBL at a time with one vector load and read
 // back with v_readlane, instead of a chain of dependent scalar loads per pair.  TBL == 0 (reset kernel, which runs
 // under a per-env mask): one scalar load per pair.
+// Only the candidate pairs [pair_lo, pair_hi) are tested and their contacts go to the list at `list` (the helper-wave
+// kernel cuts the pair table in two for two wavefronts; pair order, hence contact order, is kept by appending the
+// second list to the first).
 template <int LANES, int TBL>
-DGD int collide(const Lane<LANES>& ln) {
+DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff, int list = -1) {
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
-  if (sc.npairs == 0) { ln.L(sc.cont_off) = 0.f; return 0; }
+  if (list < 0) list = sc.cont_off;
+  if (sc.npairs == 0) { ln.L(list) = 0.f; return 0; }
   for (int sh = 0; sh < sc.nsh; sh++) {
     const int type = sc.SI[sh * DG_SI_STRIDE + DG_SI_TYPE]; if (type == DG_SHAPE_BOX) continue;
     WShape w; shape_world(ln, sh, w); V3 e0 = w.p, e1 = w.p;
@@ -126,6 +130,7 @@ DGD int collide(const Lane<LANES>& ln) {
   const int lane = threadIdx.x & 63;
   for (int g = 0; g < sc.ngroups; g++) {
     cip gi = sc.GI + g * DG_GI_STRIDE; const int ba = gi[DG_GI_BODY_A], bb = gi[DG_GI_BODY_B], ss = gi[DG_GI_STATIC_SHAPE];
+    if (gi[DG_GI_FIRST] >= pair_hi || gi[DG_GI_FIRST] + gi[DG_GI_COUNT] <= pair_lo) continue;
     if (ba != cached_body) { cpos = ln.base_pos(ba); cached_body = ba; }
     V3 other; float reach = sc.BF[ba * DG_BF_STRIDE + DG_BF_BOUND] + margin;
     if (ss >= 0) {
@@ -135,7 +140,7 @@ DGD int collide(const Lane<LANES>& ln) {
       else { WShape w; shape_world(ln, ss, w); other = w.p; }
     } else { other = ln.base_pos(bb); reach += sc.BF[bb * DG_BF_STRIDE + DG_BF_BOUND]; }
     { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
-  const int first = gi[DG_GI_FIRST], count = gi[DG_GI_COUNT];
+  const int first = max(gi[DG_GI_FIRST], pair_lo), count = min(gi[DG_GI_FIRST] + gi[DG_GI_COUNT], pair_hi) - first;  // this wave's share
   constexpr int CH = TBL > 0 ? TBL : 1;
   for (int c0 = 0; c0 < count; c0 += CH) {
     const int n = min(CH, count - c0);
@@ -160,16 +165,16 @@ DGD int collide(const Lane<LANES>& ln) {
       V3 ca = a0, cb = b0;
       if (ta == DG_SHAPE_SPHERE && tb != DG_SHAPE_SPHERE) cb = closest_on_seg(b0, b1, a0);
       else if (ta != DG_SHAPE_SPHERE) seg_seg(a0, a1, b0, b1, ca, cb);
-      emit_contact(ln, cnt, pi, sphere_sphere(ca, ra, cb, rb, margin), flip);
+      emit_contact(ln, list, cnt, pi, sphere_sphere(ca, ra, cb, rb, margin), flip);
     } else {
       WShape b; shape_world(ln, sb, b);
       const V3 ha = ln.L3(oa + SC_H); const V3 a0 = cu.ca - ha, a1 = cu.ca + ha; const float ra = ln.L(oa + SC_R);
       // cull with the bounding sphere of the round shape against the box
       { Hit hb = sphere_box(cu.ca, ln.L(oa + SC_BOUND), b, margin); if (!__any(hb.hit)) continue; }
-      if (ta == DG_SHAPE_SPHERE) emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
+      if (ta == DG_SHAPE_SPHERE) emit_contact(ln, list, cnt, pi, sphere_box(a0, ra, b, margin), flip);
       else if (ta == DG_SHAPE_CAPSULE) {
-        emit_contact(ln, cnt, pi, sphere_box(a0, ra, b, margin), flip);
-        if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) emit_contact(ln, cnt, pi, sphere_box(a1, ra, b, margin), flip);
+        emit_contact(ln, list, cnt, pi, sphere_box(a0, ra, b, margin), flip);
+        if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) emit_contact(ln, list, cnt, pi, sphere_box(a1, ra, b, margin), flip);
       } else if (ta == DG_SHAPE_POINTS) {
         const int abody = sc.SI[sa * DG_SI_STRIDE + DG_SI_BODY], alink = sc.SI[sa * DG_SI_STRIDE + DG_SI_LINK];
         const int poff = sc.SI[sa * DG_SI_STRIDE + DG_SI_POINT_OFF], npts = sc.SI[sa * DG_SI_STRIDE + DG_SI_N_POINTS];
@@ -197,14 +202,14 @@ DGD int collide(const Lane<LANES>& ln) {
           cfp pp = sc.PF + 3 * (poff + k2);  // per-lane index: vector load
           Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
           h.hit = h.hit && bi4[j] >= 0;
-          emit_contact(ln, cnt, pi, h, flip);
+          emit_contact(ln, list, cnt, pi, h, flip);
         }
       }
     }
   }
   }
   }
-  ln.L(sc.cont_off) = (float)cnt;
+  ln.L(list) = (float)cnt;
   return cnt;
 }
 
@@ -1076,7 +1081,24 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
-  if (!own_collide) ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront before B2
+  if (!own_collide) {
+    ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront(s) before B2
+    if (sc.coll_split && !early) {  // append the second wavefront's contacts (later pairs) behind the first's (the early
+                                    // first substep was done by one wavefront over the whole pair table)
+      const int nb2 = (int)ln.L(sc.cont2_off);
+      if (__any(nb2 > 0)) {
+        for (int j = 0; j < sc.max_contacts; j++) {
+          if (!__any(j < nb2)) break;
+          if (j < nb2 && ncont + j < sc.max_contacts) {
+            float* dst = ln.lds + (sc.cont_off + 1 + (ncont + j) * CL_STRIDE) * envs_per_wave(LANES);  // per-lane destination entry
+#pragma unroll
+            for (int k = 0; k < CL_DIST + 1; k++) dst[k * envs_per_wave(LANES)] = ln.L(sc.cont2_off + 1 + j * CL_STRIDE + k);
+          }
+        }
+        ncont = min(ncont + nb2, sc.max_contacts); ln.L(sc.cont_off) = (float)ncont;
+      }
+    }
+  }
   // ---- motor and joint-limit rows (per link, uniform)
   // (the helper wave sets up the rows of its own body when the sweeps can be split)
   const bool helper_rows = PAR && sc.split_pgs;

@@ -241,6 +241,8 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('ur_ik', {'DG_NO_EARLY_DYNAMICS': '1'}, 64, 30, 5e-4),
     ('ur_ik', {'DG_NO_COLLIDE_WAVE': '1'}, 64, 30, 5e-4),    # main wave runs the narrow phase itself
     ('ur_ik', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-4),    # main wave sweeps both arms
+    ('touching', {'DG_NO_COLLIDE_SPLIT': '1'}, 64, 30, 5e-3),  # one narrow-phase wavefront instead of two (contacts present)
+    ('touching', {'DG_NO_EARLY_DYNAMICS': '1'}, 64, 30, 5e-3),  # both substeps merge two contact lists
 ])
 def test_alternative_workspace_modes(name, env_vars, lanes, steps, tol):
     # every scene normally takes ONE path through the mode selection; force the others

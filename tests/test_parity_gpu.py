@@ -21,6 +21,7 @@ CONFIGS = {
     'gripper': os.path.join(ROOT, 'tests', 'golden', 'ur5_gripper.yaml'),
     'child': os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'),
     'touching': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching.yaml'),
+    'touching_ik': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching_ik.yaml'),
 }
 
 
@@ -154,6 +155,14 @@ def test_arms_driven_into_their_joint_limits(env_var):
     q = cpu.sim.obs[:, 0:12]
     assert float(q.abs().max()) > 3.0            # limits were reached
     assert worst < 2e-3, worst
+
+
+def test_arms_in_contact_under_ik_control_30_steps():
+    gpu, cpu = make_pair('touching_ik', 37)
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, 30, scale=1.0)
+    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+    assert int(d[:, 0].max()) >= 1   # still touching at the end
 
 
 def test_drone_pilot_60_steps():

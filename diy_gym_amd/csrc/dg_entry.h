@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
     for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0);
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
     __syncthreads();  // B4
+    // its arm's joint-state observations (state reads only; the main wave skips them)
+    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, sc.helper_body, -1);
     return;
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr);
+                 (valid && term_flag) ? term_flag + e : nullptr, -1, sc.helper_body);
   prof.stamp(PS_OUTPUT);
   if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
 }

@@ -1685,7 +1685,10 @@ DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
 
 // observe / reward / terminal ops; POSE must be current for every body
 template <int LANES>
-DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag) {
+// joint_only_body >= 0: only the joint-state ops of that body (they read nothing but the state, so the helper wave can
+// emit its arm's while the main wave is still busy); joint_skip_body: everything but those.
+DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag,
+                        int joint_only_body = -1, int joint_skip_body = -1) {
   const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
   // a reach_target addon emits a reward op and a terminal op on the same pair of frames: the distance is computed once
   int rk_a = -2, rk_b = -2, rk_c = -2, rk_d = -2; float rk_dist = 0.f;
@@ -1698,6 +1701,8 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE;
     const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST];
+    if (joint_only_body >= 0 && !(code == DG_OP_OBS_JOINT_STATE && oi[DG_OI_BODY] == joint_only_body)) continue;
+    if (joint_skip_body >= 0 && code == DG_OP_OBS_JOINT_STATE && oi[DG_OI_BODY] == joint_skip_body) continue;
     if (code == DG_OP_OBS_JOINT_STATE) {
       const int n = oi[DG_OI_N]; int k2 = n;
       if (obs) {
@@ -1751,6 +1756,7 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
       if (t) { any = true; groups |= 1ull << (oi[DG_OI_SLOT] & 63); }
     }
   }
+  if (joint_only_body >= 0) return;
   if (rew_sum) *rew_sum = rsum;
   if (term_flag) {
     if (sc.term_mode == DG_COLLAPSE_ALL) { const uint64_t want = sc.n_term_groups >= 64 ? ~0ull : ((1ull << sc.n_term_groups) - 1ull); *term_flag = (sc.n_term_groups > 0 && (groups & want) == want) ? 1 : 0; }

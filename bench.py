@@ -5,31 +5,39 @@
 
 One "step" = one DIYGym.step() over the whole batch: controller addons (batched
 IK for ur_high_5) -> one 1/240 s physics step (2 substeps, <=150 PGS iterations)
--> sensor / reward / terminal addons, followed by the masked auto-reset of the
-envs whose terminal fired.  Inputs are synthetic uniform random
-actions within each addon's declared action_space, generated before the timed
-region and already resident in HBM.  Weak scaling: every rank owns
---envs-per-gpu independent envs; there is no collective on the data path (envs
-never interact); the only collectives are the barrier and the max-over-ranks of
-the elapsed time that the bench contract asks for.
+-> sensor / reward / terminal addons (and the camera render for workloads with a
+camera), followed by the masked auto-reset of the envs whose terminal fired
+(SURVEY.md 8d).  The timed region drives the backend entry points
+(dg_world_step + dg_world_reset) the way a trainer would, from a replayed
+hipGraph; the eager ``env.step()`` API rates (dict and flat) are measured
+separately after it and reported as ``api_eager``.  Inputs are synthetic uniform
+random actions within each addon's declared action_space, generated before the
+timed region and already resident in HBM.
 
-Rank 0 prints ONE JSON line (schema in the task statement) with two extra
-objects: `roofline` (dominant kernel = step_kernel, timed live with HIP events
-on the launch stream) and `cpu_baseline` (the C oracle -- a port, NOT pybullet
+N > 1: weak scaling, one process per GPU, every rank owns --envs-per-gpu
+independent envs; no collective on the data path (envs never interact); the only
+collectives are the barrier and the max-over-ranks of the elapsed time the bench
+contract asks for.  ``python bench.py --gpus N`` WITHOUT torchrun's environment
+spawns the N ranks itself (the parent never touches a GPU); under
+``python -m torch.distributed.run`` it is a rank.
+
+Rank 0 prints ONE JSON line (schema in the task statement) with extra objects:
+``roofline`` (dominant kernel timed live with HIP events on the launch stream),
+``solver`` (live Gauss-Seidel / IK iteration statistics from the kernel's
+diagnostics buffer), ``aged`` (the same timed loop after --age-steps more
+steps), ``api_eager`` and ``cpu_baseline`` (the C oracle -- a port, NOT pybullet
 -- on the box's host cores, N=1 only, bounded sample).
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 WORKLOADS = {
     # name: (config file, metric config description)
@@ -37,51 +45,94 @@ WORKLOADS = {
     'ur_high_5_joint': ('examples/ur_high_5/ur_high_5_joint.yaml', 'VARIANT of ur_high_5 with joint_controller(position) instead of ik_controller'),
     'drone_pilot': ('examples/drone_pilot/drone_pilot.yaml', 'drone_pilot.yaml as in the reference: quadrotor + 4 propellor + fell_over + reach_target'),
     'r2d2_maze': ('examples/r2d2_maze/r2d2_maze.yaml', 'r2d2_maze: R2D2 stand-in (mass 50, 4 velocity-driven wheels) among 119 fixed walls, tools/generate_maze.py --seed 7'),
-    'from_the_readme': ('examples/from_the_readme/from_the_readme.yaml', 'from_the_readme.yaml: Jaco + table + 1:10 R2D2 with a 200x200 gripper camera (rendered every step)'),
+    'from_the_readme': ('examples/from_the_readme/from_the_readme.yaml', 'from_the_readme.yaml: Jaco + table + 1:10 R2D2; the 200x200 gripper camera (rgb + depth) is rendered inside every timed step'),
     'marbles': ('tests/golden/basic_env_nocam.yaml', 'reference test fixture basic_env.yaml minus the camera: 3 marbles + plane + external_force'),
+    'ur5_gripper': ('tests/golden/ur5_gripper.yaml', 'UR5 with the two-finger gripper asset (12-DoF tree), joint_controller'),
 }
+DEFAULT_ENVS = {'r2d2_maze': 4096, 'from_the_readme': 1024}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD-32; MI355X_MICROARCH.md
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """Parent of an N-rank run started as plain ``python bench.py --gpus N``: spawns one child per GPU with
+    torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), forwards their output and exits with the
+    first non-zero child status (the other children are then terminated by PID).  The parent makes no HIP / CUDA
+    call -- ``torch.cuda.device_count()`` does not initialise the runtime on this image."""
+    n = args.gpus
+    if not args.selftest_launcher:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print('bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks than asked' % (n, have), file=sys.stderr)
+            return 2
+    port = args.master_port or free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print('bench.py: rank %d exited with status %d; stopping the other ranks' % (r, code), file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    if args.selftest_launcher:
+        import torch
+        print('launcher: parent cuda_initialized=%s' % torch.cuda.is_initialized(), file=sys.stderr)
+    return rc
+
+
+def selftest_rank(args):
+    """CPU-only rank body for tests/test_bench_launcher.py: same rendezvous, barrier and max-over-ranks as the real
+    bench (gloo instead of RCCL), no GPU call."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = int(os.environ['RANK']), int(os.environ['LOCAL_RANK']), int(os.environ['WORLD_SIZE'])
+    if os.environ.get('DG_BENCH_SELFTEST_FAIL_RANK') == str(rank):
+        sys.exit(3)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.barrier()
+    elapsed = torch.tensor([0.25 + rank], dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, local_rank, args.envs_per_gpu or 16384))
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'ranks': seen, 'elapsed_max': float(elapsed.item()),
+                          'cuda_initialized': torch.cuda.is_initialized()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------- helpers
 def action_bounds(env):
+    import torch
     from diy_gym_amd.utils import flatten, get_bounds_for_space
-    lo = flatten(get_bounds_for_space(env.action_space, True))
-    hi = flatten(get_bounds_for_space(env.action_space, False))
+    space = getattr(env, 'original_action_space', env.action_space)
+    lo = flatten(get_bounds_for_space(space, True))
+    hi = flatten(get_bounds_for_space(space, False))
     return torch.as_tensor(lo, dtype=torch.float32), torch.as_tensor(hi, dtype=torch.float32)
 
 
-def algorithmic_bytes_per_env_step(layout):
-    """Compulsory HBM traffic of one env-step: persistent state read once and written once,
-    actions read, observations / rewards / terminals / collapsed outputs written (DESIGN.md 'Measurement')."""
-    return 2 * 4 * layout.state_dim + 4 * layout.act_dim + 4 * layout.obs_dim + 4 * layout.rew_dim + layout.term_dim + 4 + 1
-
-
-def cpu_baseline(cfg, act_dim, lo, hi, seconds=12.0):
-    """Times the C oracle (same algorithm, fp64) on the host cores with the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import oracle_backend
-    from diy_gym_amd import DIYGym
-    omp = os.path.join(ROOT, 'oracle', 'libdgsim_oracle_omp.so')
-    cores = usable_cores()
-    os.environ['OMP_NUM_THREADS'] = str(cores)
-    if os.path.isfile(omp):
-        oracle_backend._LIB = None
-        oracle_backend.ORACLE_LIB = omp
-    else:
-        cores = 1
-    envs = 64 * cores
-    env = DIYGym(cfg, num_envs=envs, seed=1234, backend_factory=oracle_backend.OracleBackend)
-    gen = torch.Generator().manual_seed(99)
-    act = lo + (hi - lo) * torch.rand((envs, act_dim), generator=gen)
-    env.sim.step(env._all_slots, act)  # warm
-    steps, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        env.sim.step(env._all_slots, act)
-        steps += 1
-    dt = time.time() - t0
-    return {'value': envs * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d envs x %d steps of the same config in %.1f s, C oracle (fp64, OpenMP over envs); pybullet itself is %s' %
-                      (envs, steps, dt, pybullet_status())}
+def algorithmic_bytes_per_env_step(layout, image_bytes=0):
+    """Compulsory HBM traffic of one env-step: persistent state read once and written once, actions read,
+    observations / rewards / terminals / collapsed outputs written, camera images written (DESIGN.md 'Measurement')."""
+    return 2 * 4 * layout.state_dim + 4 * layout.act_dim + 4 * layout.obs_dim + 4 * layout.rew_dim + layout.term_dim + 4 + 1 + image_bytes
 
 
 def usable_cores():
@@ -110,24 +161,85 @@ def pybullet_status():
         return 'unavailable on this box'
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300)
-    ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--workload', default='ur_high_5', choices=sorted(WORKLOADS))
-    ap.add_argument('--envs-per-gpu', type=int, default=None, help='default: the size BASELINE.json quotes for the workload')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-auto-reset', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='time the eager launch loop instead of a replayed hipGraph')
-    args = ap.parse_args()
+def cpu_baseline(cfg, act_dim, lo, hi, seconds=12.0):
+    """Times the C oracle (same algorithm, fp64) on the host cores with the same workload."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_backend
+    from diy_gym_amd import DIYGym
+    omp = os.path.join(ROOT, 'oracle', 'libdgsim_oracle_omp.so')
+    cores = usable_cores()
+    os.environ['OMP_NUM_THREADS'] = str(cores)
+    if os.path.isfile(omp):
+        oracle_backend._LIB = None
+        oracle_backend.ORACLE_LIB = omp
+    else:
+        cores = 1
+    envs = 64 * cores
+    env = DIYGym(cfg, num_envs=envs, seed=1234, backend_factory=oracle_backend.OracleBackend)
+    gen = torch.Generator().manual_seed(99)
+    act = lo + (hi - lo) * torch.rand((envs, act_dim), generator=gen)
+    env.sim.step(env._all_slots, act)  # warm
+    steps, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        env.sim.step(env._all_slots, act)
+        steps += 1
+    dt = time.time() - t0
+    return {'value': envs * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d envs x %d steps of the same config in %.1f s, C oracle (fp64, OpenMP over envs); pybullet itself is %s' %
+                      (envs, steps, dt, pybullet_status())}
 
+
+def quantiles(t):
+    """mean / p50 / p99 / max of an integer tensor, as plain floats."""
+    f = t.float().flatten()
+    return {'mean': round(float(f.mean()), 2), 'p50': float(f.median()), 'p99': float(f.quantile(0.99)) if f.numel() < (1 << 24) else None,
+            'max': float(f.max())}
+
+
+def pmc_traffic(args, argv):
+    """--pmc: HBM bytes and VALU instructions per launch of the dominant kernel, measured NOW by running this very
+    command (fewer steps, no extra segments) under rocprofv3 in child processes, one counter pass each, before this
+    process touches the GPU.  Corrections per MI355X_MICROARCH.md (FETCH_SIZE / WRITE_SIZE in KiB; gfx950 FETCH_SIZE
+    counts half of a coalesced read)."""
+    import csv
+    import glob
+    import tempfile
+    out = {}
+    base = [a for a in argv if a != '--pmc']
+    inner = ['--steps', '40', '--warmup', '10', '--inner']
+    for counters in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES']):
+        d = tempfile.mkdtemp(prefix='dg_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
+        cmd = ['rocprofv3', '--pmc'] + counters + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + inner
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True, cwd='/tmp')
+        except Exception as exc:
+            print('bench.py: rocprofv3 pass %s failed (%s); traffic stays null' % (counters, exc), file=sys.stderr)
+            return None
+        agg = {}
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if args.kernel_filter in r['Kernel_Name']:
+                    agg.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+        for k, v in agg.items():
+            out[k] = sum(v) / len(v)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(args, argv):
+    import numpy as np
+    import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     distributed = world > 1
+
+    pmc = None
+    if args.pmc and not distributed and not args.inner:
+        args.kernel_filter = 'render_kernel' if args.workload == 'from_the_readme' else 'step_kernel'
+        pmc = pmc_traffic(args, argv)  # child processes; this process has not touched the GPU yet
+
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
@@ -136,26 +248,34 @@ def main():
 
     import diy_gym_amd.examples  # noqa: F401
     from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
     cfg_rel, cfg_desc = WORKLOADS[args.workload]
     cfg = os.path.join(ROOT, cfg_rel)
-    B = args.envs_per_gpu or {'r2d2_maze': 4096, 'from_the_readme': 1024}.get(args.workload, 16384)
+    B = args.envs_per_gpu or DEFAULT_ENVS.get(args.workload, 16384)
     env = DIYGym(cfg, num_envs=B, device=device, seed=1234, env_index_base=rank * B)
     lo, hi = action_bounds(env)
     gen = torch.Generator().manual_seed(1234 + rank)
     ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to(device) for _ in range(8)]
     sim, slots = env.sim, env._all_slots
     auto_reset = not args.no_auto_reset
+    cameras = [a for r in env.receptors.values() for a in r.addons.values() if hasattr(a, 'camera_index')]
+    image_bytes = 0
+    for cam in cameras:  # allocate the image buffers once; the timed step renders into them
+        cam.observe()
+        image_bytes += sum(t.numel() * t.element_size() for t in cam._buffers if t is not None) // B
 
     def one_step(i):
         sim.step(slots, ring[i % len(ring)])
+        for cam in cameras:
+            sim.render(cam.camera_index, *cam._buffers)
         if auto_reset:
             sim.reset(sim.term_flag)
 
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    # The timed region replays a hipGraph of len(ring) consecutive steps (step + masked auto-reset each): the work
-    # is identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.3 ms kernels.
+    # The timed region replays a hipGraph of len(ring) consecutive steps (step [+ render] + masked auto-reset each): the
+    # work is identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.2 ms kernels.
     graph, R = None, len(ring)
     if not args.eager:
         try:
@@ -171,84 +291,211 @@ def main():
         except Exception as exc:  # pragma: no cover
             print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
             graph = None
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+
+    def timed(steps):
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    if graph is not None:
-        for _ in range(args.steps // R):
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        if graph is not None:
+            for _ in range(steps // R):
+                graph.replay()
+            done = (steps // R) * R
+        for i in range(done, steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(args.steps)
+    episodes_main = float(sim.state[1, :B].sum().item()) - B  # DG_ST_EPISODE summed over envs
+
+    def kernel_times(n):
+        """Average duration of the dominant kernel(s): HIP events around the launches, on the launch stream (torch's
+        current stream IS the stream the C-ABI launches on), same inputs; events cannot be recorded per launch inside
+        a replayed graph, so this runs right after the timed region."""
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        for i in range(n):
+            ev[i][0].record()
+            sim.step(slots, ring[i % R])
+            ev[i][1].record()
+            for cam in cameras:
+                sim.render(cam.camera_index, *cam._buffers)
+            ev[i][2].record()
+            if auto_reset:
+                sim.reset(sim.term_flag)
+        torch.cuda.synchronize()
+        return (float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])))
+
+    step_ms, render_ms = kernel_times(min(64, args.steps))
+
+    # live solver statistics from the kernel's diagnostics buffer (a separate, untimed segment: the production
+    # launches above carry no diagnostics)
+    solver = None
+    if rank == 0 and not args.inner:
+        d = sim.enable_diagnostics()
+        acc = []
+        for i in range(16):
+            one_step(i)
+            acc.append(d.clone())
+        torch.cuda.synchronize()
+        sim.disable_diagnostics()
+        D = torch.stack(acc)  # [16, B, 8]
+        n_ik = sum(1 for r in env.receptors.values() for a in r.addons.values() if type(a).__name__ == 'InverseKinematicsController')
+        per_wave = D[:, :, sim.DIAG_PGS_ITERS].reshape(16, -1, min(sim.envs_per_wave, B)).max(2).values if B % sim.envs_per_wave == 0 else None
+        solver = {'iteration_cap': int(env.builder.solver_iterations), 'substeps': env.layout.substeps,
+                  'pgs_iterations_last_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS]),
+                  'pgs_iterations_first_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS_FIRST]),
+                  'pgs_iterations_wavefront_max': quantiles(per_wave) if per_wave is not None else None,
+                  'contacts_per_env': quantiles(D[:, :, sim.DIAG_CONTACTS]),
+                  'ik_iteration_cap': int(env.builder.params['ik_iterations']) if n_ik else None,
+                  'ik_iterations': quantiles(D[:, :, sim.DIAG_IK_ITERS:sim.DIAG_IK_ITERS + min(n_ik, sim.DIAG_N_IK)]) if n_ik else None,
+                  'sample': '16 steps after the timed region, every env'}
+
+    # aged segment: the same loop after --age-steps more (untimed) steps of the same random-action rollout
+    aged = None
+    if args.age_steps > 0 and not args.inner:
+        for i in range(args.age_steps // R if graph is not None else 0):
             graph.replay()
-        done = (args.steps // R) * R
-    for i in range(done, args.steps):
-        one_step(i)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+        for i in range((args.age_steps // R) * R if graph is not None else 0, args.age_steps):
+            one_step(i)
+        el = timed(args.steps)
+        a_step_ms, a_render_ms = kernel_times(min(32, args.steps))
+        aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps, 'ms_per_step_aged': el / args.steps * 1e3,
+                'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
+                'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B}
+
+    # eager public-API rates: env.step() with the reference's dict actions, and with flatten_actions /
+    # flatten_observations + collapsed reward / terminal (the trainer-facing fast path); auto-reset as above
+    api = None
+    if rank == 0 and not args.inner and not args.no_api:
+        from diy_gym_amd.utils import unflatten
+        n_api = 100
+        dict_ring = [unflatten(r, env.action_space, batch_dims=1) for r in ring] if lo.numel() else [{} for _ in ring]
+        for i in range(5):
+            env.step(dict_ring[i % R])
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # dominant-kernel duration: HIP events around dg_world_step on the launch stream, same inputs, right after the
-    # timed region (events cannot be recorded per launch inside a replayed graph)
-    ncal = min(64, args.steps)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ncal)]
-    for i in range(ncal):
-        ev[i][0].record()
-        sim.step(slots, ring[i % R])
-        ev[i][1].record()
-        if auto_reset:
-            sim.reset(sim.term_flag)
-    torch.cuda.synchronize()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    resets = float(sim.state[1, :B].sum().item())  # DG_ST_EPISODE summed over envs
+        t0 = time.perf_counter()
+        for i in range(n_api):
+            _, _, term, _ = env.step(dict_ring[i % R])
+            if auto_reset:
+                env.reset(sim.term_flag)
+        torch.cuda.synchronize()
+        dict_ms = (time.perf_counter() - t0) / n_api * 1e3
+        api = {'steps': n_api, 'dict_api_ms_per_step': dict_ms, 'dict_api_env_steps_per_s': B / dict_ms * 1e3}
+        try:
+            conf = Configuration.from_file(cfg)
+            for k, v in (('flatten_actions', True), ('flatten_observations', True), ('sum_rewards', True)):
+                conf.set(k, v)
+            if not (conf.get('terminal_if_any', False) or conf.get('terminal_if_all', False)):
+                conf.set('terminal_if_any', True)
+            env2 = DIYGym(conf, num_envs=B, device=device, seed=1234, env_index_base=rank * B)
+            for i in range(5):
+                env2.step(ring[i % R])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_api):
+                _, _, term, _ = env2.step(ring[i % R])
+                if auto_reset:
+                    env2.reset(term)
+            torch.cuda.synchronize()
+            flat_ms = (time.perf_counter() - t0) / n_api * 1e3
+            api.update({'flat_api_ms_per_step': flat_ms, 'flat_api_env_steps_per_s': B / flat_ms * 1e3})
+            env2.close()
+        except Exception as exc:  # pragma: no cover
+            api['flat_api_error'] = repr(exc)
 
     if rank == 0:
         total_envs = B * world
         value = total_envs * args.steps / elapsed
-        bytes_unit = algorithmic_bytes_per_env_step(env.layout)
-        achieved = bytes_unit * B / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-        if os.path.isfile(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload)
-            except Exception:
-                traffic = None
-        # informative: share of the chip's VALU issue slots the kernel used (wave-instructions from the committed PMC
-        # pass of the same command x 4 cycles each, over 256 CUs x 4 SIMDs x the live kernel time at 2.4 GHz)
-        valu_frac = None
-        pmc_sq = os.path.join(ROOT, 'profiles', 'r1_ur_high_5_16384_pmc_step_kernel.json')
-        if args.workload == 'ur_high_5' and B == 16384 and os.path.isfile(pmc_sq):
-            try:
-                valu = json.load(open(pmc_sq))['per_launch_means'].get('SQ_INSTS_VALU')
-                valu_frac = valu * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9) if valu else None
-            except Exception:
-                valu_frac = None
+        render_bound = bool(cameras) and render_ms > step_ms * 0.2
+        state_bytes = algorithmic_bytes_per_env_step(env.layout)
+        # the dominant kernel for the roofline: the step kernel, except for camera workloads whose image writes are
+        # the HBM-bound part of the step (SURVEY 8d cfg5) -- there the render kernel is quoted
+        if args.workload == 'from_the_readme':
+            kname, kms, kbytes = 'render_kernel', render_ms, image_bytes
+        else:
+            kname, kms, kbytes = ('step_kernel_par' if getattr(sim, 'par', False) else 'step_kernel'), step_ms, state_bytes
+        achieved = kbytes * B / (kms * 1e-3) / 1e9
+        traffic = valu_frac = wait_frac = None
+        if pmc:
+            if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
+                traffic = (2.0 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024.0
+            if 'SQ_INSTS_VALU' in pmc:  # one VALU wave-instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
+                valu_frac = pmc['SQ_INSTS_VALU'] * 2.0 / (SIMDS * kms * 1e-3 * CLOCK_HZ)
+            if pmc.get('SQ_WAVE_CYCLES'):
+                wait_frac = pmc.get('SQ_WAIT_ANY', 0.0) / pmc['SQ_WAVE_CYCLES']
         out = {
             'metric': 'env steps/sec (whole node)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s x %d envs per GPU' % (args.workload, B), 'what': cfg_desc, 'envs_total': total_envs,
-                       'timestep': 1.0 / 240.0, 'substeps': env.layout.substeps, 'solver_iterations': int(env.builder.solver_iterations),
-                       'auto_reset': auto_reset, 'launch': 'hipGraph replay of %d-step segments' % R if graph is not None else 'eager', 'episodes_finished_rank0': resets - B, 'parallelism': 'independent env shards x%d, no collective' % world,
-                       'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes},
+                       'timestep': 1.0 / 240.0, 'substeps': env.layout.substeps, 'solver_iteration_cap': int(env.builder.solver_iterations),
+                       'auto_reset': auto_reset, 'timed_path': 'backend entry points dg_world_step%s + dg_world_reset(term_flag); env.step() rates are in api_eager' % (' + dg_world_render' if cameras else ''),
+                       'launch': 'hipGraph replay of %d-step segments' % R if graph is not None else 'eager',
+                       'episodes_finished_rank0': episodes_main, 'parallelism': 'independent env shards x%d, no collective' % world,
+                       'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes,
+                       'parity': 'vs the C oracle only; parity with pybullet itself is UNPINNED (DESIGN.md 4)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'step_kernel_par' if getattr(sim, 'lanes', 0) == 64 and args.workload.startswith('ur_high_5') else 'step_kernel', 'kernel_ms': kernel_ms, 'bytes_per_env_step': bytes_unit,
+                         'traffic': traffic, 'kernel': kname, 'kernel_ms': kms, 'bytes_per_env_step': kbytes,
+                         'step_kernel_ms': step_ms, 'render_kernel_ms': render_ms if cameras else None,
                          'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
-                         'valu_issue_frac': valu_frac,
-                         'note': 'the step kernel keeps all per-env scratch in LDS; it is bound by instruction issue and latency of one '
-                                 'wavefront per SIMD (three per workgroup), not by HBM (DESIGN.md Measurement)'},
+                         'limiter': ('HBM image writes' if args.workload == 'from_the_readme' else
+                                     'NOT HBM: instruction issue and latency of one wavefront per SIMD; the hbm fraction is reported because the contract asks for it'),
+                         'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac,
+                         'pmc_source': 'rocprofv3 child runs of this command, this invocation' if pmc else None},
+            'solver': solver, 'aged': aged, 'api_eager': api,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if render_bound and args.workload != 'from_the_readme':
+            out['roofline']['note'] = 'camera render takes %.2f ms of the step' % render_ms
+        if world == 1 and not args.no_cpu_baseline and not args.inner:
             out['cpu_baseline'] = cpu_baseline(cfg, lo.numel(), lo, hi)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=304)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--workload', default='ur_high_5', choices=sorted(WORKLOADS))
+    ap.add_argument('--envs-per-gpu', type=int, default=None, help='default: the size BASELINE.json quotes for the workload')
+    ap.add_argument('--age-steps', type=int, default=4000, help='untimed steps before the second (aged) timed segment; 0 disables it')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-auto-reset', action='store_true')
+    ap.add_argument('--no-api', action='store_true', help='skip the eager env.step() API measurements')
+    ap.add_argument('--eager', action='store_true', help='time the eager launch loop instead of a replayed hipGraph')
+    ap.add_argument('--pmc', action='store_true', help='N=1: measure roofline.traffic / VALU share now, with rocprofv3 child runs of this command')
+    ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)  # the profiled child of --pmc: timed loop only
+    ap.add_argument('--master-port', type=int, default=0)
+    ap.add_argument('--selftest-launcher', action='store_true', help='CPU-only rendezvous test of the N-rank launcher (gloo)')
+    args = ap.parse_args()
+    argv = sys.argv[1:]
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    world_env = os.environ.get('WORLD_SIZE')
+    if world_env is None:
+        if args.gpus > 1:
+            sys.exit(launch(args, argv))  # this process stays GPU-free
+    elif int(world_env) != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%s; refusing to report a different GPU count than asked' % (args.gpus, world_env))
+    if args.selftest_launcher:
+        if world_env is None:
+            os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+        return selftest_rank(args)
+    run_rank(args, argv)
 
 
 if __name__ == '__main__':

@@ -28,6 +28,7 @@ SYMBOLS = {
                                          ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64, ctypes.POINTER(_vp)]),
     'dg_world_destroy': (None, [_vp]),
     'dg_world_dims': (ctypes.c_int32, [_vp, _c_i32p]),
+    'dg_world_kernel_name': (ctypes.c_char_p, [_vp]),
     'dg_world_get_motor_cfg': (ctypes.c_int32, [_vp, _c_f64p]),
     'dg_world_set_motor_cfg': (ctypes.c_int32, [_vp, _c_f64p]),
     'dg_world_init_state': (ctypes.c_int32, [_vp, _vp, _vp]),
@@ -57,6 +58,11 @@ def load_library(path=None):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _scene_constants():
+    from .scene import K
+    return K
 
 
 def _ptr(t):
@@ -115,14 +121,47 @@ class HipBackend:
         except Exception:
             pass
 
+    # -- argument checks ------------------------------------------------------
+    # The kernels index raw device pointers: a CPU tensor, a strided view, a wrong width or a short mask would be an
+    # out-of-bounds device access, not a Python error -- so every caller-supplied tensor is checked here.
+    def _require(self, name, t, shape, dtype):
+        if not isinstance(t, torch.Tensor):
+            raise ValueError('%s must be a torch.Tensor, got %s' % (name, type(t).__name__))
+        if t.device != self.device:
+            raise ValueError('%s is on %s, this backend runs on %s' % (name, t.device, self.device))
+        if t.dtype != dtype:
+            raise ValueError('%s must be %s, got %s' % (name, dtype, t.dtype))
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError('%s must have shape %s, got %s' % (name, tuple(shape), tuple(t.shape)))
+        if not t.is_contiguous():
+            raise ValueError('%s must be contiguous' % name)
+        return t
+
+    def _require_numel(self, name, t, numel, dtype):
+        if not isinstance(t, torch.Tensor):
+            raise ValueError('%s must be a torch.Tensor, got %s' % (name, type(t).__name__))
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous() or t.numel() != numel:
+            raise ValueError('%s must be a contiguous %s tensor of %d elements on %s, got %s %s on %s' %
+                             (name, dtype, numel, self.device, t.dtype, tuple(t.shape), t.device))
+        return t
+
     # -- step path --------------------------------------------------------
     def reset(self, mask=None):
+        """``mask``: None (all envs) or one flag per env; bool / uint8 masks on the backend's device are used as they
+        are (a bool tensor is reinterpreted, not copied), anything else is converted."""
         if mask is not None:
-            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if not isinstance(mask, torch.Tensor):
+                mask = torch.as_tensor(mask)
+            if mask.numel() != self.num_envs:
+                raise ValueError('reset mask must have one element per env (%d), got shape %s' % (self.num_envs, tuple(mask.shape)))
+            if mask.dtype == torch.bool and mask.device == self.device and mask.is_contiguous():
+                mask = mask.view(torch.uint8)
+            elif mask.dtype != torch.uint8 or mask.device != self.device or not mask.is_contiguous():
+                mask = (mask != 0).to(device=self.device, dtype=torch.uint8).contiguous()
         self._check(self.lib.dg_world_reset(self.handle, _ptr(self.state), _ptr(mask), _ptr(self.obs), self._stream()))
 
     def step(self, update_mask, actions=None):
-        act = self.act if actions is None else actions
+        act = self.act if actions is None else self._require('actions', actions, (self.num_envs, max(self.act_dim, 1)), torch.float32)
         self._check(
             self.lib.dg_world_step(self.handle, _ptr(self.state), _ptr(act) if self.act_dim else None,
                                    ctypes.c_uint64(update_mask), _ptr(self.obs), _ptr(self.rew), _ptr(self.term),
@@ -139,7 +178,22 @@ class HipBackend:
                                                   self._stream()))
         return out
 
+    def camera_resolution(self, camera):
+        I, K = self.layout.I, _scene_constants()
+        if not 0 <= int(camera) < int(I[K.H_N_CAMERAS]):
+            raise ValueError('camera %d out of range (scene has %d)' % (camera, int(I[K.H_N_CAMERAS])))
+        ci = I[I[K.H_OFF_CAMERA_I] + int(camera) * K.CI_STRIDE:]
+        return int(ci[K.CI_WIDTH]), int(ci[K.CI_HEIGHT])
+
     def render(self, camera, rgb=None, depth=None, seg=None):
+        w, h = self.camera_resolution(camera)
+        px = self.num_envs * w * h
+        if rgb is not None:
+            self._require_numel('rgb', rgb, 3 * px, torch.float32)
+        if depth is not None:
+            self._require_numel('depth', depth, px, torch.float32)
+        if seg is not None:
+            self._require_numel('seg', seg, px, torch.int32)
         self._check(self.lib.dg_world_render(self.handle, _ptr(self.state), int(camera), _ptr(rgb), _ptr(depth), _ptr(seg), self._stream()))
 
     def motor_cfg(self):
@@ -151,10 +205,25 @@ class HipBackend:
         cfg = np.ascontiguousarray(cfg, dtype=np.float64)
         self._check(self.lib.dg_world_set_motor_cfg(self.handle, cfg.ctypes.data_as(_c_f64p)))
 
+    # columns of the diagnostics buffer (include/diygym_hip.h DG_DIAG_*)
+    DIAG_STRIDE, DIAG_CONTACTS, DIAG_PGS_ITERS, DIAG_PGS_ITERS_FIRST, DIAG_CONTACTS_FIRST, DIAG_IK_ITERS, DIAG_N_IK = 8, 0, 1, 2, 3, 4, 4
+
     def enable_diagnostics(self):
-        self.diag = torch.zeros((self.num_envs, 2), dtype=torch.int32, device=self.device)
+        self.diag = torch.zeros((self.num_envs, self.DIAG_STRIDE), dtype=torch.int32, device=self.device)
         self._check(self.lib.dg_world_set_diag_buffer(self.handle, _ptr(self.diag)))
         return self.diag
+
+    def disable_diagnostics(self):
+        self._check(self.lib.dg_world_set_diag_buffer(self.handle, None))
+
+    @property
+    def kernel_name(self):
+        return self.lib.dg_world_kernel_name(self.handle).decode()
+
+    @property
+    def par(self):
+        """True when the step runs as the four-wavefront helper-wave kernel."""
+        return self.kernel_name.startswith('step_kernel_par')
 
     SECTIONS = ['update_ops', 'kinematics', 'narrow_phase', 'aba', 'minv', 'rows', 'pgs_other', 'integrate', 'outputs', 'pgs_motor', 'pgs_limit',
                 'pgs_contact']
@@ -180,4 +249,6 @@ class HipBackend:
 
     def set_state(self, arr):
         t = torch.as_tensor(np.asarray(arr, dtype=np.float32), device=self.device)
+        if tuple(t.shape) != (self.num_envs, self.state_dim):
+            raise ValueError('state must have shape %s, got %s' % ((self.num_envs, self.state_dim), tuple(t.shape)))
         self.state[:, :self.num_envs] = t.t()

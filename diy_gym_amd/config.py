@@ -15,9 +15,10 @@ _MISSING = object()
 
 
 class Configuration:
-    def __init__(self, name, node):
+    def __init__(self, name, node, source_dir=''):
         self.name = name
         self.node = node if node is not None else {}
+        self.source_dir = source_dir  # directory of the YAML file (relative URDF paths resolve against it)
 
     @classmethod
     def from_file(cls, path):
@@ -26,7 +27,7 @@ class Configuration:
         if tree is None:
             tree = {}
         stem = os.path.splitext(os.path.basename(path))[0]
-        return cls(tree.get('name', stem), tree)
+        return cls(tree.get('name', stem), tree, os.path.dirname(os.path.abspath(path)))
 
     @classmethod
     def from_dict(cls, name, tree):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,18 @@ static int fail(int code, const char* fmt, ...) {
 }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(DG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// Every entry point runs with the world's device current and puts the caller's device back on the way out (a torch
+// process may have another device current; launches and frees must not land there).
+struct DeviceGuard {
+  int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define DG_ON_DEVICE(dev) DeviceGuard guard_(dev); if (guard_.err != hipSuccess) return fail(DG_ERR_HIP, "hipSetDevice(%d): %s", (dev), hipGetErrorString(guard_.err))
+
 __global__ void init_state_kernel(const float* init, float* state, int state_dim, int stride) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x; if (e >= stride) return;
   for (int k = 0; k < state_dim; k++) state[(size_t)k * stride + e] = init[k];
@@ -45,7 +58,33 @@ struct dg_world {
   bool par = false;  // step runs as two wavefronts per workgroup (helper wave)
   float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
+  ~dg_world() {  // also the clean-up of a dg_world_create that failed half way
+    DeviceGuard g(device);
+    (void)hipFree(d_gws); (void)hipFree(d_render_table); (void)hipFree(d_blob_i); (void)hipFree(d_blob_f); (void)hipFree(d_plan); (void)hipFree(d_init);
+  }
 };
+
+// Bounds of the blob's tables against the array lengths the caller passed: a malformed blob must fail here, not read
+// out of bounds on the host or the device.
+static const char* check_blob(const int32_t* I, int64_t n_i, int64_t n_f) {
+  struct T { int off, count_idx, stride; bool is_f; const char* name; };
+  const T tables[] = {
+    {DG_H_OFF_BODY_I, DG_H_N_BODIES, DG_BI_STRIDE, false, "body ints"}, {DG_H_OFF_LINK_I, DG_H_N_LINKS, DG_LI_STRIDE, false, "link ints"},
+    {DG_H_OFF_FRAME_I, DG_H_N_FRAMES, DG_FI_STRIDE, false, "frame ints"}, {DG_H_OFF_SHAPE_I, DG_H_N_SHAPES, DG_SI_STRIDE, false, "shape ints"},
+    {DG_H_OFF_PAIR_I, DG_H_N_PAIRS, DG_PI_STRIDE, false, "pairs"}, {DG_H_OFF_GROUP_I, DG_H_N_GROUPS, DG_GI_STRIDE, false, "pair groups"},
+    {DG_H_OFF_CAMERA_I, DG_H_N_CAMERAS, DG_CI_STRIDE, false, "camera ints"}, {DG_H_OFF_OP_I, DG_H_N_OPS, DG_OI_STRIDE, false, "op ints"},
+    {DG_H_OFF_ILIST, DG_H_N_ILIST, 1, false, "int list"},
+    {DG_H_OFF_BODY_F, DG_H_N_BODIES, DG_BF_STRIDE, true, "body floats"}, {DG_H_OFF_LINK_F, DG_H_N_LINKS, DG_LF_STRIDE, true, "link floats"},
+    {DG_H_OFF_FRAME_F, DG_H_N_FRAMES, DG_FF_STRIDE, true, "frame floats"}, {DG_H_OFF_SHAPE_F, DG_H_N_SHAPES, DG_SF_STRIDE, true, "shape floats"},
+    {DG_H_OFF_POINT_F, DG_H_N_POINTS, 3, true, "hull points"}, {DG_H_OFF_PLANE_F, DG_H_N_PLANES, 4, true, "hull planes"},
+    {DG_H_OFF_CAMERA_F, DG_H_N_CAMERAS, DG_CF_STRIDE, true, "camera floats"}, {DG_H_OFF_OP_F, DG_H_N_OPS, DG_OF_STRIDE, true, "op floats"},
+    {DG_H_OFF_FLIST, DG_H_N_FLIST, 1, true, "float list"}};
+  for (const T& t : tables) {
+    const int64_t off = I[t.off], cnt = I[t.count_idx], lim = t.is_f ? n_f : n_i;
+    if (cnt < 0 || off < (t.is_f ? DG_HF_FLOAT_COUNT : DG_H_INT_COUNT) || off + cnt * t.stride > lim) return t.name;
+  }
+  return nullptr;
+}
 
 extern "C" {
 
@@ -60,8 +99,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   const int nb = I[DG_H_N_BODIES], nl = I[DG_H_N_LINKS];
   if (nl > DG_MAX_LINKS) return fail(DG_ERR_UNSUPPORTED, "%d links > %d supported", nl, DG_MAX_LINKS);
   if (nb > DG_MAX_BODIES) return fail(DG_ERR_UNSUPPORTED, "%d bodies > %d supported", nb, DG_MAX_BODIES);
-  HIP_TRY(hipSetDevice(device));
-  dg_world* w = new dg_world();
+  if (n_f < DG_HF_FLOAT_COUNT) return fail(DG_ERR_BAD_SCENE, "float array shorter than its header");
+  if (const char* bad = check_blob(I, n_i, n_f)) return fail(DG_ERR_BAD_SCENE, "scene table '%s' does not fit the arrays passed (n_i=%lld, n_f=%lld)", bad, (long long)n_i, (long long)n_f);
+  if (I[DG_H_N_SHAPES] > 4096) return fail(DG_ERR_UNSUPPORTED, "%d shapes > 4096 supported", I[DG_H_N_SHAPES]);
+  if (I[DG_H_N_TERM_GROUPS] > 64) return fail(DG_ERR_UNSUPPORTED, "%d receptors with terminal addons > 64 supported", I[DG_H_N_TERM_GROUPS]);
+  { int ndev = 0; HIP_TRY(hipGetDeviceCount(&ndev)); if (device < 0 || device >= ndev) return fail(DG_ERR_ARG, "device %d out of range (%d visible)", device, ndev); }
+  DG_ON_DEVICE(device);
+  std::unique_ptr<dg_world> holder(new dg_world());  // every early return below frees what was allocated so far
+  dg_world* w = holder.get();
   w->I.assign(I, I + n_i); w->F.assign(F, F + n_f); w->device = device; w->num_envs = num_envs; w->stride = env_stride;
   const int32_t* BI = I + I[DG_H_OFF_BODY_I]; const int32_t* LI = I + I[DG_H_OFF_LINK_I]; const int32_t* OI = I + I[DG_H_OFF_OP_I];
   // ---- LDS plan (slots per lane)
@@ -165,7 +210,6 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // pair descriptors in canonical order (lower shape type first, a box always second), one word per pair
   const size_t pd_off = plan.size();
   { const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
-    if (I[DG_H_N_SHAPES] > 4096) return fail(DG_ERR_UNSUPPORTED, "%d shapes > 4096 supported", I[DG_H_N_SHAPES]);
     for (int p = 0; p < I[DG_H_N_PAIRS]; p++) {
       const int sA = PIh[p * DG_PI_STRIDE + DG_PI_A], sB = PIh[p * DG_PI_STRIDE + DG_PI_B];
       const int tA = SIh[sA * DG_SI_STRIDE + DG_SI_TYPE], tB = SIh[sB * DG_SI_STRIDE + DG_SI_TYPE];
@@ -268,14 +312,18 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   if (w->ncam > 0) HIP_TRY(hipMalloc((void**)&w->d_render_table, sizeof(float) * (size_t)num_envs * (size_t)(sc.nsh * RS_STRIDE + w->ncam * RC_STRIDE)));
   // allow > 64 KiB of dynamic LDS for this mode's kernels
   HIP_TRY(launch_table(lanes).prepare(w->lds_bytes));
-  *out = w;
+  *out = holder.release();
   return DG_OK;
 }
 
-void dg_world_destroy(dg_world* w) {
-  if (!w) return;
-  (void)hipFree(w->d_gws); (void)hipFree(w->d_render_table); (void)hipFree(w->d_blob_i); (void)hipFree(w->d_blob_f); (void)hipFree(w->d_plan); (void)hipFree(w->d_init);
-  delete w;
+void dg_world_destroy(dg_world* w) { delete w; }  // ~dg_world frees the device allocations on the world's device
+
+const char* dg_world_kernel_name(const dg_world* w) {
+  if (!w) return "";
+  static thread_local char buf[96];
+  if (w->par) snprintf(buf, sizeof buf, "step_kernel_par (4 wavefronts per 64 envs)");
+  else snprintf(buf, sizeof buf, "step_kernel<%d>", w->lanes);
+  return buf;
 }
 
 int32_t dg_world_dims(const dg_world* w, int32_t dims[8]) {
@@ -298,6 +346,7 @@ int32_t dg_world_set_diag_buffer(dg_world* w, int32_t* diag) { if (!w) return fa
 
 int32_t dg_world_init_state(dg_world* w, float* state, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  DG_ON_DEVICE(w->device);
   hipLaunchKernelGGL(init_state_kernel, dim3((w->stride + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->d_init, state, w->sc.state_dim, w->stride);
   HIP_TRY(hipGetLastError());
   return DG_OK;
@@ -307,6 +356,7 @@ static dim3 grid_of(const dg_world* w) { const int per = envs_per_wave(w->lanes)
 
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  DG_ON_DEVICE(w->device);
   launch_table(w->lanes).reset(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, state, mask, obs, w->d_gws);
   HIP_TRY(hipGetLastError());
   return DG_OK;
@@ -315,6 +365,8 @@ int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* ob
 int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t update_mask, float* obs, float* rew, uint8_t* term,
                       float* rew_sum, uint8_t* term_flag, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  if (w->sc.act_dim > 0 && update_mask != 0 && !actions) return fail(DG_ERR_ARG, "update_mask selects controller addons but actions is NULL");
+  DG_ON_DEVICE(w->device);
   if (actions) {
     // motor gains / force limits are uniform over envs: the controller ops selected by the mask set them here
     // (p.setJointMotorControlArray's positionGains / velocityGains / forces; joint_controller.py:53-58, ik_controller.py:71-80)
@@ -345,6 +397,7 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
 int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
   if (camera < 0 || camera >= w->ncam) return fail(DG_ERR_ARG, "camera %d out of range (scene has %d)", camera, w->ncam);
+  DG_ON_DEVICE(w->device);
   launch_table(w->lanes).pose(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table, w->d_gws);
   HIP_TRY(hipGetLastError());
   const int32_t* I = w->I.data(); const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE;
@@ -359,6 +412,7 @@ int32_t dg_world_set_profile_buffer(dg_world* w, uint64_t* cycles) { if (!w) ret
 
 int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  DG_ON_DEVICE(w->device);
   launch_table(w->lanes).observe(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), obs, rew, term, rew_sum, term_flag, w->d_gws);
   HIP_TRY(hipGetLastError());
   return DG_OK;
@@ -374,6 +428,7 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
     for (int f = 0; f < w->sc.nfr; f++) if (FI[f * DG_FI_STRIDE + DG_FI_BODY] == body) { if (seen == frame) { gf = f; found = true; break; } seen++; }
     if (!found) return fail(DG_ERR_ARG, "body %d has no frame %d", body, frame);
   }
+  DG_ON_DEVICE(w->device);
   launch_table(w->lanes).frame(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), body, gf, com, out, w->d_gws);
   HIP_TRY(hipGetLastError());
   return DG_OK;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   if (primary) {
     for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
     prof.stamp(PS_KIN);
-    if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask);
+    if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask, -1, -1, diag);
     ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
     prof.stamp(PS_UPDATE);
   }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     ln.kinematics(sc.helper_body);
     __syncthreads();  // B0: every pose is in LDS
-    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1);
+    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1, diag);
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0);
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B0
   prof.stamp(PS_KIN);
-  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body);
+  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body, diag);
   ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
   __syncthreads();  // B0': the helper's motor targets are in the state
   prof.stamp(PS_UPDATE);

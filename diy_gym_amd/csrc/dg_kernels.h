@@ -1,9 +1,10 @@
 // dg_kernels.h -- the batched DIYGym step path as hand-written HIP for gfx950.
 //
-// One environment per lane.  A workgroup is ONE wavefront (64 threads); LANES of
-// its lanes own an environment each (64 normally; 32 or 16 when a scene's
-// per-env scratch would not fit 160 KiB of LDS at 64).  There is no
-// __syncthreads anywhere: all cross-lane traffic is wave ballots.
+// One environment per lane.  step_kernel runs a workgroup of ONE wavefront (64 threads); LANES of its lanes own
+// an environment each (64 normally; 32 / 16 / 8 / 4 when a scene's per-env scratch would not fit 160 KiB of LDS
+// at 64 -- the spare lanes then join the Gauss-Seidel sweeps) and all cross-lane traffic is wave ballots / DPP.
+// step_kernel_par (dg_entry.h) runs FOUR wavefronts per workgroup on the same 64 envs and the same LDS workspace
+// and hands work between them through __syncthreads.
 //
 // What the kernels replace (reference call sites):
 //   step_kernel   : DIYGym.step (diy_gym/diy_gym.py:187-209) = addon.update for
@@ -22,6 +23,7 @@
 #pragma once
 #include "dg_device.h"
 #include "../../include/diygym_scene.h"
+#include "../../include/diygym_hip.h"
 
 namespace dg {
 

@@ -1270,7 +1270,11 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   }  // unsliced
   prof.stamp(PS_PGS);
   if (primary) {
-  if (diag_out && ln.valid) { diag_out[2 * ln.env] = ncont; diag_out[2 * ln.env + 1] = iters_done; }
+  if (diag_out && ln.valid) {  // include/diygym_hip.h: dg_world_set_diag_buffer
+    int32_t* d = diag_out + (size_t)DG_DIAG_STRIDE * ln.env;
+    d[DG_DIAG_CONTACTS] = ncont; d[DG_DIAG_PGS_ITERS] = iters_done;
+    if (index == 0) { d[DG_DIAG_PGS_ITERS_FIRST] = iters_done; d[DG_DIAG_CONTACTS_FIRST] = ncont; }
+  }
   // ---- apply velocity changes and integrate positions
   for (int b = 0; b < sc.nb; b++) if (!(split_now && b == hb)) integrate_body(ln, b);  // split sweeps: the helper integrates its own body
   }  // primary
@@ -1309,7 +1313,7 @@ DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, fl
 // Transient layout: [q n][J 6n][v0 n][dth n].  POSE of the body is overwritten by trial poses
 // and must be refreshed by the caller afterwards.
 template <int LANES>
-DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane) {
+DGD int run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane) {
   const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
   const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
   const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
@@ -1325,13 +1329,14 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
   // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d
   const float lam2 = nullsp ? sc.HF[DG_HF_IK_LAMBDA_SQ] : sc.HF[DG_HF_IK_JOINT_DAMPING], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
   const float resid = sc.HF[DG_HF_IK_RESIDUAL];
-  bool live = live_lane;
+  bool live = live_lane; int iters = 0;
   for (int it = 0; it < sc.ik_iters; it++) {
     ln.kinematics(b, qo);
     V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, true, fp, fq, fv, fw, false);
     V3 ep = tp - fp;
     if (it > 0 && norm(ep) < resid) live = false;
     if (!__any(live)) break;
+    iters += live ? 1 : 0;
     float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
     if (use_orn) {
       Q4 dq = qmul(tq, qconj(fq)); if (dq.w < 0.f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
@@ -1395,6 +1400,7 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
     const float scl = mx > maxang ? maxang / mx : 1.0f;
     for (int k = 0; k < n; k++) if (live) ln.L(qo + k) += scl * ln.L(dto + k);
   }
+  return iters;
 }
 
 // Register-resident variant for serial chains of at most N joints on a fixed or floating base (every 6-axis arm):
@@ -1402,7 +1408,7 @@ DGD void run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane)
 // through LDS.  Same recursion as run_ik; selected per op at world creation (DG_IK_DEV_CHAIN).
 #define DG_IK_DEV_CHAIN 256
 template <int LANES, int N>
-DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_lane, float* qout) {
+DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_lane, float* qout) {
   const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
   const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
   const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
@@ -1487,12 +1493,13 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   // identity that equals J^T (J J^T + d I)^-1 e, i.e. the same 6x6 solve with lambda^2 = d
   const float lam2 = nullsp ? sc.HF[DG_HF_IK_LAMBDA_SQ] : sc.HF[DG_HF_IK_JOINT_DAMPING], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
   const float resid = sc.HF[DG_HF_IK_RESIDUAL];
-  bool live = live_lane;
+  bool live = live_lane; int iters = 0;
   for (int it = 0; it < sc.ik_iters; it++) {
     if (it > 0) fk();
     const V3 ep = tp - pe;
     if (it > 0 && norm(ep) < resid) live = false;
     if (!__any(live)) break;
+    iters += live ? 1 : 0;
     float dS[6] = {ep.x, ep.y, ep.z, 0.f, 0.f, 0.f};
     if (use_orn) {
       // M = Tm Re^T; rotation vector = axis * angle with axis sin = vee(M - M^T) / 2, cos = (tr M - 1) / 2
@@ -1560,14 +1567,16 @@ DGD void run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live
   }
 #pragma unroll
   for (int i = 0; i < N; i++) qout[i] = q[i];
+  return iters;
 }
 
 // ------------------------------------------------------------ addon program
 template <int LANES>
-DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask, int only_body = -1, int skip_body = -1) {
-  const DevScene& sc = ln.sc;
+DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask, int only_body = -1, int skip_body = -1, int32_t* diag = nullptr) {
+  const DevScene& sc = ln.sc; int ik_ord = -1;
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE; const int code = oi[DG_OI_CODE];
+    if (code == DG_OP_IK_CONTROL) ik_ord++;  // ordinal among the scene's inverse-kinematics ops (diagnostics column)
     if (code < DG_OP_JOINT_CONTROL || code > DG_OP_ADMITTANCE) continue;
     if ((only_body >= 0 && oi[DG_OI_BODY] != only_body) || oi[DG_OI_BODY] == skip_body) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ull)) continue;
@@ -1585,7 +1594,8 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
       float av[6] = {a[0], a[1], a[2], 0.f, 0.f, 0.f};
       if (oi[DG_OI_FLAGS] & DG_IK_USE_ORIENTATION) { av[3] = a[3]; av[4] = a[4]; av[5] = a[5]; }
       if (oi[DG_OI_FLAGS] & DG_IK_DEV_CHAIN) {
-        float qs[6]; run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
+        float qs[6]; const int ik_it = run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
+        if (diag && ln.valid && ik_ord < DG_DIAG_N_IK) diag[(size_t)DG_DIAG_STRIDE * ln.env + DG_DIAG_IK_ITERS + ik_ord] = ik_it;
         const int first = ln.bi(b)[DG_BI_FIRST_LINK];
         for (int k = 0; k < n; k++) {
           const int lo = ln.li(il[k])[DG_LI_STATE_OFF], j = il[k] - first; float v = qs[0];
@@ -1595,7 +1605,8 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
         }
         continue;  // POSE was not touched
       }
-      run_ik(ln, op, av, ln.valid);
+      { const int ik_it = run_ik(ln, op, av, ln.valid);
+        if (diag && ln.valid && ik_ord < DG_DIAG_N_IK) diag[(size_t)DG_DIAG_STRIDE * ln.env + DG_DIAG_IK_ITERS + ik_ord] = ik_it; }
       for (int k = 0; k < n; k++) {
         const int lo = ln.li(il[k])[DG_LI_STATE_OFF];
         ln.Sset(lo + DG_LS_TARGET_POS, ln.L(sc.tr_off + (il[k] - ln.bi(b)[DG_BI_FIRST_LINK]))); ln.Sset(lo + DG_LS_TARGET_VEL, 0.f);

@@ -43,7 +43,7 @@ class DIYGym(Receptor):
         Receptor.__init__(self)
         config = config_file if isinstance(config_file, Configuration) else Configuration.from_file(config_file)
         self.env = self
-        self.config_dir = os.path.dirname(os.path.abspath(config_file)) if isinstance(config_file, str) else ''
+        self.config_dir = config.source_dir
         self.name = config.name
         self.compat = num_envs is None
         self.num_envs = 1 if num_envs is None else int(num_envs)
@@ -201,7 +201,9 @@ class DIYGym(Receptor):
         if self.flatten_actions:
             if self._flat_fast and isinstance(action, torch.Tensor) and not self.compat:
                 # the flat action tensor already has the kernel's column order: hand it over as is
-                act = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, -1).contiguous()
+                if action.numel() != self.num_envs * self.layout.act_dim:
+                    raise ValueError('flat action must have %d x %d elements, got shape %s' % (self.num_envs, self.layout.act_dim, tuple(action.shape)))
+                act = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.layout.act_dim).contiguous() if self.layout.act_dim else None
                 self.sim.step(self._all_slots, act)
                 self._tick += 1
                 return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}

@@ -286,6 +286,8 @@ class SceneBuilder:
                 raise ValueError('more than 64 controller addons in one environment')
         if kind == 'term':
             if group not in self.term_groups:
+                if len(self.term_groups) >= 64:  # terminal_if_all folds the groups into a 64-bit mask on the device
+                    raise ValueError('more than 64 receptors with terminal addons in one environment')
                 self.term_groups.append(group)
             slot = self.term_groups.index(group)
         ioff, foff = len(self.ilist), len(self.flist)

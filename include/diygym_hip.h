@@ -58,6 +58,10 @@ void dg_world_destroy(dg_world* w);
  * wavefront, scratch in that buffer (chosen by dg_world_create from the scene's scratch footprint). */
 int32_t dg_world_dims(const dg_world* w, int32_t dims[8]);
 
+/* Name of the step kernel dg_world_step launches for this world (for benchmark / profile labels):
+ * "step_kernel<lanes>" or "step_kernel_par (...)".  The pointer is valid until the calling thread's next call. */
+const char* dg_world_kernel_name(const dg_world* w);
+
 /* Host-side view of the motor table (p.setJointMotorControlArray gains/forces,
  * uniform over envs): cfg[n_links][3] = kp, kd, max_force (<0: raw impulse). */
 int32_t dg_world_get_motor_cfg(const dg_world* w, double* cfg);
@@ -104,9 +108,12 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
  * flat pixel index = row * width + col, row 0 at the top; any pointer may be NULL. */
 int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream);
 
-/* Per-env diagnostics of the last step: diag[num_envs][2] = contact count,
- * solver iterations of the final substep (int32).  Optional; pass NULL to
- * disable (default).  The buffer must stay valid until changed. */
+/* Per-env diagnostics of the last step: diag[num_envs][DG_DIAG_STRIDE] (int32), columns DG_DIAG_*: contact count and
+ * Gauss-Seidel iterations of the final substep, the same two of the first substep, and the iterations each of the
+ * scene's first DG_DIAG_N_IK inverse-kinematics ops ran for that env.  Optional; pass NULL to disable (default).  The
+ * buffer must stay valid until changed. */
+enum { DG_DIAG_CONTACTS = 0, DG_DIAG_PGS_ITERS = 1, DG_DIAG_PGS_ITERS_FIRST = 2, DG_DIAG_CONTACTS_FIRST = 3, DG_DIAG_IK_ITERS = 4,
+       DG_DIAG_N_IK = 4, DG_DIAG_STRIDE = 8 };
 int32_t dg_world_set_diag_buffer(dg_world* w, int32_t* diag);
 
 /* Diagnostic build of the step kernel with in-kernel cycle stamps (s_memtime): when `cycles` is

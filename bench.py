@@ -340,8 +340,7 @@ def run_rank(args, argv):
 
     # live solver statistics from the kernel's diagnostics buffer (a separate, untimed segment: the production
     # launches above carry no diagnostics)
-    solver = None
-    if rank == 0 and not args.inner:
+    def solver_stats():
         d = sim.enable_diagnostics()
         acc = []
         for i in range(16):
@@ -352,14 +351,17 @@ def run_rank(args, argv):
         D = torch.stack(acc)  # [16, B, 8]
         n_ik = sum(1 for r in env.receptors.values() for a in r.addons.values() if type(a).__name__ == 'InverseKinematicsController')
         per_wave = D[:, :, sim.DIAG_PGS_ITERS].reshape(16, -1, min(sim.envs_per_wave, B)).max(2).values if B % sim.envs_per_wave == 0 else None
-        solver = {'iteration_cap': int(env.builder.solver_iterations), 'substeps': env.layout.substeps,
-                  'pgs_iterations_last_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS]),
-                  'pgs_iterations_first_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS_FIRST]),
-                  'pgs_iterations_wavefront_max': quantiles(per_wave) if per_wave is not None else None,
-                  'contacts_per_env': quantiles(D[:, :, sim.DIAG_CONTACTS]),
-                  'ik_iteration_cap': int(env.builder.params['ik_iterations']) if n_ik else None,
-                  'ik_iterations': quantiles(D[:, :, sim.DIAG_IK_ITERS:sim.DIAG_IK_ITERS + min(n_ik, sim.DIAG_N_IK)]) if n_ik else None,
-                  'sample': '16 steps after the timed region, every env'}
+        return {'iteration_cap': int(env.builder.solver_iterations), 'substeps': env.layout.substeps,
+                'pgs_iterations_last_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS]),
+                'pgs_iterations_first_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS_FIRST]),
+                'pgs_iterations_wavefront_max': quantiles(per_wave) if per_wave is not None else None,
+                'contacts_per_env': quantiles(D[:, :, sim.DIAG_CONTACTS]),
+                'envs_with_contacts_frac': float((D[:, :, sim.DIAG_CONTACTS] > 0).float().mean()),
+                'ik_iteration_cap': int(env.builder.params['ik_iterations']) if n_ik else None,
+                'ik_iterations': quantiles(D[:, :, sim.DIAG_IK_ITERS:sim.DIAG_IK_ITERS + min(n_ik, sim.DIAG_N_IK)]) if n_ik else None,
+                'sample': '16 steps after the timed region, every env'}
+
+    solver = solver_stats() if rank == 0 and not args.inner else None
 
     # aged segment: the same loop after --age-steps more (untimed) steps of the same random-action rollout
     aged = None
@@ -372,7 +374,8 @@ def run_rank(args, argv):
         a_step_ms, a_render_ms = kernel_times(min(32, args.steps))
         aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps, 'ms_per_step_aged': el / args.steps * 1e3,
                 'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
-                'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B}
+                'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B,
+                'solver': solver_stats() if rank == 0 else None}
 
     # eager public-API rates: env.step() with the reference's dict actions, and with flatten_actions /
     # flatten_observations + collapsed reward / terminal (the trainer-facing fast path); auto-reset as above

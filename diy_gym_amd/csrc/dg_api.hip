@@ -204,6 +204,10 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     bool chain = n >= 1 && n <= 6;
     for (int i = 0; i < n && chain; i++) chain = LI[(first + i) * DG_LI_STRIDE + DG_LI_PARENT] == (i == 0 ? -1 : first + i - 1);
     if (chain) oi[DG_OI_FLAGS] |= DG_IK_DEV_CHAIN;
+    // six revolute joints with the end-effector frame on the last link: the fully specialised solve
+    bool full = chain && n == 6 && I[I[DG_H_OFF_FRAME_I] + oi[DG_OI_FRAME] * DG_FI_STRIDE + DG_FI_LINK] == first + 5;
+    for (int i = 0; i < n && full; i++) full = LI[(first + i) * DG_LI_STRIDE + DG_LI_TYPE] == 0;
+    if (full && !getenv("DG_NO_FULL_IK")) oi[DG_OI_FLAGS] |= DG_IK_DEV_FULL;
   }
   HIP_TRY(hipMalloc(&w->d_blob_i, sizeof(int32_t) * (size_t)n_i)); HIP_TRY(hipMemcpy(w->d_blob_i, Idev.data(), sizeof(int32_t) * (size_t)n_i, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&w->d_blob_f, sizeof(float) * (size_t)n_f)); HIP_TRY(hipMemcpy(w->d_blob_f, Ff.data(), sizeof(float) * (size_t)n_f, hipMemcpyHostToDevice));

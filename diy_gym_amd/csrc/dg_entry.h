@@ -57,10 +57,12 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
       __syncthreads();  // B1
       if (sc.coll_split && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, sc.npairs / 2, 0x7fffffff, sc.cont2_off);
       __syncthreads();  // B2
-      if (split_decide_follow(ln, 0u, false)) pgs_reg_split(ln, -1, 0, split_slots(sc));
+      if (split_decide_follow(ln, 0u, false)) __syncthreads();  // Bs: the sweeps run on the first two wavefronts
       __syncthreads();  // B3
     }
-    __syncthreads();  // B4
+    __syncthreads();  // B4: every final pose is in LDS, every state row written
+    run_output_ops(ln, nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr, (valid && term) ? term + (size_t)e * sc.term_dim : nullptr,
+                   (valid && rew_sum) ? rew_sum + e : nullptr, (valid && term_flag) ? term_flag + e : nullptr, OUT_REW_TERM);
     return;
   }
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
@@ -80,10 +82,11 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
       __syncthreads();  // B1: every pose is in LDS
       if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, 0, sc.coll_split ? sc.npairs / 2 : 0x7fffffff);  // contact list + count go to LDS; the main wave reads them after B2
       __syncthreads();  // B2
-      if (split_decide_follow(ln, false, false)) pgs_reg_split(ln, -1, 0, split_slots(sc));
+      if (split_decide_follow(ln, false, false)) __syncthreads();  // Bs
       __syncthreads();  // B3
     }
     __syncthreads();  // B4
+    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_OBS_REST);
     return;
   }
   if (wave == 1) {  // ---------------- helper
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
     __syncthreads();  // B4
     // its arm's joint-state observations (state reads only; the main wave skips them)
-    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, sc.helper_body, -1);
+    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_OF, sc.helper_body);
     return;
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B4: the helper's body too
   prof.stamp(PS_KIN);
-  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
-                 (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr, -1, sc.helper_body);
+  // the output phase is shared: this wave emits the joint states of its bodies, the helper its arm's, the third
+  // wavefront the other observe ops, the fourth the reward / terminal ops and the collapsed outputs
+  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_NOT_OF, sc.helper_body);
   prof.stamp(PS_OUTPUT);
   if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
 }

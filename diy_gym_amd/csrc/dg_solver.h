@@ -967,84 +967,90 @@ DGD bool split_decide_follow(const Lane<LANES>& ln, unsigned my_limit_bits, bool
   return ln.L(xo + 4) != 0.f;
 }
 
-// ---- register-chain sweeps split across the wavefronts of the helper-wave kernel -------------------------------
-// When a substep has no contact and no active joint-limit row, the rows of the two register-chain bodies share no
-// unknown: the main wave sweeps one body, the helper wave the other, and the only coupling -- the per-env residual
-// that decides the early-out -- is exchanged through LDS once per iteration (double-buffered, one __syncthreads).
-// Every wavefront of the workgroup runs this loop (b < 0: the narrow-phase wave only follows the barriers), and
-// all of them derive the same `live` flags from the same exchanged residuals, so they leave the loop together.
+// ---- register-chain sweeps of the helper-wave kernel, one (env, arm) per lane ------------------------------------
+// When a substep has no contact, the rows of the two register-chain bodies share no unknown; the only coupling is
+// the per-env residual that decides the early-out.  Wavefront w (0 = main, 1 = helper) sweeps BOTH arms of the envs
+// [32 w, 32 w + 32) of the workgroup: lane l holds arm (l >> 5) of env 32 w + (l & 31), so the two residuals of an env
+// sit in lanes l and l ^ 32 of the same wavefront and are combined with one v_permlane32_swap -- no LDS round trip,
+// no workgroup barrier inside the loop (the previous form, one arm per wavefront, exchanged the residual through LDS
+// and a __syncthreads every iteration: ~400 of its ~860 cycles).  Each wavefront leaves the loop as soon as ITS 32
+// envs have converged.  M^-1, right-hand sides and limit flags are read from where the per-arm passes left them in
+// LDS (per-lane slot offsets); velocity changes and accumulated impulses go back the same way, and the caller's
+// __syncthreads hands them to the wavefront that integrates the arm.
 // Bitwise the same impulses as the single-wave sweep: rows of different bodies were already independent chains.
+DGD float half_swap_max(float x) {  // max over lanes l and l ^ 32, in every lane
+  // v_permlane32_swap a, b exchanges lanes 32..63 of a with lanes 0..31 of b: with a = b = x on entry, a ends up as
+  // x[l & 31] and b as x[32 + (l & 31)] in every lane.  Inline assembly because hipcc 7.2 folds the two results of
+  // __builtin_amdgcn_permlane32_swap(x, x) into one register (it emits max(a, a)); the s_nop covers the VALU-write ->
+  // permlane hazard the compiler pads for its own builtin.
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 template <int LANES>
-DGD int pgs_reg_split(const Lane<LANES>& ln, int b, int slot, int xo) {
+DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
   constexpr int RN = 6;
   const DevScene& sc = ln.sc; const float h = sc.h; const float thr_abs = sqrtf(sc.HF[DG_HF_RESIDUAL_THRESHOLD]);
-  float rM[RN * RN], rdv[RN], rb[RN], racc[RN], rdi[RN], rdg[RN], smax[RN]; int n = 0, dvo = 0, mo0 = 0;
-  // joint-limit rows of the body (lower, upper per joint): right-hand side and accumulated impulse; an impulse < 0
-  // marks a row that is inactive in this lane (the flag set up with the rows; it cannot change during the sweeps)
-  float lb[2][RN], la[2][RN]; bool any_limit = false;
+  const int lane = threadIdx.x & 63, half = lane >> 5, el = (lane & 31) + 32 * wave;
+  float* const col = ln.lds - lane + el;  // this lane's ENV column of the workspace
+  const bool valid = (int)blockIdx.x * 64 + el < sc.num_envs;
+  const int b0 = sc.reg_body[0], b1 = sc.helper_body;
+  const int f0 = ln.bi(b0)[DG_BI_FIRST_LINK], f1 = ln.bi(b1)[DG_BI_FIRST_LINK], n0 = ln.bi(b0)[DG_BI_N_LINKS], n1 = ln.bi(b1)[DG_BI_N_LINKS];
+  const int n = half ? n1 : n0, mvo = half ? ln.plb(b1)[PLB_MINV] : ln.plb(b0)[PLB_MINV], dvo = half ? ln.plb(b1)[PLB_DV] : ln.plb(b0)[PLB_DV];
+  const int mo0 = half ? ln.pll(f1)[PLL_MROW] : ln.pll(f0)[PLL_MROW];
+  auto W = [&](int slot) -> float& { return col[slot * 64]; };
+  float rM[RN * RN], rdv[RN], rb[RN], racc[RN], rdi[RN], rdg[RN], smax[RN], lb[2][RN], la[2][RN]; bool any_limit = false;
 #pragma unroll
-  for (int i = 0; i < RN; i++) { rdv[i] = 0.f; rb[i] = 0.f; racc[i] = 0.f; rdi[i] = 0.f; rdg[i] = 0.f; smax[i] = 0.f;
-    lb[0][i] = lb[1][i] = 0.f; la[0][i] = la[1][i] = -1.f;
-    _Pragma("unroll") for (int c = 0; c < RN; c++) rM[i * RN + c] = 0.f; }
-  if (b >= 0) {
-    const int first = ln.bi(b)[DG_BI_FIRST_LINK], mvo = ln.plb(b)[PLB_MINV];
-    n = ln.bi(b)[DG_BI_N_LINKS]; dvo = ln.plb(b)[PLB_DV]; mo0 = ln.pll(first)[PLL_MROW];
+  for (int i = 0; i < RN; i++) {
+    const bool has = i < n; const int ic = has ? i : 0;  // absent rows: clamped address, zeroed value
+    const float mf0 = ln.mt.v[3 * (f0 + (i < n0 ? i : 0)) + 2], mf1 = ln.mt.v[3 * (f1 + (i < n1 ? i : 0)) + 2];
+    const float maxf = half ? mf1 : mf0;
+    smax[i] = has ? (maxf < 0.f ? -maxf : maxf * h) : 0.f;
+    const int mo = mo0 + ic * MR_STRIDE;
+    rb[i] = has ? W(mo + MR_B) : 0.f; rdg[i] = has ? W(mvo + ic * n + ic) : 1.f; rdi[i] = has ? 1.0f / rdg[i] : 0.f;
+    lb[0][i] = W(mo + MR_LO_B); la[0][i] = has ? W(mo + MR_LO_ACC) : -1.f;
+    lb[1][i] = W(mo + MR_HI_B); la[1][i] = has ? W(mo + MR_HI_ACC) : -1.f;
+    any_limit = any_limit || la[0][i] >= 0.f || la[1][i] >= 0.f;
+    rdv[i] = 0.f; racc[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < RN; i++) {
-      if (i < n) {
-        const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[i] = maxf < 0.f ? -maxf : maxf * h;
-        rb[i] = ln.L(mo0 + i * MR_STRIDE + MR_B); rdg[i] = ln.L(mvo + i * n + i); rdi[i] = 1.0f / rdg[i];
-        lb[0][i] = ln.L(mo0 + i * MR_STRIDE + MR_LO_B); la[0][i] = ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC);
-        lb[1][i] = ln.L(mo0 + i * MR_STRIDE + MR_HI_B); la[1][i] = ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC);
-        any_limit = any_limit || la[0][i] >= 0.f || la[1][i] >= 0.f;
-      }
-#pragma unroll
-      for (int c = 0; c < RN; c++) rM[i * RN + c] = (i < n && c < n) ? ln.L(mvo + i * n + c) : 0.f;
-    }
+    for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
   }
   const bool wave_limit = __any(any_limit);  // no lane near a limit: the limit block is skipped altogether
-  bool live = ln.valid; int iters_done = 0;
+  bool live = valid; int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
-    const int xb = xo + 2 * (it & 1);
-    if (b >= 0) {
-      float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
+    float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < RN; i++) {
+      const float want = racc[i] + (rb[i] - rdv[i]) * rdi[i];
+      const float nacc = __builtin_amdgcn_fmed3f(want, -smax[i], smax[i]);
+      const float delta = (nacc - racc[i]) * lv; racc[i] += delta;
+#pragma unroll
+      for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
+      maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
+    }
+    if (wave_limit) {  // after the body's motor rows, as in the single-wave order
 #pragma unroll
       for (int i = 0; i < RN; i++) {
-        const float want = racc[i] + (rb[i] - rdv[i]) * rdi[i];
-        const float nacc = __builtin_amdgcn_fmed3f(want, -smax[i], smax[i]);
-        const float delta = (nacc - racc[i]) * lv; racc[i] += delta;
 #pragma unroll
-        for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
-        maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
-      }
-      if (wave_limit) {  // after the body's motor rows, as in the single-wave order
+        for (int side = 0; side < 2; side++) {
+          const float sg = side == 0 ? 1.f : -1.f; const bool act = la[side][i] >= 0.f;
+          const float nacc = fmaxf(la[side][i] + (lb[side][i] - sg * rdv[i]) * rdi[i], 0.f);
+          const float delta = act ? (nacc - la[side][i]) * lv : 0.f; la[side][i] += delta;
+          const float sd = sg * delta;
 #pragma unroll
-        for (int i = 0; i < RN; i++) {
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-            const float sg = side == 0 ? 1.f : -1.f; const bool act = la[side][i] >= 0.f;
-            const float nacc = fmaxf(la[side][i] + (lb[side][i] - sg * rdv[i]) * rdi[i], 0.f);
-            const float delta = act ? (nacc - la[side][i]) * lv : 0.f; la[side][i] += delta;
-            const float sd = sg * delta;
-#pragma unroll
-            for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * sd;
-            maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
-          }
+          for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * sd;
+          maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
         }
       }
-      ln.L(xb + slot) = maxabs;
     }
-    __syncthreads();
-    const float m = fmaxf(ln.L(xb), ln.L(xb + 1));
+    const float m = half_swap_max(maxabs);  // the env's residual over both arms
     if (live) iters_done = it + 1;
     live = live && !(m <= thr_abs);
     if (!__any(live)) break;
   }
-  if (b >= 0) {
 #pragma unroll
-    for (int i = 0; i < RN; i++) if (i < n) { ln.L(dvo + i) = rdv[i]; ln.L(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }
-  }
-  return iters_done;
+  for (int i = 0; i < RN; i++) if (i < n) { W(dvo + i) = rdv[i]; W(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }
+  if (half == 0) W(split_slots(sc)) = (float)iters_done;  // for the diagnostics column, read by the main wave after the barrier
 }
 
 // ---------------------------------------------------------------- substep
@@ -1150,7 +1156,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       else iters_done = pgs_dense_sliced_global<LANES, 32, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
     }
   } else if (PAR && split_now) {
-    iters_done = pgs_reg_split(ln, sc.reg_body[0], 0, split_slots(sc));
+    pgs_reg_halves(ln, 0);
+    __syncthreads();  // Bs: both wavefronts' velocity changes and impulses are in LDS
+    iters_done = (int)ln.L(split_slots(sc));
   } else if (primary) {
   bool live = ln.valid;
   // register-chain bodies in contact: their rows are coupled, the register sweeps no longer apply -- every row
@@ -1295,7 +1303,11 @@ DGD void helper_substep(const Lane<LANES>& ln, bool early) {
   uint64_t lm = 0ull, lr = 0ull;
   if (sc.split_pgs) { const int hf = ln.bi(hb)[DG_BI_FIRST_LINK]; setup_link_rows(ln, hf, hf + ln.bi(hb)[DG_BI_N_LINKS], lm, lr); }
   const int hf0 = ln.bi(hb)[DG_BI_FIRST_LINK];
-  if (split_decide_follow(ln, hf0 + 6 <= 32 ? (unsigned)((lr >> (2 * hf0)) & 0xFFFull) : 0u, true)) { pgs_reg_split(ln, hb, 1, split_slots(sc)); integrate_body(ln, hb); }
+  if (split_decide_follow(ln, hf0 + 6 <= 32 ? (unsigned)((lr >> (2 * hf0)) & 0xFFFull) : 0u, true)) {
+    pgs_reg_halves(ln, 1);
+    __syncthreads();  // Bs
+    integrate_body(ln, hb);
+  }
   __syncthreads();  // B3
 }
 
@@ -1407,13 +1419,18 @@ DGD int run_ik(const Lane<LANES>& ln, int op, const float* act, bool live_lane) 
 // forward kinematics, Jacobian columns, the 6x6 normal matrix and both solves live in registers; nothing goes
 // through LDS.  Same recursion as run_ik; selected per op at world creation (DG_IK_DEV_CHAIN).
 #define DG_IK_DEV_CHAIN 256
-template <int LANES, int N>
+// FULL (flag DG_IK_DEV_FULL, set at world creation): the chain has exactly N joints, all revolute, and the end-effector
+// frame sits on the last link -- every 6-axis arm.  The per-link conditions are then compile-time constants and the
+// whole solve is straight-line code (no selects, no branches, no copies at control-flow joins): ~1 000 instructions
+// per iteration instead of ~1 600.  NS / ORN: null-space projection / orientation target, fixed per instantiation.
+#define DG_IK_DEV_FULL 512
+template <int LANES, int N, bool FULL = false, bool NS = false, bool ORN = false>
 DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_lane, float* qout) {
   const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
   const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
-  const bool use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE;
-  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS];
-  const int eel = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK] - first;
+  const bool use_orn = FULL ? ORN : (flags & DG_IK_USE_ORIENTATION) != 0, nullsp = FULL ? NS : (flags & DG_IK_NULLSPACE) != 0;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = FULL ? N : ln.bi(b)[DG_BI_N_LINKS];
+  const int eel = FULL ? N - 1 : sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK] - first;
   cfp rest = sc.FL + oi[DG_OI_FLIST]; cfp ff = sc.FF + fr * DG_FF_STRIDE;
   const V3 off = v3(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2]);
   const Q4 qoff = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
@@ -1434,8 +1451,8 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
     for (int k = 0; k < 9; k++) cR[i][k] = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; k++) cP[i][k] = 0.f;
-    if (i < n) {
-      cfp f = ln.lf(first + i); q[i] = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q); rev[i] = ln.li(first + i)[DG_LI_TYPE] == 0;
+    if (FULL || i < n) {
+      cfp f = ln.lf(first + i); q[i] = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q); rev[i] = FULL || ln.li(first + i)[DG_LI_TYPE] == 0;
       M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = pin(f[DG_LF_ROT + k]);
       const V3 pT = v3(pin(f[DG_LF_POS]), pin(f[DG_LF_POS + 1]), pin(f[DG_LF_POS + 2]));
       const V3 ax = v3(pin(f[DG_LF_AXIS]), pin(f[DG_LF_AXIS + 1]), pin(f[DG_LF_AXIS + 2]));
@@ -1445,7 +1462,7 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 #pragma unroll
       for (int k = 0; k < 9; k++) cR[i][k] = RTp.m[k];
       cP[i][0] = pTp.x; cP[i][1] = pTp.y; cP[i][2] = pTp.z;
-      Qprev = Qi; if (i == eel) Qee = Qi;
+      Qprev = Qi; if (FULL ? i == N - 1 : i == eel) Qee = Qi;
     }
   }
   const V3 offp = tmul(Qee, off);  // frame offset in the primed end-effector frame
@@ -1455,25 +1472,25 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 #pragma unroll
   for (int i = 0; i < N; i++) {
     nRest[i] = 0.f; nLo[i] = -3.0e38f; nHi[i] = 3.0e38f; nIrg[i] = 0.f;
-    if (nullsp && i < n) { nRest[i] = pin(rest[i]); nLo[i] = pin(rest[n + i]); nHi[i] = pin(rest[2 * n + i]); nIrg[i] = pin(frcp(rest[3 * n + i])); }
+    if (nullsp && (FULL || i < n)) { nRest[i] = pin(rest[i]); nLo[i] = pin(rest[n + i]); nHi[i] = pin(rest[2 * n + i]); nIrg[i] = pin(frcp(rest[3 * n + i])); }
   }
   V3 pe; M3 Re;  // end-effector point and PRIMED link rotation R_ee Q_ee (Q and the frame offset are folded into the target)
   auto fk = [&]() {
     M3 R = R0; V3 p = p0; M3 Rl = R0; V3 pl = p0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      if (i < n) {
+      if (FULL || i < n) {
         M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = cR[i][k];
         p = p + mul(R, v3(cP[i][0], cP[i][1], cP[i][2]));
         const M3 C = mul(R, RT);
         const V3 c0 = v3(C.m[0], C.m[3], C.m[6]), c1 = v3(C.m[1], C.m[4], C.m[7]), c2 = v3(C.m[2], C.m[5], C.m[8]);
-        if (rev[i]) {
+        if (FULL || rev[i]) {
           const float sn = __sinf(q[i]), cs = __cosf(q[i]);
           const V3 n0 = c0 * cs + c1 * sn, n1 = c1 * cs - c0 * sn;
           const M3 Rn = {{n0.x, n1.x, c2.x, n0.y, n1.y, c2.y, n0.z, n1.z, c2.z}}; R = Rn;
         } else { R = C; p = p + c2 * q[i]; }
         ow[i] = p; aw[i] = c2;
-        if (i == eel) { Rl = R; pl = p; }
+        if (FULL ? i == N - 1 : i == eel) { Rl = R; pl = p; }
       }
     }
     pe = pl + mul(Rl, offp); Re = Rl;
@@ -1516,19 +1533,19 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 #pragma unroll
     for (int k = 0; k < 21; k++) U[k] = 0.f;
     auto column = [&](int i, float* col) {
-      const V3 jl = rev[i] ? cross(aw[i], pe - ow[i]) : aw[i]; const V3 ja = (rev[i] && use_orn) ? aw[i] : v3(0.f, 0.f, 0.f);
+      const V3 jl = (FULL || rev[i]) ? cross(aw[i], pe - ow[i]) : aw[i]; const V3 ja = ((FULL || rev[i]) && use_orn) ? aw[i] : v3(0.f, 0.f, 0.f);
       col[0] = jl.x; col[1] = jl.y; col[2] = jl.z; col[3] = ja.x; col[4] = ja.y; col[5] = ja.z;
     };
 #pragma unroll
     for (int i = 0; i < N; i++) {
       v0[i] = 0.f;
-      if (i < n) {
+      if (FULL || i < n) {
         if (nullsp) {
           v0[i] = g0 * (nRest[i] - q[i]);
           if (q[i] > nHi[i]) v0[i] += g1 * (nHi[i] - q[i]) * nIrg[i];
           if (q[i] < nLo[i]) v0[i] += g1 * (nLo[i] - q[i]) * nIrg[i];
         }
-        if (i <= eel) {
+        if (FULL || i <= eel) {
           float col[6]; column(i, col);
 #pragma unroll
           for (int r = 0; r < 6; r++) {
@@ -1551,9 +1568,9 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 #pragma unroll
     for (int i = 0; i < N; i++) {
       dth[i] = 0.f;
-      if (i < n) {
+      if (FULL || i < n) {
         float t = 0.f;
-        if (i <= eel) {
+        if (FULL || i <= eel) {
           float col[6]; column(i, col);
 #pragma unroll
           for (int r = 0; r < 6; r++) t += col[r] * y[r];
@@ -1563,7 +1580,7 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
     }
     const float scl = mx > maxang ? fdiv(maxang, mx) : 1.0f;
 #pragma unroll
-    for (int i = 0; i < N; i++) if (i < n && live) q[i] += scl * dth[i];
+    for (int i = 0; i < N; i++) if ((FULL || i < n) && live) q[i] += scl * dth[i];
   }
 #pragma unroll
   for (int i = 0; i < N; i++) qout[i] = q[i];
@@ -1594,7 +1611,11 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
       float av[6] = {a[0], a[1], a[2], 0.f, 0.f, 0.f};
       if (oi[DG_OI_FLAGS] & DG_IK_USE_ORIENTATION) { av[3] = a[3]; av[4] = a[4]; av[5] = a[5]; }
       if (oi[DG_OI_FLAGS] & DG_IK_DEV_CHAIN) {
-        float qs[6]; const int ik_it = run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
+        float qs[6]; int ik_it;
+        const int fl = oi[DG_OI_FLAGS];
+        if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE) && (fl & DG_IK_USE_ORIENTATION)) ik_it = run_ik_chain<LANES, 6, true, true, true>(ln, op, av, ln.valid, qs);
+        else if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE)) ik_it = run_ik_chain<LANES, 6, true, true, false>(ln, op, av, ln.valid, qs);
+        else ik_it = run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
         if (diag && ln.valid && ik_ord < DG_DIAG_N_IK) diag[(size_t)DG_DIAG_STRIDE * ln.env + DG_DIAG_IK_ITERS + ik_ord] = ik_it;
         const int first = ln.bi(b)[DG_BI_FIRST_LINK];
         for (int k = 0; k < n; k++) {
@@ -1694,12 +1715,15 @@ DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
   return norm(pb - pa);
 }
 
-// observe / reward / terminal ops; POSE must be current for every body
+// observe / reward / terminal ops; POSE must be current for every body.
+// `part` lets the four wavefronts of the helper-wave kernel share the output phase (they write disjoint columns):
+//   OUT_ALL everything; OUT_JOINT_OF: the joint-state ops of body `pb` (they read nothing but the state);
+//   OUT_JOINT_NOT_OF: the joint-state ops of every other body; OUT_OBS_REST: the remaining observe ops;
+//   OUT_REW_TERM: reward and terminal ops and the collapsed reward / terminal.
+enum { OUT_ALL = 0, OUT_JOINT_OF, OUT_JOINT_NOT_OF, OUT_OBS_REST, OUT_REW_TERM };
 template <int LANES>
-// joint_only_body >= 0: only the joint-state ops of that body (they read nothing but the state, so the helper wave can
-// emit its arm's while the main wave is still busy); joint_skip_body: everything but those.
 DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag,
-                        int joint_only_body = -1, int joint_skip_body = -1) {
+                        int part = OUT_ALL, int pb = -1) {
   const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
   // a reach_target addon emits a reward op and a terminal op on the same pair of frames: the distance is computed once
   int rk_a = -2, rk_b = -2, rk_c = -2, rk_d = -2; float rk_dist = 0.f;
@@ -1712,8 +1736,12 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
   for (int op = 0; op < sc.nops; op++) {
     cip oi = sc.OI + op * DG_OI_STRIDE; cfp of = sc.OF + op * DG_OF_STRIDE;
     const int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; cip il = sc.IL + oi[DG_OI_ILIST];
-    if (joint_only_body >= 0 && !(code == DG_OP_OBS_JOINT_STATE && oi[DG_OI_BODY] == joint_only_body)) continue;
-    if (joint_skip_body >= 0 && code == DG_OP_OBS_JOINT_STATE && oi[DG_OI_BODY] == joint_skip_body) continue;
+    if (part != OUT_ALL) {
+      const bool js = code == DG_OP_OBS_JOINT_STATE, ob = code >= DG_OP_OBS_JOINT_STATE && code < DG_OP_REW_REACH;
+      const bool mine = part == OUT_JOINT_OF ? (js && oi[DG_OI_BODY] == pb) : part == OUT_JOINT_NOT_OF ? (js && oi[DG_OI_BODY] != pb)
+                        : part == OUT_OBS_REST ? (ob && !js) : code >= DG_OP_REW_REACH;
+      if (!mine) continue;
+    }
     if (code == DG_OP_OBS_JOINT_STATE) {
       const int n = oi[DG_OI_N]; int k2 = n;
       if (obs) {
@@ -1767,7 +1795,7 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
       if (t) { any = true; groups |= 1ull << (oi[DG_OI_SLOT] & 63); }
     }
   }
-  if (joint_only_body >= 0) return;
+  if (part != OUT_ALL && part != OUT_REW_TERM) return;
   if (rew_sum) *rew_sum = rsum;
   if (term_flag) {
     if (sc.term_mode == DG_COLLAPSE_ALL) { const uint64_t want = sc.n_term_groups >= 64 ? ~0ull : ((1ull << sc.n_term_groups) - 1ull); *term_flag = (sc.n_term_groups > 0 && (groups & want) == want) ? 1 : 0; }

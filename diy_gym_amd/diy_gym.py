@@ -15,6 +15,10 @@ attributes.  Differences, all additive:
   numpy in, numpy out (this path synchronises every step and exists for
   compatibility and tests, not for speed).
 * ``reset(mask)`` resets a subset of envs (the reference can only reset all).
+* config key ``auto_reset: true`` (needs ``terminal_if_any`` / ``terminal_if_all``): ``step()`` resets the envs
+  whose collapsed terminal fired before it returns -- their row of the returned observation is the first
+  observation of the new episode, reward and terminal are those of the step that ended the old one (the usual
+  vector-env convention).  Respawn jitter is drawn per (seed, global env index, episode), so a shard replays.
 * ``render`` is accepted and ignored: there is no GUI.
 
 ``step()`` never calls back into a per-env engine: controller addons, the
@@ -61,6 +65,9 @@ class DIYGym(Receptor):
             'terminal_if_all', False) else None
         self.flatten_observations = config.get('flatten_observations', False)
         self.flatten_actions = config.get('flatten_actions', False)
+        self.auto_reset = bool(config.get('auto_reset', False))
+        if self.auto_reset and self.collapse_terminals_func is None:
+            raise ValueError('auto_reset needs one terminal flag per env: set terminal_if_any or terminal_if_all')
         term_mode = {None: K.COLLAPSE_NONE, any: K.COLLAPSE_ANY, all: K.COLLAPSE_ALL}[self.collapse_terminals_func]
         self.builder = SceneBuilder(timestep=timestep, substeps=sub_steps, solver_iterations=iterations, gravity=gravity,
                                     max_episode_steps=self._max_episode_steps, hot_start=self.hot_start,
@@ -103,6 +110,11 @@ class DIYGym(Receptor):
         # zero-copy flat paths are valid when every addon is compiled and none is hidden
         visible = all(not a.hide for r in self.receptors.values() for a in r.addons.values())
         self._flat_fast = visible and not self._hook_addons
+        # camera images live in their own buffers, not in the observation rows: with a camera the flat observation is
+        # assembled by flatten() (reference utils.py:46-60), images included, instead of being handed out as a view
+        self._flat_obs_fast = self._flat_fast and not self.builder.cameras
+        if self.auto_reset and self._has_hook_terminals:
+            raise ValueError('auto_reset needs every terminal addon compiled into the step kernel')
 
         self.seed(seed)
         self.reset()
@@ -137,7 +149,7 @@ class DIYGym(Receptor):
         return self._out(self.sim.rew[:, off])
 
     def _term_view(self, off):
-        return self._out(self.sim.term[:, off].bool())
+        return self._out(self.sim.term[:, off].view(torch.bool))  # 0 / 1 bytes: a reinterpreting view, no copy
 
     def _as_batch(self, value, width):
         t = torch.as_tensor(np.asarray(value, dtype=np.float32) if not isinstance(value, torch.Tensor) else value,
@@ -175,7 +187,7 @@ class DIYGym(Receptor):
     def observe(self, _refresh=True):
         if _refresh:
             self.sim.observe()
-        if self.flatten_observations and self._flat_fast:
+        if self.flatten_observations and self._flat_obs_fast:
             return self._out(self.sim.obs[:, :self.layout.obs_dim])
         ret = self.walk_addons(lambda addon: addon.observe())
         return flatten(ret, batch_dims=0 if self.compat else 1) if self.flatten_observations else ret
@@ -188,7 +200,7 @@ class DIYGym(Receptor):
 
     def is_terminal(self):
         if self.collapse_terminals_func is not None and not self._has_hook_terminals:
-            return self._out(self.sim.term_flag.bool())
+            return self._out(self.sim.term_flag.view(torch.bool))
         ret = self.walk_addons(lambda addon: addon.is_terminal())
         if self._timer_op is not None:
             if self.name not in ret:
@@ -206,7 +218,7 @@ class DIYGym(Receptor):
                 act = action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.layout.act_dim).contiguous() if self.layout.act_dim else None
                 self.sim.step(self._all_slots, act)
                 self._tick += 1
-                return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}
+                return self._finish_step()
             action = unflatten(torch.as_tensor(np.asarray(action, dtype=np.float32)) if not isinstance(action, torch.Tensor)
                                else action, self.original_action_space, batch_dims=0 if self.compat else 1)
         self._mask = 0
@@ -215,7 +227,17 @@ class DIYGym(Receptor):
                 self.receptors[receptor_name].addons[addon_name].update(addon_action)
         self.sim.step(self._mask)
         self._tick += 1
-        return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}
+        return self._finish_step()
+
+    def _finish_step(self):
+        if not self.auto_reset:
+            return self.observe(_refresh=False), self.reward(), self.is_terminal(), {}
+        # reward / terminal of the finished step first (they are views of buffers the reset does not write), then the
+        # masked reset, which rewrites the observation rows of the envs it restarted
+        rew, term = self.reward(), self.is_terminal()
+        self.sim.reset(self.sim.term_flag)
+        self._tick += 1
+        return self.observe(_refresh=False), rew, term, {}
 
     def walk_addons(self, func):
         ret = OrderedDict()

@@ -27,6 +27,8 @@ SCENES = {  # name: (config, envs, steps, action scale)
     'maze': ('examples/r2d2_maze/r2d2_maze.yaml', 2, 12, 10.0),
     'admittance': ('tests/golden/ur_admittance.yaml', 3, 30, 1.0),
     'readme': ('examples/from_the_readme/from_the_readme.yaml', 2, 30, 0.2),   # R2D2 lands on the table: 25 contacts
+    'touching': ('tests/golden/ur_arms_touching.yaml', 3, 30, 0.3),            # crossed forearms: contacts between two arms
+    'gripper': ('tests/golden/ur5_gripper.yaml', 3, 30, 0.5),                  # UR5 + two-finger gripper, 12-DoF tree
 }
 
 

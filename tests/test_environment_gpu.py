@@ -166,3 +166,77 @@ def test_step_and_masked_reset_are_graph_capturable():
         envs[1].sim.step(envs[1]._all_slots, act); envs[1].sim.reset(envs[1].sim.term_flag)
     torch.cuda.synchronize()
     assert torch.equal(envs[0].sim.state, envs[1].sim.state) and torch.equal(envs[0].sim.obs, envs[1].sim.obs)
+
+
+FLAT_KEYS = 'flatten_actions: yes\nflatten_observations: yes\nsum_rewards: yes\nauto_reset: yes\n'
+
+
+def _flat_config(tmp_path, name, episode_steps):
+    """The reference's YAML plus the trainer-facing keys of diy_gym.py:94-96,114-122 (and the auto_reset extension)."""
+    src = {'drone': DRONE, 'ur': os.path.join(ROOT, 'examples', 'ur_high_5', 'ur_high_5_joint.yaml')}[name]
+    text = open(src).read().replace('max_episode_steps: 10000', '')
+    cfg = tmp_path / (name + '_flat.yaml')
+    cfg.write_text(FLAT_KEYS + 'max_episode_steps: %d\n' % episode_steps + text)
+    return str(cfg)
+
+
+@pytest.mark.parametrize('name,tol', [('drone', 2e-3), ('ur', 5e-4)])
+def test_flat_env_step_with_timer_auto_reset_matches_oracle_over_three_episodes(tmp_path, name, tol):
+    """N3 (reference diy_gym.py:114-122,180-183): env.step() itself -- flat torch tensor in, (obs [B, O], reward [B],
+    terminal [B], {}) out -- with flatten_actions + flatten_observations + sum_rewards + terminal_if_any +
+    max_episode_steps; the episode timer fires every 7 steps and the masked auto-reset restarts those envs (new
+    respawn jitter per episode: the drone's target moves).  Same calls on the HIP backend and on the oracle backend.
+    Blind to: everything both share (Bullet constants from recollection, no warm starting)."""
+    import diy_gym_amd.examples  # noqa: F401
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    cfg = _flat_config(tmp_path, name, 7)
+    B = 70
+    gpu = DIYGym(cfg, num_envs=B, device='cuda:0', seed=21)
+    cpu = DIYGym(cfg, num_envs=B, seed=21, backend_factory=OracleBackend)
+    assert gpu._flat_fast and gpu.auto_reset
+    lo, hi = torch.as_tensor(gpu.action_space.low), torch.as_tensor(gpu.action_space.high)
+    A = lo.numel()
+    assert gpu.observation_space.shape == (gpu.layout.obs_dim,) and A == gpu.layout.act_dim
+    gen = torch.Generator().manual_seed(2)
+    fired, first_obs = 0, gpu.observe().clone()
+    ptrs = None
+    for step in range(1, 24):
+        act = lo + (hi - lo) * torch.rand((B, A), generator=gen)
+        act_dev = act.to('cuda:0')
+        mem = torch.cuda.memory_allocated()
+        g_obs, g_rew, g_term, g_info = gpu.step(act_dev)
+        assert torch.cuda.memory_allocated() == mem   # the step (and its auto-reset) allocated nothing on the device
+        c_obs, c_rew, c_term, _ = cpu.step(act)
+        # zero-copy: the returned tensors ARE the backend's persistent buffers, and a step allocates nothing
+        assert g_obs.data_ptr() == gpu.sim.obs.data_ptr() and g_rew.data_ptr() == gpu.sim.rew_sum.data_ptr()
+        assert g_term.data_ptr() == gpu.sim.term_flag.data_ptr() and g_term.dtype == torch.bool and g_info == {}
+        assert g_obs.shape == (B, gpu.layout.obs_dim) and g_rew.shape == (B,) and g_term.shape == (B,)
+        if step == 1:
+            ptrs = (g_obs.data_ptr(), g_rew.data_ptr(), g_term.data_ptr())
+        assert (g_obs.data_ptr(), g_rew.data_ptr(), g_term.data_ptr()) == ptrs
+        assert torch.equal(g_term.cpu(), c_term), step
+        assert float((g_obs.cpu() - c_obs).abs().max()) < tol and float((g_rew.cpu() - c_rew).abs().max()) < tol, step
+        if step % 7 == 0:   # the timer ended every env's episode; obs rows are the new episode's first observation
+            assert bool(g_term.all())
+            fired += 1
+            assert torch.equal(gpu.sim.state[0, :B].cpu(), torch.zeros(B))           # step counters restarted
+            assert torch.equal(gpu.sim.state[1, :B].cpu(), torch.full((B,), 1.0 + fired))   # episode counters
+        else:
+            assert not bool(g_term.all())
+    assert fired == 3
+    if name == 'drone':   # the target respawned somewhere else in every episode (jitter keyed by episode)
+        assert float((gpu.observe() - first_obs).abs().max()) > 0.5
+
+
+def test_flat_env_step_rejects_a_wrong_width():
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
+    conf = Configuration.from_file(UR)
+    conf.set('flatten_actions', True)
+    env = DIYGym(conf, num_envs=8, device='cuda:0')
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((8, 11), device='cuda:0'))
+    with pytest.raises(ValueError):
+        env.sim.step(env._all_slots, torch.zeros((8, 12)))   # CPU tensor
+    env.step(torch.zeros((8, 12), device='cuda:0'))

@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
@@ -26,7 +27,7 @@ def test_oracle_reproduces_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,tol', [('marbles', 2e-3), ('drone', 2e-3), ('ur_ik', 5e-4), ('ur_joint', 5e-4), ('cart_tree', 5e-3), ('maze', 5e-3),
-                                      ('admittance', 3e-3), ('readme', 2e-3)])
+                                      ('admittance', 3e-3), ('readme', 2e-3), ('touching', 3e-3), ('gripper', 5e-4)])
 def test_hip_matches_golden(name, tol):
     r = make_vectors.run(name, device='cuda:0')
     obs, ref = r['obs'], V[name + '/obs']

@@ -25,6 +25,11 @@ CONFIGS = {
 }
 
 
+# tolerances of the loosely-conditioned scenes, set from measured differences (tools/gpu_tolerances.py) with ~3x margin
+CART_STATE_TOL = 1e-3                                     # measured 1.3e-4
+MAZE_VEL_TOL, MAZE_Q_TOL, MAZE_QD_TOL = 3e-1, 4e-2, 3e-1   # measured 1.2e-1, 1.5e-2, 1.0e-1 (|qd| up to 5 rad/s, iteration-capped sweeps)
+
+
 def make_pair(name, B, seed=5, **engine):
     import diy_gym_amd.examples  # noqa: F401  registers propellor / fell_over
     from diy_gym_amd import DIYGym
@@ -110,14 +115,16 @@ def test_admittance_controller_80_steps():
 
 
 def test_ur5_with_two_finger_gripper_asset_40_steps():
+    # Blind to: hull thinning to <= 32 points and mesh-vs-mesh via fitted capsules (same on both sides), no warm starting.
     # ur5_2f.urdf of the reference's data tree: a 12-DoF fixed-base TREE (arm + six finger joints), hull-vs-plane
     # contacts; generic articulated-body path, all-dense sweeps
     gpu, cpu = make_pair('gripper', 5)
     w = rollout(gpu, cpu, 40, scale=0.5)
-    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+    assert w['obs'] < 5e-4 and w['effort_rel'] < 5e-3 and w['term_mismatch'] == 0, w   # measured 4.6e-5, 6e-4
 
 
 def test_child_model_gripper_40_steps():
+    # Blind to: the rigid merge itself (Bullet couples parent and child with a soft, iterated fixed constraint).
     # robotiq_2f attached as a child model to the UR5's flange: one 12-DoF tree, no contacts
     gpu, cpu = make_pair('child', 5)
     w = rollout(gpu, cpu, 40)
@@ -125,6 +132,7 @@ def test_child_model_gripper_40_steps():
 
 
 def test_arms_in_contact_30_steps():
+    # Blind to: mesh-vs-mesh contacts through fitted capsules (Bullet uses GJK/EPA on the hulls) and no warm starting.
     # the two arms start with crossed forearms: contacts between two register-chain bodies, so the three-wavefront
     # kernel takes its single-wave sweeps with dense contact rows (and switches to split sweeps once they separate)
     gpu, cpu = make_pair('touching', 37)
@@ -132,7 +140,7 @@ def test_arms_in_contact_30_steps():
     gpu.sim.step(gpu._all_slots, torch.zeros((37, 12), device=gpu.device)); cpu.sim.step(cpu._all_slots, torch.zeros((37, 12)))
     assert int(d[:, 0].max()) >= 1 and d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(37)]
     w = rollout(gpu, cpu, 30, scale=0.3)
-    assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+    assert w['obs'] < 3e-3 and w['term_mismatch'] == 0, w   # measured 7.5e-4
 
 
 @pytest.mark.parametrize('env_var', [None, 'DG_NO_HELPER_WAVE', 'DG_NO_SPLIT_SWEEPS'])
@@ -172,38 +180,54 @@ def test_drone_pilot_60_steps():
 
 
 def test_marbles_contacts_200_steps():
+    # Blind to: no warm starting (Bullet warm-starts contact impulses), no rolling / spinning friction.
     # resting + rolling contacts with friction; chaotic once marbles collide, so compare a short horizon
     gpu, cpu = make_pair('marbles', 9)
     w = rollout(gpu, cpu, 200, scale=1.0)
     assert w['obs'] < 2e-3, w
 
 
-def test_cart_tree_every_feature_60_steps():
-    # floating articulated base (branching tree, prismatic + revolute, limits, damping), sphere contacts,
-    # every sensor flag, electricity cost, time penalty, episode timer, terminal_if_all, respawn jitter
-    # (the scene is a cart balancing on a plane next to a marble: contact-rich, so the horizon is short)
+def test_cart_tree_every_feature_at_pybullet_residual_threshold_30_steps():
+    """LOOSE BY CONSTRUCTION (2e-2): floating articulated base (branching tree, prismatic + revolute, limits, damping),
+    sphere contacts, every sensor flag, electricity cost, time penalty, episode timer, terminal_if_all, respawn jitter.
+    The cart balances on a plane next to a marble; with pybullet's 1e-7 early-out the contact impulses are only
+    determined to that residual, and the balancing cart amplifies the difference between an fp32 and an fp64 solve.
+    Efforts are excluded here and asserted in the converged variant below.
+    Blind to (shared by oracle and kernel): no warm starting, Bullet constants from recollection."""
     gpu, cpu = make_pair('cart_tree', 37)
     w = rollout(gpu, cpu, 30)
     assert w['obs'] < 2e-2 and w['rew'] < 2e-2 and w['term_mismatch'] == 0, w
     assert torch.equal(gpu.sim.term_flag.cpu(), cpu.sim.term_flag)
-    # with the solver run to (fp32) convergence instead of pybullet's 1e-7 early-out, motor efforts agree too
+
+
+def test_cart_tree_every_feature_converged_solver():
+    """The same scene with the solver run to fp32 convergence (residual threshold 1e-13 instead of 1e-7): the two
+    implementations then solve the same well-posed problem and agree to 2e-3 on every observation INCLUDING the motor
+    efforts (relative 2e-2), and on the whole state.  Blind to: the choice of threshold itself, no warm starting."""
     gpu, cpu = make_pair('cart_tree', 37, residual_threshold=1e-13)
     w = rollout(gpu, cpu, 12)
-    assert w['obs'] < 2e-3 and w['effort_rel'] < 2e-2 and w['term_mismatch'] == 0, w
+    assert w['obs'] < 1e-3 and w['rew'] < 1e-3 and w['effort_rel'] < 2e-3 and w['term_mismatch'] == 0, w   # measured 2.8e-4, 7e-6, 1.9e-4
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < CART_STATE_TOL
 
 
 def test_r2d2_maze_40_steps():
-    # floating 8-DoF tree (wheels, prismatic gripper, head) on a plane among 119 frozen walls: LDS at 16 envs per
-    # wavefront, one-sided contact rows, generic (LDS) solver path
+    """Floating 8-DoF tree (wheels, prismatic gripper, head) on a plane among 119 frozen walls, wheels driven at the
+    +-10 rad/s of the reference's example (r2d2_maze.py:14): lane-sliced Gauss-Seidel, one-sided contact rows.  The
+    wheel-on-plane contact problem runs into the 150-iteration cap, so fp32 and fp64 drift apart faster than in the
+    converged scenes.  Asserted: base pose (5e-3), base twist, every joint angle and joint rate.
+    Blind to: hull thinning (the wheels' hulls are thinned identically on both sides), no warm starting."""
     gpu, cpu = make_pair('maze', 19)
-    assert gpu.sim.lanes in (16, 32) and gpu.layout.state_dim < 100  # walls and plane carry no per-env state
-    w = rollout(gpu, cpu, 40, scale=10.0)  # the reference's example drives the wheels at +-10 rad/s (r2d2_maze.py:14)
+    assert gpu.sim.lanes in (8, 16, 32) and gpu.layout.state_dim < 100  # walls and plane carry no per-env state
+    w = rollout(gpu, cpu, 40, scale=10.0)
     assert w['term_mismatch'] == 0
     a, b = gpu.sim.get_state(), cpu.sim.get_state()
-    so = gpu.layout.body_state_off[0]
-    # the wheel-on-plane contact problem runs into the 150-iteration cap, so fp32 and fp64 drift apart faster than in
-    # the converged scenes: 5 mm / 5e-3 quaternion units after 40 steps of hard driving
+    L = gpu.layout
+    so = L.body_state_off[[i for i in range(L.n_bodies) if L.body_n_links[i] > 0][0]]
     assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
+    assert np.abs(a[:, so + 7:so + 13] - b[:, so + 7:so + 13]).max() < MAZE_VEL_TOL
+    q, qd = list(L.link_state_off), [o + 1 for o in L.link_state_off]
+    assert len(q) == 8
+    assert np.abs(a[:, q] - b[:, q]).max() < MAZE_Q_TOL and np.abs(a[:, qd] - b[:, qd]).max() < MAZE_QD_TOL
 
 
 def test_from_the_readme_scene_and_gripper_camera():

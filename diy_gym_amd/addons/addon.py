@@ -30,9 +30,8 @@ class AddonFactory:
             from .controllers import AdmittanceController, InverseKinematicsController, JointController, ExternalForce
             from .sensors import Camera, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
-            from .misc import Respawn, SpawnMultiple
-            from .unsupported import (ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer,
-                                      DynamicsRandomizer)
+            from .misc import DynamicsRandomizer, Respawn, SpawnMultiple
+            from .unsupported import ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer
             # same 17 keys as reference addon.py:36-54
             self.addons = {
                 'ik_controller': InverseKinematicsController,

@@ -34,3 +34,58 @@ class SpawnMultiple(Addon):
 
     def compile(self, builder):
         pass
+
+
+class DynamicsRandomizer(Addon):
+    """Per-env link masses and body angular damping re-drawn at every reset (reference:
+    diy_gym/addons/misc/dynamics_randomizer.py:8-32; the sim-to-real randomisation the README advertises).
+
+    The reference formula, kept literally: for every movable joint ``k`` of the parent model, in joint order,
+
+    * ``mass_k <- log(U(mass_range)) * getDynamicsInfo(uid, k)[0]`` -- it reads the CURRENT mass back, so the factors
+      compound from reset to reset;
+    * ``changeDynamics(angularDamping = log(U(damping_range)) * getJointInfo(uid, k)[6])`` -- pybullet's
+      ``angularDamping`` is a property of the whole multibody [R], so the draw of the last joint is what stays; the
+      second factor is the URDF joint damping (0 for most robot descriptions, which switches Bullet's default
+      angular damping of 0.04 off).
+
+    ``log(U(0.25, 4))`` is negative for a fifth of the draws; a negative link mass has no defined behaviour in
+    Bullet.  Guards chosen here (``mass_scale_limits`` is an extension key): the mass factor is ``|log U|``, the
+    accumulated scale relative to the URDF mass is clamped to ``mass_scale_limits`` (default [1e-3, 1e3]); the
+    angular damping is clamped at 0.  A link's inertia tensor is scaled with its mass (same convention as the
+    ``mass`` key of a model).  The reference draws once at construction and once more in the constructor's
+    ``reset()``; so does this addon at an env's first reset.  Draws come from the per-env counter-based stream
+    (seed, global env index, episode) instead of python's global ``random``.
+    """
+    def __init__(self, parent, config):
+        super().__init__(parent, config)
+        self.uid = parent.uid
+        robot = parent.robot
+        self.joint_ids = [j.index for j in robot.joints if j.q_index > -1]
+        if not self.joint_ids:
+            # the reference falls back to joint -1 and then fails in p.getJointInfo(uid, -1) (dynamics_randomizer.py:30)
+            raise ValueError('dynamics_randomizer: model %r has no movable joint (the reference raises here too: '
+                             'getJointInfo(uid, -1) is out of range)' % parent.name)
+        self.mass_range = [float(v) for v in config.get('mass_range', [0.25, 4.0])]
+        self.damping_range = [float(v) for v in config.get('damping_range', [0.2, 20])]
+        self.mass_scale_limits = [float(v) for v in config.get('mass_scale_limits', [1e-3, 1e3])]
+        if min(self.mass_range) <= 0 or min(self.damping_range) <= 0:
+            raise ValueError('dynamics_randomizer: ranges must be positive (log of the draw is taken)')
+
+    def compile(self, builder):
+        robot = self.parent.robot
+        dofs = [builder.global_link(self.uid, robot.joints[j].q_index) for j in self.joint_ids]
+        self.op = builder.add_op(K.OP_RANDOMIZE_DYNAMICS, 'reset', body=self.uid, ilist=dofs,
+                                 flist=[robot.joints[j].damping for j in self.joint_ids],
+                                 fparams=self.mass_range + self.damping_range + self.mass_scale_limits, state_dim=len(dofs) + 1)
+
+    def mass_scales(self):
+        """[B, n_joints] current mass scale of every randomised link (host copy, for inspection / tests)."""
+        import torch
+        o = self.env.layout.addon_off + self.op.state_off
+        return torch.as_tensor(self.env.sim.get_state()[:, o:o + len(self.joint_ids)])
+
+    def angular_damping(self):
+        import torch
+        o = self.env.layout.addon_off + self.op.state_off + len(self.joint_ids)
+        return torch.as_tensor(self.env.sim.get_state()[:, o])

@@ -17,6 +17,3 @@ StuckJointCost = _stub('stuck_joint_cost', 'the reference implementation raises 
                        '(stuck_joint_cost.py:16-21); there is no behaviour to match')
 DrawCoords = _stub('draw_coords', 'GUI-only debug drawing')
 VisualRandomizer = _stub('visual_randomizer', 'GUI-only cosmetics; downloads a dataset over HTTP in the reference')
-DynamicsRandomizer = _stub('dynamics_randomizer', 'the reference scales masses by log(uniform(0.25, 4)), which is negative with '
-                           'probability 0.2 per link per reset and compounds across resets (dynamics_randomizer.py:27-32): '
-                           'there is no well-defined behaviour to match; per-env parameter tables are SURVEY 8(f) N1')

@@ -310,6 +310,12 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     for (int k = 0; k < 3; k++) init[so + DG_BS_POS + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_POS + k];
     for (int k = 0; k < 4; k++) init[so + DG_BS_QUAT + k] = (float)BF[b * DG_BF_STRIDE + DG_BF_INIT_QUAT + k];
   }
+  for (int op = 0; op < I[DG_H_N_OPS]; op++) {  // dynamics_randomizer state before its first draw: URDF masses, default damping
+    const int32_t* oi = OI + op * DG_OI_STRIDE; if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;
+    const int so = sc.addon_off + oi[DG_OI_STATE_OFF];
+    for (int k = 0; k < oi[DG_OI_N]; k++) init[so + k] = 1.f;
+    init[so + oi[DG_OI_N]] = (float)F[DG_HF_ANG_DAMPING];
+  }
   HIP_TRY(hipMalloc((void**)&w->d_init, sizeof(float) * init.size())); HIP_TRY(hipMemcpy(w->d_init, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
   // cameras: per-env shape/camera pose table written by pose_kernel, read by render_kernel
   w->ncam = I[DG_H_N_CAMERAS]; w->d_CI = dI + I[DG_H_OFF_CAMERA_I]; w->d_CF = dF + I[DG_H_OFF_CAMERA_F]; w->d_PLN = dF + I[DG_H_OFF_PLANE_F];

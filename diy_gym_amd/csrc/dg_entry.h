@@ -37,6 +37,19 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
 }
 
+// First substep's dynamics of the moving bodies number `parity`, `parity` + 2, ... (two wavefronts share them while the
+// other two run the update ops; sc.coll_wave guarantees every moving body is a register-resident chain).
+template <int LANES>
+DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
+  const DevScene& sc = ln.sc; Prof<false> none; int m = 0;
+  for (int b = 0; b < sc.nb; b++) {
+    if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
+    if ((m++ & 1) != parity) continue;
+    ln.template dynamics_chain<6>(b, none);
+    const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+  }
+}
+
 // Four wavefronts per workgroup, same 64 envs, same LDS workspace (wave 3 takes half of the narrow phase in substeps
 // where it is on the critical path): wave 1 (the helper) runs the inverse kinematics
 // and the register-resident dynamics of sc.helper_body, wave 2 the narrow phase (when sc.coll_wave), wave 0 everything else.  Every global / LDS
@@ -49,9 +62,10 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
   const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
-  if (wave == 3) {  // ---------------- second half of the narrow phase (substeps whose narrow phase is on the critical path)
+  if (wave == 3) {  // ---------------- second half of the narrow phase; in the early first substep, the dynamics of every second moving body
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     __syncthreads();  // B0
+    if (sc.early_dyn) early_dynamics(ln, 1);
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {
       __syncthreads();  // B1
@@ -68,14 +82,9 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     __syncthreads();  // B0
-    if (sc.early_dyn) {  // first substep: narrow phase and both arms' dynamics while the other two waves run the update ops
-      collide<64, 64>(ln);
-      Prof<false> none;
-      for (int b = 0; b < sc.nb; b++) {
-        if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
-        ln.template dynamics_chain<6>(b, none);  // coll_wave guarantees every moving body is such a chain
-        const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
-      }
+    if (sc.early_dyn) {  // first substep: narrow phase and the arms' dynamics while the first two waves run the update ops
+      collide<64, 64>(ln);  // (the fourth wavefront takes every second moving body's dynamics)
+      early_dynamics(ln, 0);
     }
     __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {

@@ -146,6 +146,14 @@ struct Lane {
   DGD bool fixed(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
   DGD bool frozen(int b) const { return bi(b)[DG_BI_FLAGS] & DG_BODY_FROZEN; }
   DGD int ext_off(int b) const { return bi(b)[DG_BI_STATE_OFF] + (fixed(b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END); }
+  // per-env dynamics parameters written by the dynamics_randomizer's reset op (wave-uniform offsets, -1 = none)
+  DGD float mass_scale(int gl) const { const int o = li(gl)[DG_LI_MASS_SCALE]; return o >= 0 ? S(o) : 1.0f; }
+  DGD float ang_damping(int b) const { const int o = bi(b)[DG_BI_DYN_OFF]; return o >= 0 ? S(o) : sc.HF[DG_HF_ANG_DAMPING]; }
+  // rigid inertia of link gl about its frame origin with the per-env mass scale applied to mass and inertia tensor
+  DGD void link_inertia(int gl, float& m, V3& c, Sym3& Ic) const {
+    cfp f = lf(gl); m = f[DG_LF_MASS]; c = v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]); Ic = sym6(f + DG_LF_INERTIA);
+    if (li(gl)[DG_LI_MASS_SCALE] >= 0) { const float s = mass_scale(gl); m *= s; Ic.xx *= s; Ic.xy *= s; Ic.xz *= s; Ic.yy *= s; Ic.yz *= s; Ic.zz *= s; }
+  }
 
   DGD V3 base_pos(int b) const {
     if (frozen(b)) { cfp f = bf(b) + DG_BF_INIT_POS; return v3(f[0], f[1], f[2]); }
@@ -235,8 +243,8 @@ struct Lane {
   DGD int aw(int i) const { return sc.tr_off + sc.ab_stride + i * AW_STRIDE; }
   DGD int ab() const { return sc.tr_off; }
 
-  DGD S6 damping_force(float m, V3 c, const Sym3& Ic, const S6& v) const {
-    float kl = sc.HF[DG_HF_LIN_DAMPING], ka = sc.HF[DG_HF_ANG_DAMPING];
+  DGD S6 damping_force(float m, V3 c, const Sym3& Ic, const S6& v, float ka) const {
+    float kl = sc.HF[DG_HF_LIN_DAMPING];
     V3 vc = v.l + cross(v.a, c);
     V3 f = vc * (-m * (kl + kl * norm(vc)));
     V3 n = mul(Ic, v.a) * (-(ka + ka * norm(v.a)));
@@ -257,6 +265,7 @@ struct Lane {
     const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     const bool fx = fixed(b); const float h = sc.h;
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV], nb6 = fx ? 0 : 6;
+    const float ka = ang_damping(b);
     M3 R0 = LR(plb(b)[PLB_R0]);
     // ---- pass 1
     S6 v0 = {v3(0, 0, 0), v3(0, 0, 0)};
@@ -266,7 +275,7 @@ struct Lane {
       v0.a = tmul(R0, ww); v0.l = tmul(R0, vw);
       V3 c = v3(Bf[DG_BF_COM], Bf[DG_BF_COM + 1], Bf[DG_BF_COM + 2]); Sym3 Ic = sym6(Bf + DG_BF_INERTIA);
       AI I0 = rigid_inertia(Bf[DG_BF_MASS], c, Ic);
-      S6 p0 = crf(v0, mul(I0, v0)) - damping_force(Bf[DG_BF_MASS], c, Ic, v0);
+      S6 p0 = crf(v0, mul(I0, v0)) - damping_force(Bf[DG_BF_MASS], c, Ic, v0, ka);
       int eo = ext_off(b);
       S6 fx6; fx6.l = tmul(R0, v3(S(eo), S(eo + 1), S(eo + 2))); fx6.a = tmul(R0, v3(S(eo + 3), S(eo + 4), S(eo + 5)));
       LAIset(ab() + AB_IA, I0); L6set(ab() + AB_PA, p0 - fx6);
@@ -279,9 +288,9 @@ struct Lane {
       S6 vp = par < 0 ? v0 : L6(aw(par - first) + AW_V);
       S6 Sx = subspace(gl);
       S6 v = xmotion(E, r, vp) + Sx * qd;
-      V3 c = v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]); Sym3 Ic = sym6(f + DG_LF_INERTIA);
-      AI I = rigid_inertia(f[DG_LF_MASS], c, Ic);
-      S6 pA = crf(v, mul(I, v)) - damping_force(f[DG_LF_MASS], c, Ic, v);
+      float lm; V3 c; Sym3 Ic; link_inertia(gl, lm, c, Ic);
+      AI I = rigid_inertia(lm, c, Ic);
+      S6 pA = crf(v, mul(I, v)) - damping_force(lm, c, Ic, v, ka);
       int o = aw(i);
       LMset(o + AW_E, E); L3set(o + AW_R, r); L6set(o + AW_V, v); L6set(o + AW_PA, pA);
       const int acc = pll(gl)[PLL_IAACC];
@@ -293,7 +302,7 @@ struct Lane {
       int gl = first + i, par = li(gl)[DG_LI_PARENT]; cfp f = lf(gl); int o = aw(i);
       int lo = li(gl)[DG_LI_STATE_OFF]; float qd = S(lo + DG_LS_QD);
       float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd;
-      AI IA = rigid_inertia(f[DG_LF_MASS], v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]), sym6(f + DG_LF_INERTIA));
+      AI IA; { float lm; V3 lc; Sym3 lI; link_inertia(gl, lm, lc, lI); IA = rigid_inertia(lm, lc, lI); }
       if (carry_parent == gl) {
         IA.I.xx += carry.I.xx; IA.I.xy += carry.I.xy; IA.I.xz += carry.I.xz; IA.I.yy += carry.I.yy; IA.I.yz += carry.I.yz; IA.I.zz += carry.I.zz;
         IA.M.xx += carry.M.xx; IA.M.xy += carry.M.xy; IA.M.xz += carry.M.xz; IA.M.yy += carry.M.yy; IA.M.yz += carry.M.yz; IA.M.zz += carry.M.zz;
@@ -421,6 +430,7 @@ struct Lane {
   DGD void dynamics_chain(int b, PROF_T& prof) const {
     cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], mo = plb(b)[PLB_MINV]; const float h = sc.h;
     const M3 R0 = LR(plb(b)[PLB_R0]); const V3 gb = tmul(R0, v3(sc.gx, sc.gy, sc.gz));
+    const float ka = ang_damping(b);
     const S6 zero6 = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
     M3 E[N]; V3 r[N]; S6 v[N], pA[N], U[N], Sx[N]; float dinv[N], u[N], qd[N];
     S6 vp = zero6;
@@ -432,9 +442,9 @@ struct Lane {
         const float q = S(lo + DG_LS_Q); qd[i] = S(lo + DG_LS_QD);
         M3 Rpc; joint_xform(gl, q, Rpc, r[i]); E[i] = transpose(Rpc); Sx[i] = subspace(gl);
         v[i] = xmotion(E[i], r[i], vp) + Sx[i] * qd[i]; vp = v[i];
-        const V3 c = v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]); const Sym3 Ic = sym6(f + DG_LF_INERTIA);
-        const AI I = rigid_inertia(f[DG_LF_MASS], c, Ic);
-        pA[i] = crf(v[i], mul(I, v[i])) - damping_force(f[DG_LF_MASS], c, Ic, v[i]);
+        float lm; V3 c; Sym3 Ic; link_inertia(gl, lm, c, Ic); (void)f;
+        const AI I = rigid_inertia(lm, c, Ic);
+        pA[i] = crf(v[i], mul(I, v[i])) - damping_force(lm, c, Ic, v[i], ka);
       }
     }
     AI carry; bool have = false;
@@ -443,7 +453,7 @@ struct Lane {
       if (i < n) {
         const int gl = first + i, lo = li(gl)[DG_LI_STATE_OFF]; cfp f = lf(gl);
         const float tau = S(lo + DG_LS_TORQUE) - f[DG_LF_DAMPING] * qd[i];
-        AI IA = rigid_inertia(f[DG_LF_MASS], v3(f[DG_LF_COM], f[DG_LF_COM + 1], f[DG_LF_COM + 2]), sym6(f + DG_LF_INERTIA));
+        AI IA; { float lm; V3 lc; Sym3 lI; link_inertia(gl, lm, lc, lI); IA = rigid_inertia(lm, lc, lI); }
         if (have) {
           IA.I.xx += carry.I.xx; IA.I.xy += carry.I.xy; IA.I.xz += carry.I.xz; IA.I.yy += carry.I.yy; IA.I.yz += carry.I.yz; IA.I.zz += carry.I.zz;
           IA.M.xx += carry.M.xx; IA.M.xy += carry.M.xy; IA.M.xz += carry.M.xz; IA.M.yy += carry.M.yy; IA.M.yz += carry.M.yz; IA.M.zz += carry.M.zz;

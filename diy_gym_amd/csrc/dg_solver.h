@@ -1015,7 +1015,12 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
     for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
   }
-  const bool wave_limit = __any(any_limit);  // no lane near a limit: the limit block is skipped altogether
+  // limit rows some lane of the wavefront has active (the flags cannot change during the sweeps): bit 2 i + side.  Rows
+  // nobody needs are skipped with a wave-uniform branch, so a sweep costs what the wavefront's active limits cost
+  unsigned lim_rows = 0u;
+#pragma unroll
+  for (int i = 0; i < RN; i++) { if (__any(la[0][i] >= 0.f)) lim_rows |= 1u << (2 * i); if (__any(la[1][i] >= 0.f)) lim_rows |= 2u << (2 * i); }
+  (void)any_limit;
   bool live = valid; int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
@@ -1028,11 +1033,12 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
       for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
       maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
     }
-    if (wave_limit) {  // after the body's motor rows, as in the single-wave order
+    if (lim_rows) {  // after the body's motor rows, as in the single-wave order
 #pragma unroll
       for (int i = 0; i < RN; i++) {
 #pragma unroll
         for (int side = 0; side < 2; side++) {
+          if (!((lim_rows >> (2 * i + side)) & 1u)) continue;
           const float sg = side == 0 ? 1.f : -1.f; const bool act = la[side][i] >= 0.f;
           const float nacc = fmaxf(la[side][i] + (lb[side][i] - sg * rdv[i]) * rdi[i], 0.f);
           const float delta = act ? (nacc - la[side][i]) * lv : 0.f; la[side][i] += delta;
@@ -1652,7 +1658,7 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
           bool sub = false; for (int q = i; q >= 0; q = ln.li(q)[DG_LI_PARENT]) if (q == gl) sub = true;
           if (!sub) continue;
           cfp fi2 = ln.lf(i); const int pi2 = ln.pll(i)[PLL_POSE];
-          const V3 cw = ln.L3(pi2 + 6) + mul(ln.LR(pi2), v3(fi2[DG_LF_COM], fi2[DG_LF_COM + 1], fi2[DG_LF_COM + 2])); const V3 w8 = g * fi2[DG_LF_MASS];
+          const V3 cw = ln.L3(pi2 + 6) + mul(ln.LR(pi2), v3(fi2[DG_LF_COM], fi2[DG_LF_COM + 1], fi2[DG_LF_COM + 2])); const V3 w8 = g * (fi2[DG_LF_MASS] * ln.mass_scale(i));
           tau -= rev ? dot(w8, cross(axw, cw - oj)) : dot(w8, axw);
         }
         tau += of[3] * (tgt[k] - ln.S(lo + DG_LS_Q)) - of[4] * ln.S(lo + DG_LS_QD);
@@ -1702,6 +1708,31 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
     } else if (code == DG_OP_RESET_JOINTS) {
       cip il = sc.IL + oi[DG_OI_ILIST]; cfp fl = sc.FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { const int lo = ln.li(il[k])[DG_LI_STATE_OFF]; ln.Sset(lo + DG_LS_Q, fl[k]); ln.Sset(lo + DG_LS_QD, 0.f); }
+    } else if (code == DG_OP_RANDOMIZE_DYNAMICS) {
+      // dynamics_randomizer.py:24-32 (see DG_OP_RANDOMIZE_DYNAMICS in diygym_scene.h): new mass = log(U) * current mass
+      // per joint, angular damping = log(U) * URDF joint damping (body-wide, the last joint's stays); two rounds at an
+      // env's first reset, because the reference draws at construction and again in its constructor's reset()
+      cfp fl = sc.FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N], so = sc.addon_off + oi[DG_OI_STATE_OFF];
+      const uint64_t ge = (uint64_t)(sc.env_base + ln.env); float damp = ln.S(so + n);
+      for (int k = 0; k < n; k++) {
+        float s = ln.S(so + k);
+        for (int round = 0; round < 2; round++) {
+          if (round == 0 && episode != 0ull) continue;
+          const uint64_t ep = round == 0 ? 0ull : episode + 1ull;
+          const float um = of[0] + (of[1] - of[0]) * rng_uniform(sc.seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k));
+          s = fminf(fmaxf(s * fabsf(logf(um)), of[4]), of[5]);
+        }
+        ln.Sset(so + k, s);
+      }
+      for (int round = 0; round < 2; round++) {  // rounds outermost for the damping: the LAST draw of the LAST round stays
+        if (round == 0 && episode != 0ull) continue;
+        const uint64_t ep = round == 0 ? 0ull : episode + 1ull;
+        for (int k = 0; k < n; k++) {
+          const float ud = of[2] + (of[3] - of[2]) * rng_uniform(sc.seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k + 1));
+          damp = fmaxf(logf(ud) * fl[k], 0.f);
+        }
+      }
+      ln.Sset(so + n, damp);
     }
   }
   ln.Sset(DG_ST_EPISODE, (float)(episode + 1ull));

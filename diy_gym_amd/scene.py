@@ -331,7 +331,7 @@ class SceneBuilder:
             frozen = (not dynamic) and b not in respawned
             flags = (K.BODY_FIXED if flat.fixed_base else 0) | (K.BODY_FROZEN if frozen else 0)
             # frozen bodies have no per-env state at all: their pose is the load pose in the body table
-            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off])
+            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off, -1])
             if not frozen:
                 state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
             I = flat.base_inertia
@@ -340,7 +340,7 @@ class SceneBuilder:
                            *q_link, *flat.T_base_report.p, *rep_q, *self.colors[b], body_bound(flat), 0.0, 0.0, 0.0])
             for i, fl in enumerate(flat.links):
                 parent = -1 if fl.parent < 0 else first + fl.parent
-                link_i.append([parent, fl.joint_type, b, state_off])
+                link_i.append([parent, fl.joint_type, b, state_off, -1])
                 link_state_offs.append(state_off)
                 state_off += K.LS_STRIDE
                 I = fl.inertia
@@ -412,6 +412,16 @@ class SceneBuilder:
                     shape_anchor.append((np.asarray(p_link, dtype=np.float64), (link_reach[sh.link] if sh.link >= 0 else 0.0) + ext))
         addon_off = state_off
         state_dim = state_off + self.addon_state
+        # per-env dynamics parameters (dynamics_randomizer): the links / bodies they belong to point at the addon state
+        for row, _ in self.ops:
+            if row[K.OI_CODE] == K.OP_RANDOMIZE_DYNAMICS:
+                base = addon_off + row[K.OI_STATE_OFF]
+                links = self.ilist[row[K.OI_ILIST]:row[K.OI_ILIST] + row[K.OI_N]]
+                for k, gl_ in enumerate(links):
+                    if link_i[gl_][K.LI_MASS_SCALE] >= 0:
+                        raise ValueError('two dynamics_randomizer addons on the same joint')
+                    link_i[gl_][K.LI_MASS_SCALE] = base + k
+                body_i[row[K.OI_BODY]][K.BI_DYN_OFF] = base + len(links)
 
         # candidate collision pairs: different bodies, at least one of them able to move,
         # and a narrow-phase routine exists for the pair (no box-box)

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 5
+#define DG_VERSION 6
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -103,7 +103,9 @@ enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_E
 #define DG_BODY_FIXED 1  /* base does not move (use_fixed_base / massless root) */
 #define DG_BODY_FROZEN 2 /* fixed, no joints and never respawned: its shapes are stored in WORLD coordinates,
                             it has no per-env state (DG_BI_STATE_OFF = -1) and its pose is DG_BF_INIT_* */
-enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF, DG_BI_STRIDE };
+enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF,
+       DG_BI_DYN_OFF /* state offset of the body's per-env angular damping (dynamics_randomizer), or -1: DG_HF_ANG_DAMPING */,
+       DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)
  * angvel[3] (world); then ext_force[3] ext_torque[3] (world, about the base
@@ -122,7 +124,9 @@ enum {
 
 /* ---- link table (one row per DoF, bodies contiguous, parents first) -- */
 enum { DG_LI_PARENT = 0 /* global link index, -1 = base of own body */, DG_LI_TYPE /* 0 revolute 1 prismatic */,
-       DG_LI_BODY, DG_LI_STATE_OFF, DG_LI_STRIDE };
+       DG_LI_BODY, DG_LI_STATE_OFF,
+       DG_LI_MASS_SCALE /* state offset of the link's per-env mass (and inertia) scale (dynamics_randomizer), or -1: 1 */,
+       DG_LI_STRIDE };
 enum {
   DG_LF_POS = 0,   /* joint frame origin in the parent reference frame      */
   DG_LF_ROT = 3,   /* 3x3                                                    */
@@ -185,6 +189,12 @@ enum {
   /* reset phase (reference Addon.reset, diy_gym.py:141-143) */
   DG_OP_RESPAWN = 16,        /* respawn.py:31-39 */
   DG_OP_RESET_JOINTS = 17,   /* joint_controller.py:36-38, ik_controller.py:47-49 */
+  DG_OP_RANDOMIZE_DYNAMICS = 18, /* dynamics_randomizer.py:24-32: per joint k (ILIST, FLIST = URDF joint damping):
+                                  mass_k <- log(U(f0, f1)) * mass_k (compounding, as the reference reads the current mass back),
+                                  angularDamping <- log(U(f2, f3)) * jointDamping_k (body-wide: the last joint's draw stays).
+                                  Addon state: N mass scales, then the angular damping.  Guards (the reference formula goes
+                                  negative for U < 1): |log U| for the mass, scale clamped to [f4, f5]; damping >= 0.  Drawn
+                                  twice at an env's first reset (the reference draws at construction and again in reset()) */
   /* observe phase */
   DG_OP_OBS_JOINT_STATE = 32,  /* joint_state_sensor.py:47-57 */
   DG_OP_OBS_OBJECT_STATE = 33, /* object_state_sensor.py:49-75 */

@@ -333,6 +333,13 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
       for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] = bf[DG_BF_INIT_POS + k];
       for (int k = 0; k < 4; k++) bs[DG_BS_QUAT + k] = bf[DG_BF_INIT_QUAT + k];
     }
+    for (int op = 0; op < w->sc.nops; op++) { /* dynamics_randomizer state before its first draw: URDF masses, default damping */
+      const int32_t* oi = w->sc.OI + op * DG_OI_STRIDE;
+      if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;
+      double* ps = st + w->sc.addon_off + oi[DG_OI_STATE_OFF];
+      for (int k = 0; k < oi[DG_OI_N]; k++) ps[k] = 1.0;
+      ps[oi[DG_OI_N]] = w->sc.F[DG_HF_ANG_DAMPING];
+    }
   }
   return w;
 }
@@ -407,17 +414,24 @@ static s6 damping_force(double m, v3 c, const m3* Ic, const s6* v, double kl, do
 
 /* articulated-body algorithm, passes 1-3 (Featherstone, RBDA ch. 7).  tau = joint
  * torques (damping, torque-control).  Leaves IA, U, d in ws for impulse responses. */
+/* per-env link mass: the URDF mass times the dynamics_randomizer's scale for this link, if it has one (the inertia
+ * tensor is scaled with the mass) */
+static double link_mass_scale(const Scene* s, const double* st, int gl) {
+  int o = link_i(s, gl)[DG_LI_MASS_SCALE]; return o >= 0 ? st[o] : 1.0;
+}
 static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
   const double* bf = body_f(s, b);
   double kl = s->F[DG_HF_LIN_DAMPING], ka = s->F[DG_HF_ANG_DAMPING];
+  if (body_i(s, b)[DG_BI_DYN_OFF] >= 0) ka = st[body_i(s, b)[DG_BI_DYN_OFF]]; /* changeDynamics(angularDamping=) per env */
   /* pass 1: inertias and bias forces */
   for (int i = 0; i < ws->n; i++) {
-    const double* lf = link_f(s, ws->first + i);
+    const double* lf = link_f(s, ws->first + i); const double ms = link_mass_scale(s, st, ws->first + i);
     v3 c = V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]); m3 Ic = msym6(lf + DG_LF_INERTIA);
-    ws->IA[i] = rigid_inertia(lf[DG_LF_MASS], c, &Ic);
+    for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Ic.m[r][cc] *= ms;
+    ws->IA[i] = rigid_inertia(lf[DG_LF_MASS] * ms, c, &Ic);
     s6 Iv = m6v(&ws->IA[i], &ws->v[i]);
     ws->pA[i] = crf(&ws->v[i], &Iv);
-    s6 fd = damping_force(lf[DG_LF_MASS], c, &Ic, &ws->v[i], kl, ka);
+    s6 fd = damping_force(lf[DG_LF_MASS] * ms, c, &Ic, &ws->v[i], kl, ka);
     for (int k = 0; k < 6; k++) ws->pA[i].v[k] -= fd.v[k];
   }
   if (!ws->fixed) {
@@ -1000,7 +1014,7 @@ static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t ma
           if (!sub) continue;
           const double* lf = link_f(s, ws->first + i);
           v3 cw = vadd(ws->pw[i], mv(&ws->Rw[i], V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2])));
-          v3 w8 = vscale(s->g, lf[DG_LF_MASS]);
+          v3 w8 = vscale(s->g, lf[DG_LF_MASS] * link_mass_scale(s, st, ws->first + i));
           tau -= rev ? vdot(w8, vcross(aw, vsub(cw, ws->pw[j]))) : vdot(w8, lw);
         }
         tau += of[3] * (tgt[k] - ls[DG_LS_Q]) - of[4] * ls[DG_LS_QD];
@@ -1048,6 +1062,21 @@ static void run_reset_ops(dgo_world* w, int env) {
     } else if (code == DG_OP_RESET_JOINTS) { /* joint_controller.py:36-38 */
       const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { double* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
+    } else if (code == DG_OP_RANDOMIZE_DYNAMICS) { /* dynamics_randomizer.py:24-32 */
+      const double* fl = s->FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N]; double* ps = st + s->addon_off + oi[DG_OI_STATE_OFF];
+      const uint64_t ge = (uint64_t)(w->env_base + env);
+      /* the reference draws in __init__ and again in the constructor's reset(): two rounds at an env's first reset */
+      for (int round = (episode == 0 ? 0 : 1); round < 2; round++) {
+        const uint64_t ep = round == 0 ? 0 : episode + 1;
+        for (int k = 0; k < n; k++) {
+          const double um = of[0] + (of[1] - of[0]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k));
+          const double ud = of[2] + (of[3] - of[2]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k + 1));
+          /* new mass = log(U) * CURRENT mass (guards: |log U|, accumulated scale clamped to [of[4], of[5]]) */
+          double sc_ = ps[k] * fabs(log(um)); sc_ = sc_ < of[4] ? of[4] : (sc_ > of[5] ? of[5] : sc_); ps[k] = sc_;
+          /* angularDamping = log(U) * URDF joint damping: body-wide, the last joint's value stays (guard: >= 0) */
+          double da = log(ud) * fl[k]; ps[n] = da > 0.0 ? da : 0.0;
+        }
+      }
     }
   }
   st[DG_ST_EPISODE] = (double)(episode + 1);

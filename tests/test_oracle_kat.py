@@ -380,3 +380,69 @@ def test_head_on_collision_is_inelastic_and_conserves_momentum(tmp_path):
     assert abs((va + vb) - 1.0) < 1e-6                      # momentum (equal masses)
     assert abs(va - 0.5) < 2e-3 and abs(vb - 0.5) < 2e-3    # perfectly inelastic: common velocity
     assert vb >= va - 1e-6                                  # separating or together, never interpenetrating further
+
+
+# ---------------------------------------------------------------- dynamics_randomizer (reference dynamics_randomizer.py:24-32)
+def _pendulum_with_randomizer(tmp_path, body, B=1, seed=0):
+    cfg = tmp_path / 'pend_rand.yaml'
+    cfg.write_text('render: no\npend:\n  model: %s\n  xyz: [0, 0, 0]\n  rand: {addon: dynamics_randomizer, %s}\n' %
+                   (os.path.join(G, 'urdf', 'pendulum.urdf'), body))
+    return DIYGym(str(cfg), num_envs=B, seed=seed, backend_factory=OracleBackend, engine=NODAMP)
+
+
+def _held_effort(env):
+    """Torque the default velocity motor applies to hold the bob at 1 rad (= m g L sin q while it holds)."""
+    qo = link_q(env, 0, 0)
+    st = env.sim.get_state(); st[:, qo] = 1.0; st[:, qo + 1] = 0.0; env.sim.set_state(st)
+    env.sim.set_motor_cfg(np.array([[0.0, 1.0, 1e4]]))  # a velocity motor strong enough for any mass drawn here
+    for _ in range(20):
+        env.sim.step(0)
+    return np.abs(env.sim.get_state()[:, qo + K.LS_APPLIED])
+
+
+def test_dynamics_randomizer_compounds_masses_like_the_reference(tmp_path):
+    # log(U(e^2, e^2)) = 2: the reference multiplies the CURRENT mass by it at construction, again in the constructor's
+    # reset() and again at every later reset -> 4 m, 8 m, 16 m.  The holding torque m g L sin(q) shows the mass.
+    e2 = float(np.exp(2.0))
+    env = _pendulum_with_randomizer(tmp_path, 'mass_range: [%r, %r], damping_range: [%r, %r], mass_scale_limits: [1.0e-3, 1.0e3]' % (e2, e2, np.e, np.e))
+    rand = env.models['pend'].addons['rand']
+    base = 1.0 * 9.81 * 0.5 * np.sin(1.0)
+    for want in (4.0, 8.0, 16.0):
+        assert abs(float(rand.mass_scales()[0, 0]) - want) < 1e-9
+        assert abs(_held_effort(env)[0] - want * base) < 2e-2 * want
+        env.reset()
+    # angular damping = log(U(e, e)) * URDF joint damping = 1 * 0 for this URDF: Bullet's default 0.04 is switched off
+    assert float(rand.angular_damping()[0]) == 0.0
+
+
+def test_dynamics_randomizer_guards_and_streams(tmp_path):
+    # U = 0.5 -> log U = -0.693: the reference would set a NEGATIVE mass; the documented guard takes |log U|
+    env = _pendulum_with_randomizer(tmp_path, 'mass_range: [0.5, 0.5]')
+    rand = env.models['pend'].addons['rand']
+    assert abs(float(rand.mass_scales()[0, 0]) - np.log(2.0)**2) < 1e-12
+    # the accumulated scale is clamped (compounding would otherwise run away): 0.48^k hits the lower limit
+    env = _pendulum_with_randomizer(tmp_path, 'mass_range: [0.5, 0.5], mass_scale_limits: [0.2, 5.0]')
+    rand = env.models['pend'].addons['rand']
+    for _ in range(4):
+        env.reset()
+    assert float(rand.mass_scales()[0, 0]) == 0.2
+    # default ranges: every env draws its own factors, a masked reset only re-draws the masked envs, and a shard
+    # with env_index_base reproduces the same envs
+    env = _pendulum_with_randomizer(tmp_path, 'mass_range: [0.25, 4.0]', B=6, seed=9)
+    rand = env.models['pend'].addons['rand']
+    s0 = rand.mass_scales()[:, 0].clone()
+    assert len({round(float(v), 9) for v in s0}) == 6 and float(s0.min()) > 0
+    mask = torch.tensor([1, 0, 0, 1, 0, 0], dtype=torch.uint8)
+    env.reset(mask)
+    s1 = rand.mass_scales()[:, 0]
+    assert all((float(s1[i]) != float(s0[i])) == bool(mask[i]) for i in range(6))
+    cfg = tmp_path / 'pend_rand.yaml'
+    shard = DIYGym(str(cfg), num_envs=3, seed=9, env_index_base=3, backend_factory=OracleBackend, engine=NODAMP)
+    assert np.array_equal(shard.models['pend'].addons['rand'].mass_scales()[:, 0].numpy(), s0[3:].numpy())
+
+
+def test_dynamics_randomizer_needs_a_movable_joint(tmp_path):
+    cfg = tmp_path / 'm.yaml'
+    cfg.write_text('ball:\n  model: sphere2.urdf\n  rand: {addon: dynamics_randomizer}\n')
+    with pytest.raises(ValueError, match='no movable joint'):
+        DIYGym(str(cfg), num_envs=1, backend_factory=OracleBackend)

@@ -22,6 +22,7 @@ CONFIGS = {
     'child': os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'),
     'touching': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching.yaml'),
     'touching_ik': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching_ik.yaml'),
+    'randomized': os.path.join(ROOT, 'tests', 'golden', 'ur_randomized.yaml'),
 }
 
 
@@ -288,6 +289,36 @@ def test_alternative_workspace_modes(name, env_vars, lanes, steps, tol):
     assert gpu.sim.lanes == lanes
     w = rollout(gpu, cpu, steps, scale=0.5)
     assert w['obs'] < tol and w['term_mismatch'] == 0, w
+
+
+def test_dynamics_randomizer_three_episodes():
+    """dynamics_randomizer (reference dynamics_randomizer.py:24-32) on both arms: per-env link masses drawn by the reset op
+    from the counter RNG, compounding from episode to episode, angular damping overridden per env.  The timer ends an
+    episode every 9 steps and the masked auto-reset re-draws.  Compared with the oracle: the drawn scales themselves
+    (fp32 log vs fp64 log: 1e-5 relative) and the trajectories they produce.
+    Blind to: the guards chosen for the reference's negative masses (|log U|, clamped scale) -- shared by both."""
+    gpu, cpu = make_pair('randomized', 41, seed=12)
+    lo, hi = action_bounds(gpu)
+    gen = torch.Generator().manual_seed(3)
+    L = gpu.layout
+    scales = []
+    for step in range(1, 30):
+        act = (lo + (hi - lo) * torch.rand((41, lo.numel()), generator=gen)) * 0.5
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        assert torch.equal(gpu.sim.term_flag.cpu(), cpu.sim.term_flag)
+        eo, _ = effort_columns(gpu)
+        keep = torch.ones(gpu.sim.obs.shape[1], dtype=torch.bool); keep[eo] = False
+        d = (gpu.sim.obs.cpu() - cpu.sim.obs).abs()
+        assert float(d[:, keep].max()) < 2e-3, step
+        assert float((d[:, eo] / (1.0 + cpu.sim.obs[:, eo].abs())).max()) < 2e-2, step
+        gpu.sim.reset(gpu.sim.term_flag); cpu.sim.reset(cpu.sim.term_flag)
+        a, b = gpu.sim.get_state()[:, L.addon_off:], cpu.sim.get_state()[:, L.addon_off:]
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6), step
+        if step % 9 == 0:
+            scales.append(b.copy())
+    assert len(scales) == 3 and not np.allclose(scales[0], scales[1]) and not np.allclose(scales[1], scales[2])   # re-drawn every episode
+    ms = scales[0][:, :6]
+    assert ms.min() > 0 and len(np.unique(np.round(ms[:, 0], 6))) == 41                                       # every env its own draw
 
 
 def test_frame_state_getter_matches_oracle():

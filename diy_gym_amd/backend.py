@@ -237,7 +237,7 @@ class HipBackend:
         """Diagnostic: per-wavefront shader cycles per section of the step (see diygym_hip.h)."""
         if on:
             n_waves = (self.num_envs + self.envs_per_wave - 1) // self.envs_per_wave
-            self.cycles = torch.zeros((n_waves, len(self.SECTIONS)), dtype=torch.int64, device=self.device)
+            self.cycles = torch.zeros((n_waves, len(self.SECTIONS) + 12), dtype=torch.int64, device=self.device)
             self._check(self.lib.dg_world_set_profile_buffer(self.handle, _ptr(self.cycles)))
         else:
             self._check(self.lib.dg_world_set_profile_buffer(self.handle, None))

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
                  (valid && term_flag) ? term_flag + e : nullptr);
   prof.stamp(PS_OUTPUT);
-  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_ROW + k] = prof.acc[k]; }
 }
 
 // First substep's dynamics of the moving bodies number `parity`, `parity` + 2, ... (two wavefronts share them while the
@@ -54,6 +54,9 @@ DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
 // where it is on the critical path): wave 1 (the helper) runs the inverse kinematics
 // and the register-resident dynamics of sc.helper_body, wave 2 the narrow phase (when sc.coll_wave), wave 0 everything else.  Every global / LDS
 // hand-off between the two is separated by a __syncthreads (workgroup-scope release / acquire).
+// Diagnostic build only: wavefronts 1..3 record when they reach the workgroup's hand-over points (shader cycles since
+// their own start) behind the main wave's section stamps: cycles[workgroup][PS_COUNT + 4 (wave - 1) + {B0, B0', B4, end}].
+#define DG_WAVE_STAMP(k) do { if constexpr (PROF) { if (lane == 0) cycles[(size_t)blockIdx.x * PS_ROW + PS_COUNT + 4 * (wave - 1) + (k)] = __builtin_amdgcn_s_memtime() - t_start; } } while (0)
 template <bool PROF>
 __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
                                                         float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
@@ -62,11 +65,12 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
   const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
+  const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0ull; (void)t_start;
   if (wave == 3) {  // ---------------- second half of the narrow phase; in the early first substep, the dynamics of every second moving body
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    __syncthreads();  // B0
+    DG_WAVE_STAMP(0); __syncthreads();  // B0
     if (sc.early_dyn) early_dynamics(ln, 1);
-    __syncthreads();  // B0'
+    DG_WAVE_STAMP(1); __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {
       __syncthreads();  // B1
       if (sc.coll_split && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, sc.npairs / 2, 0x7fffffff, sc.cont2_off);
@@ -74,19 +78,20 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
       if (split_decide_follow(ln, 0u, false)) __syncthreads();  // Bs: the sweeps run on the first two wavefronts
       __syncthreads();  // B3
     }
-    __syncthreads();  // B4: every final pose is in LDS, every state row written
+    DG_WAVE_STAMP(2); __syncthreads();  // B4: every final pose is in LDS, every state row written
     run_output_ops(ln, nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr, (valid && term) ? term + (size_t)e * sc.term_dim : nullptr,
                    (valid && rew_sum) ? rew_sum + e : nullptr, (valid && term_flag) ? term_flag + e : nullptr, OUT_REW_TERM);
+    DG_WAVE_STAMP(3);
     return;
   }
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    __syncthreads();  // B0
+    DG_WAVE_STAMP(0); __syncthreads();  // B0
     if (sc.early_dyn) {  // first substep: narrow phase and the arms' dynamics while the first two waves run the update ops
       collide<64, 64>(ln);  // (the fourth wavefront takes every second moving body's dynamics)
       early_dynamics(ln, 0);
     }
-    __syncthreads();  // B0'
+    DG_WAVE_STAMP(1); __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) {
       __syncthreads();  // B1: every pose is in LDS
       if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, 0, sc.coll_split ? sc.npairs / 2 : 0x7fffffff);  // contact list + count go to LDS; the main wave reads them after B2
@@ -94,21 +99,23 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
       if (split_decide_follow(ln, false, false)) __syncthreads();  // Bs
       __syncthreads();  // B3
     }
-    __syncthreads();  // B4
+    DG_WAVE_STAMP(2); __syncthreads();  // B4
     run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_OBS_REST);
+    DG_WAVE_STAMP(3);
     return;
   }
   if (wave == 1) {  // ---------------- helper
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
     ln.kinematics(sc.helper_body);
-    __syncthreads();  // B0: every pose is in LDS
+    DG_WAVE_STAMP(0); __syncthreads();  // B0: every pose is in LDS
     if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1, diag);
-    __syncthreads();  // B0'
+    DG_WAVE_STAMP(1); __syncthreads();  // B0'
     for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0);
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
-    __syncthreads();  // B4
+    DG_WAVE_STAMP(2); __syncthreads();  // B4
     // its arm's joint-state observations (state reads only; the main wave skips them)
     run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_OF, sc.helper_body);
+    DG_WAVE_STAMP(3);
     return;
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   // wavefront the other observe ops, the fourth the reward / terminal ops and the collapsed outputs
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_NOT_OF, sc.helper_body);
   prof.stamp(PS_OUTPUT);
-  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_COUNT + k] = prof.acc[k]; }
+  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_ROW + k] = prof.acc[k]; }
 }
 
 template <int LANES>

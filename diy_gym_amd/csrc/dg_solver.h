@@ -9,7 +9,8 @@ namespace dg {
 // ---------------------------------------------------------------- in-kernel stamps
 // Diagnostic builds only (template PROF = true): wave-uniform cycle counters per section of the step.
 // The production instantiation (PROF = false) contains no stamp at all.
-enum { PS_UPDATE = 0, PS_KIN, PS_COLLIDE, PS_ABA, PS_MINV, PS_ROWS, PS_PGS, PS_INTEGRATE, PS_OUTPUT, PS_PGS_MOTOR, PS_PGS_LIMIT, PS_PGS_CONTACT, PS_COUNT };
+enum { PS_UPDATE = 0, PS_KIN, PS_COLLIDE, PS_ABA, PS_MINV, PS_ROWS, PS_PGS, PS_INTEGRATE, PS_OUTPUT, PS_PGS_MOTOR, PS_PGS_LIMIT, PS_PGS_CONTACT, PS_COUNT,
+       PS_ROW = PS_COUNT + 12 /* row pitch of the stamp buffer: + {B0, B0', B4, end} arrival of wavefronts 1..3 (helper-wave kernel) */ };
 template <bool PROF> struct Prof;
 template <> struct Prof<false> { DGD void start() {} DGD void stamp(int) {} };
 template <> struct Prof<true> {
@@ -1022,7 +1023,8 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
   for (int i = 0; i < RN; i++) { if (__any(la[0][i] >= 0.f)) lim_rows |= 1u << (2 * i); if (__any(la[1][i] >= 0.f)) lim_rows |= 2u << (2 * i); }
   (void)any_limit;
   bool live = valid; int iters_done = 0;
-  for (int it = 0; it < sc.iters; it++) {
+  // one sweep over the six motor rows (straight-line), then the limit rows the wavefront needs
+  auto sweep = [&](auto with_limits) {
     float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < RN; i++) {
@@ -1033,7 +1035,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
       for (int c = 0; c < RN; c++) rdv[c] += rM[i * RN + c] * delta;
       maxabs = fmaxf(maxabs, fabsf(delta * rdg[i]));
     }
-    if (lim_rows) {  // after the body's motor rows, as in the single-wave order
+    if constexpr (decltype(with_limits)::value) {  // after the body's motor rows, as in the single-wave order
 #pragma unroll
       for (int i = 0; i < RN; i++) {
 #pragma unroll
@@ -1050,9 +1052,13 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
       }
     }
     const float m = half_swap_max(maxabs);  // the env's residual over both arms
-    if (live) iters_done = it + 1;
     live = live && !(m <= thr_abs);
-    if (!__any(live)) break;
+  };
+  // two copies of the loop: the common one (no lane near a joint limit) carries no limit code at all
+  if (lim_rows == 0u) {
+    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::false_type{}); if (!__any(live)) break; }
+  } else {
+    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::true_type{}); if (!__any(live)) break; }
   }
 #pragma unroll
   for (int i = 0; i < RN; i++) if (i < n) { W(dvo + i) = rdv[i]; W(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }

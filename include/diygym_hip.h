@@ -118,8 +118,9 @@ int32_t dg_world_set_diag_buffer(dg_world* w, int32_t* diag);
 
 /* Diagnostic build of the step kernel with in-kernel cycle stamps (s_memtime): when `cycles` is
  * non-NULL, dg_world_step launches the stamped instantiation and lane 0 of every wavefront writes
- * cycles[wave][12] = shader cycles spent in {update ops (IK), kinematics, narrow phase, ABA passes,
- * M^-1 columns, row setup, PGS (rest), position update, output ops, PGS motor rows, PGS limit rows, PGS contact rows}.  Never used for timing quotes: the
+ * cycles[workgroup][24]: entries 0..11 = shader cycles the (main) wavefront spent in {update ops (IK), kinematics, narrow phase, ABA passes,
+ * M^-1 columns, row setup, PGS (rest), position update, output ops, PGS motor rows, PGS limit rows, PGS contact rows}; entries 12..23 (helper-wave kernel only) = cycles after which wavefronts
+ * 1, 2, 3 reached {pose hand-over, end of the update phase, final hand-over, their end}.  Never used for timing quotes: the
  * stamps serialise the instruction stream.  Pass NULL (default) for the production kernel. */
 int32_t dg_world_set_profile_buffer(dg_world* w, uint64_t* cycles);
 

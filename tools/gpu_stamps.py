@@ -14,7 +14,7 @@ gen = torch.Generator().manual_seed(1)
 ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0') for _ in range(8)]
 for i in range(int(os.environ.get("SETTLE", "10"))): env.sim.step(env._all_slots, ring[i % 8] * float(os.environ.get("ACT_SCALE", "1")))
 cyc = env.sim.enable_stamps()
-tot = torch.zeros(len(env.sim.SECTIONS), dtype=torch.float64)
+tot = torch.zeros(len(env.sim.SECTIONS) + 12, dtype=torch.float64)
 scale = float(os.environ.get('ACT_SCALE', '1'))
 ring = [r * scale for r in ring]
 n = 16
@@ -22,10 +22,14 @@ for i in range(n):
     env.sim.step(env._all_slots, ring[i % 8]); torch.cuda.synchronize()
     tot += cyc.double().mean(0).cpu()
 tot /= n
+waves = tot[len(env.sim.SECTIONS):].tolist(); tot = tot[:len(env.sim.SECTIONS)]
 s = float(tot.sum())
 print('%s B=%d: %.0f cycles per wave per step (median wave)' % (name, B, s))
 for k, v in zip(env.sim.SECTIONS, tot.tolist()):
     print('  %-13s %9.0f  %5.1f %%' % (k, v, 100 * v / s))
+if any(waves):
+    for w in range(3):
+        print('  wavefront %d reached: pose hand-over %.0f | end of update phase %.0f | final hand-over %.0f | its end %.0f' % ((w + 1,) + tuple(waves[4 * w:4 * w + 4])))
 env.sim.enable_stamps(False)
 d = env.sim.enable_diagnostics()
 for i in range(4): env.sim.step(env._all_slots, ring[i % 8])

@@ -271,7 +271,11 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.split_pgs = 0;
   if (w->par && !getenv("DG_NO_SPLIT_SWEEPS")) {
     int jointed = 0; for (int b = 0; b < nb; b++) if (BI[b * DG_BI_STRIDE + DG_BI_N_LINKS] > 0) jointed++;
-    if (jointed == 2 && sc.reg_body[0] >= 0 && sc.reg_body[1] == sc.helper_body && sc.reg_body[0] != sc.helper_body) sc.split_pgs = 1;
+    if (jointed == 2 && sc.reg_body[0] >= 0 && sc.reg_body[1] == sc.helper_body && sc.reg_body[0] != sc.helper_body) {
+      sc.split_pgs = 1;
+      // contact rows too when the dense DoF vector holds nothing but the two arms (no free body a contact could involve)
+      if (dense && nt == PLB[sc.reg_body[0] * PLB_STRIDE + PLB_NV] + PLB[sc.reg_body[1] * PLB_STRIDE + PLB_NV] && !getenv("DG_NO_SPLIT_CONTACTS")) sc.split_pgs = 2;
+    }
   }
   // a fourth wavefront for the second half of the pair table, if its contact list still fits LDS
   sc.coll_split = 0; sc.cont2_off = 0;

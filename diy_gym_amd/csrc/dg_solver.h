@@ -941,6 +941,9 @@ DGD void integrate_body(const Lane<LANES>& ln, int b) {
   }
 }
 
+// contacts per env the arm-per-half-wavefront sweeps can carry in registers (3 rows of 6 + 6 floats each per lane);
+// substeps with more contacts in some env of the workgroup take the single-wave streamed sweeps
+#define DG_SPLIT_MAX_CONTACTS 3
 // Six workspace slots for the residual exchange (4) and the two decision flags: the tail of the padding behind the
 // velocity-change blocks (nv_max + 8 slots; readers of that padding only ever multiply it by zero, and these values
 // are finite).
@@ -952,7 +955,9 @@ DGD int split_slots(const DevScene& sc) { return sc.dv_base + sc.nt + sc.nv_max;
 template <int LANES>
 DGD bool split_decide_main(const Lane<LANES>& ln, int wave_max_cont, uint64_t& limit_mask, uint64_t& limit_rows) {
   const DevScene& sc = ln.sc; const int xo = split_slots(sc);
-  ln.L(xo + 4) = (sc.split_pgs && wave_max_cont == 0) ? 1.f : 0.f;  // same value in every lane's column (limit rows are swept in registers too)
+  // split unless some env has more contacts than the register sweeps carry (limit rows are swept in registers too);
+  // sc.split_pgs == 2: the dense DoF vector is exactly the two arms, so contact rows can be split by arm as well
+  ln.L(xo + 4) = (sc.split_pgs && (wave_max_cont == 0 || (sc.split_pgs == 2 && wave_max_cont <= DG_SPLIT_MAX_CONTACTS))) ? 1.f : 0.f;
   __syncthreads();  // Bq
   // the helper's active limit rows (2 bits per joint of its body, as a small integer), for the single-wave sweeps
   // that run when contacts couple the bodies
@@ -988,6 +993,11 @@ DGD float half_swap_max(float x) {  // max over lanes l and l ^ 32, in every lan
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return fmaxf(a, b);
 }
+DGD float half_swap_sum(float x) {  // x[l & 31] + x[32 + (l & 31)] in every lane (same operand order in both halves)
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 template <int LANES>
 DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
   constexpr int RN = 6;
@@ -1022,9 +1032,46 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
   for (int i = 0; i < RN; i++) { if (__any(la[0][i] >= 0.f)) lim_rows |= 1u << (2 * i); if (__any(la[1][i] >= 0.f)) lim_rows |= 2u << (2 * i); }
   (void)any_limit;
+  // Contact rows (arms touching each other): the dense rows the main wave built are [J nt][R nt][b acc diag] over the
+  // global DoF vector = (first arm, second arm), so this lane's share of a row is the 6 + 6 entries of ITS arm; the
+  // row's J . dv is the sum over the two halves (one v_permlane32_swap), and both lanes apply the same impulse to
+  // their own arm.  Same row order as every other path: normals of all contacts, then the friction pairs.
+  constexpr int CM = DG_SPLIT_MAX_CONTACTS;
+  const int ncont = (int)W(sc.cont_off), g = (half ? ln.plb(b1)[PLB_DV] : ln.plb(b0)[PLB_DV]) - sc.dv_base;
+  int cmax = 0;
+#pragma unroll
+  for (int c = 0; c < CM; c++) if (__any(c < ncont)) cmax = c + 1;
+  float cJ[3 * CM][RN], cR[3 * CM][RN], cb[3 * CM], cdg[3 * CM], cdi[3 * CM], cacc[3 * CM], cmu[CM];
+  if (cmax > 0) {
+    const int nt = sc.nt, rs = sc.crow_tail + 3;
+#pragma unroll
+    for (int c = 0; c < CM; c++) {
+      const bool has = c < ncont; const int cc = has ? c : 0;  // lanes without this contact read contact 0's slots and zero them
+      cmu[c] = has ? W(sc.cont_off + 1 + cc * CL_STRIDE + CL_MU) : 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int r = 3 * c + d, ro = sc.tr_off + (3 * cc + d) * rs;
+#pragma unroll
+        for (int k = 0; k < RN; k++) { const bool hk = has && k < n; const int kk = k < n ? k : 0; const float j = W(ro + g + kk), rr = W(ro + nt + g + kk); cJ[r][k] = hk ? j : 0.f; cR[r][k] = hk ? rr : 0.f; }
+        const float bb = W(ro + 2 * nt), dd = W(ro + 2 * nt + 2);
+        cb[r] = has ? bb : 0.f; cdg[r] = has ? dd : 1.f; cdi[r] = (has && dd > 1e-18f) ? frcp(dd) : 0.f; cacc[r] = 0.f;
+      }
+    }
+  }
   bool live = valid; int iters_done = 0;
-  // one sweep over the six motor rows (straight-line), then the limit rows the wavefront needs
-  auto sweep = [&](auto with_limits) {
+  auto contact_row = [&](int r, float lo, float hi, float lv, float& maxabs) {
+    float jp = 0.f;
+#pragma unroll
+    for (int k = 0; k < RN; k++) jp += cJ[r][k] * rdv[k];
+    const float jv = half_swap_sum(jp);
+    const float nacc = fminf(fmaxf(cacc[r] + (cb[r] - jv) * cdi[r], lo), hi);
+    const float delta = cdi[r] != 0.f ? (nacc - cacc[r]) * lv : 0.f; cacc[r] += delta;
+#pragma unroll
+    for (int k = 0; k < RN; k++) rdv[k] += cR[r][k] * delta;
+    maxabs = fmaxf(maxabs, fabsf(delta * cdg[r]));
+  };
+  // one sweep over the six motor rows (straight-line), then the limit rows the wavefront needs, then the contact rows
+  auto sweep = [&](auto with_limits, auto with_contacts) {
     float maxabs = 0.f; const float lv = live ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < RN; i++) {
@@ -1051,14 +1098,25 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
         }
       }
     }
+    if constexpr (decltype(with_contacts)::value) {
+#pragma unroll
+      for (int c = 0; c < CM; c++) if (c < cmax) contact_row(3 * c, 0.f, 3.0e38f, lv, maxabs);
+#pragma unroll
+      for (int c = 0; c < CM; c++) if (c < cmax) {
+        const float lim = cmu[c] * cacc[3 * c];  // mu = 0 (or no such contact in this lane): the pair stays at zero
+        contact_row(3 * c + 1, -lim, lim, lv, maxabs); contact_row(3 * c + 2, -lim, lim, lv, maxabs);
+      }
+    }
     const float m = half_swap_max(maxabs);  // the env's residual over both arms
     live = live && !(m <= thr_abs);
   };
-  // two copies of the loop: the common one (no lane near a joint limit) carries no limit code at all
-  if (lim_rows == 0u) {
-    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::false_type{}); if (!__any(live)) break; }
+  // three copies of the loop: the common one (no lane near a joint limit, no contact) carries neither kind of code
+  if (cmax > 0) {
+    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::true_type{}, std::true_type{}); if (!__any(live)) break; }
+  } else if (lim_rows == 0u) {
+    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::false_type{}, std::false_type{}); if (!__any(live)) break; }
   } else {
-    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::true_type{}); if (!__any(live)) break; }
+    for (int it = 0; it < sc.iters; it++) { if (live) iters_done = it + 1; sweep(std::true_type{}, std::false_type{}); if (!__any(live)) break; }
   }
 #pragma unroll
   for (int i = 0; i < RN; i++) if (i < n) { W(dvo + i) = rdv[i]; W(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }

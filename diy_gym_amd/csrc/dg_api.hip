@@ -415,10 +415,31 @@ int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* 
   launch_table(w->lanes).pose(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), w->ncam, w->d_CI, w->d_CF, w->d_render_table, w->d_gws);
   HIP_TRY(hipGetLastError());
   const int32_t* I = w->I.data(); const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE;
-  const int tiles = ((ci[DG_CI_WIDTH] + DG_TILE - 1) / DG_TILE) * ((ci[DG_CI_HEIGHT] + DG_TILE - 1) / DG_TILE);
-  hipLaunchKernelGGL(render_kernel, dim3(tiles, w->num_envs), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
-                     (cfp)w->d_render_table, rgb, depth, seg);
+  // Rows per workgroup: a multiple of 8 (the tile height of render_kernel's wavefronts; 200-wide images: whole cache lines).
+  // Every workgroup first builds its list of shapes, faces and vertices (phase A, a few microseconds of dependent loads),
+  // so a workgroup should render as many rows as the machine's occupancy allows: about four workgroups per CU over the
+  // whole launch -- with >= 1024 envs one workgroup renders a whole image.
+  const int W = ci[DG_CI_WIDTH], H = ci[DG_CI_HEIGHT];
+  int band_rows;
+  { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, w->device));
+    const int want_blocks = 4 * std::max(prop.multiProcessorCount, 1), bands_per_env = std::max(1, (want_blocks + w->num_envs - 1) / w->num_envs);
+    band_rows = std::max(8, ((H + bands_per_env - 1) / bands_per_env + 7) / 8 * 8); }
+  band_rows = std::min(band_rows, H);
+  const int nbands = (H + band_rows - 1) / band_rows;
+  const long long blocks = (long long)nbands * w->num_envs;  // the env index is folded into grid.x (grid.y stops at 65535)
+  if (blocks > 0x7fffffffLL) return fail(DG_ERR_UNSUPPORTED, "render: %lld workgroups exceed the grid limit", blocks);
+  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+                     (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, (getenv("DG_RENDER_NO_CULL") ? 1 : 0) | (getenv("DG_RENDER_DIAG") ? atoi(getenv("DG_RENDER_DIAG")) : 0));
   HIP_TRY(hipGetLastError());
+  return DG_OK;
+}
+
+// diagnostics: candidate counters of the render kernel (DG_RENDER_DIAG & 16); not part of the public header
+int32_t dg_debug_render_counters(uint64_t* out16, int32_t reset) {
+  unsigned long long h[16];
+  HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_render_count), sizeof h));
+  for (int k = 0; k < 16; k++) out16[k] = h[k];
+  if (reset) { memset(h, 0, sizeof h); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_render_count), h, sizeof h)); }
   return DG_OK;
 }
 

@@ -102,88 +102,269 @@ DGD void ray_hull(V3 o, V3 d, const M3& Rl, V3 pl, cfp planes, int np, RayHit& h
 }
 
 #ifdef DG_DEFINE_RENDER_KERNEL  // defined in exactly one translation unit (dg_api.hip)
-// One 16 x 16 pixel tile per workgroup.  Phase 1: the 256 threads cull the env's shapes against the tile's viewing
-// cone (bounding spheres) and compact the survivors IN SHAPE ORDER into an LDS list, so ties between coincident
-// surfaces resolve exactly as in a brute-force loop.  Phase 2: every pixel intersects only the listed shapes; the
-// shape index is wave-uniform, so poses and parameters come through scalar loads.
-#define DG_TILE 32  /* pixels per tile side; 256 threads x 4 pixels each */
-__global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF, cfp PLN, int cam, int ncam, cfp table, float* rgb, float* depth, int32_t* seg) {
-  __shared__ int s_list[1024]; __shared__ int s_wave_count[4]; __shared__ int s_total;
-  const int env = blockIdx.y, tid = threadIdx.x; cip ci = CI + cam * DG_CI_STRIDE; cfp cf = CF + cam * DG_CF_STRIDE;
-  const int W = ci[DG_CI_WIDTH], H = ci[DG_CI_HEIGHT]; const int tiles_x = (W + DG_TILE - 1) / DG_TILE;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+// One workgroup renders a BAND of full image rows of one env: the band is one contiguous, cache-line aligned piece of
+// every output image (200 x 200: 8 rows = 50 lines of depth, 150 of rgb), so each image line is written whole, by one
+// workgroup, through one L2.
+//   Phase A (once per band, 256 threads): thread t tests shape t against the band's viewing cone; survivors are
+//     compacted IN SHAPE ORDER (ties between coincident surfaces resolve exactly as in a brute-force loop) into an LDS
+//     list that holds everything phase B needs -- culling data, pose, parameters -- and the face planes of the
+//     surviving hulls are rewritten as (world normal, signed distance of the EYE): a ray then costs 3 FMAs and a
+//     reciprocal per face, with one broadcast LDS read.  A hull that contains the eye can never be ENTERED by a ray and
+//     is dropped.  Nothing in phase B touches the scene tables in global memory: with a handful of wavefronts per SIMD
+//     the dependent scalar loads of the previous version (two round trips to L2 per candidate, one per hull face) were
+//     what the kernel waited for -- 3.3 ms against 0.35 ms with the intersections switched off.
+//   Phase B: a wavefront takes a 16 x 8 pixel tile of the band at a time (two pixels per lane; the band is 8 rows
+//     high, so its 64-byte row pieces are completed into whole lines by the neighbouring tiles of the same workgroup),
+//     culls the band's list against the tile's cone (lane l tests entry l, one ballot), rejects every box / hull that
+//     has a SEPARATING FACE for the whole tile -- the eye on its outer side and no ray of the cone heading back towards
+//     it: lane l tests face l, one ballot -- and intersects what is left.  The separating-face test is what makes an
+//     eye sitting next to (or inside the bounding sphere of) big or nearby geometry cheap: the ground under a camera
+//     that looks up, the gripper the camera is mounted on.
+// Rays are affine in the pixel coordinates (dir = A + col B + row C): no division anywhere in the pixel path.
+__device__ unsigned long long g_render_count[16];  // diagnostic build-in counters (DG_RENDER_DIAG & 16), read by dg_debug_render_counters
+#ifdef DG_RENDER_COUNTERS  /* make CXXFLAGS+=-DDG_RENDER_COUNTERS: per-stage candidate counts for tools/gpu_cam_bench.py */
+#define DG_RCOUNT(k) do { if ((diag & 16) && lane == 0) atomicAdd(&g_render_count[k], 1ull); } while (0)
+#else
+#define DG_RCOUNT(k) do { } while (0)
+#endif
+#define DG_RL_CAP 96     /* list entries per band */
+#define DG_RP_CAP 1024   /* hull faces per band   */
+#define DG_RT_CAP 1024   /* hull points / box corners per band */
+enum { RL_V = 0 /* centre - eye */, RL_BOUND = 3, RL_R = 4, RL_P = 13, RL_PRM = 16, RL_STRIDE = 20 };  // floats per entry; ints alongside
+enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_STRIDE };
+DGD void ray_hull_world(V3 d, const float (*pl)[4], int np, RayHit& h, int sh) {
+  // faces as (world normal n, s = signed distance of the eye): the ray eye + t d crosses the face at t = -s / (n . d).
+  // Entry = the latest crossing of a front face (n . d < 0), exit = the earliest of a back face; a ray parallel to a
+  // face it lies outside of misses.  The entry face is tracked by index (its normal is fetched once at the end).
+  float tn = -3.0e38f, tf = 3.0e38f; int kn = 0; bool miss = np == 0;
+  for (int k = 0; k < np; k++) {
+    const float den = pl[k][0] * d.x + pl[k][1] * d.y + pl[k][2] * d.z, dist = pl[k][3];
+    const float t = -dist * __frcp_rn(den);
+    const bool par = fabsf(den) < 1e-30f, front = den < 0.f;
+    miss = miss || (par && dist > 0.f);
+    const bool later = front && !par && t > tn; tn = later ? t : tn; kn = later ? k : kn;
+    tf = (!front && !par) ? fminf(tf, t) : tf;
+  }
+  if (miss || tn > tf || tn <= 0.f || tn >= h.t) return;
+  h.t = tn; h.n = v3(pl[kn][0], pl[kn][1], pl[kn][2]); h.shape = sh;
+}
+__global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF, cfp PLN, int cam, int ncam, cfp table, float* rgb, float* depth, int32_t* seg,
+                                                      int band_rows, int nbands, int diag) {
+  const int no_cull = diag & 1;  // diagnostics (DG_RENDER_DIAG): 1 test every shape for every pixel group, 2 skip every intersection, 4 skip hulls
+  __shared__ float s_f[DG_RL_CAP][RL_STRIDE]; __shared__ int s_i[DG_RL_CAP][RLI_STRIDE]; __shared__ float s_pl[DG_RP_CAP][4]; __shared__ float s_pt[DG_RT_CAP][3];
+  __shared__ int s_wave_count[4]; __shared__ int s_scan[4], s_scan2[4];
+  const int env = blockIdx.x / nbands, band = blockIdx.x - env * nbands, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  cip ci = CI + cam * DG_CI_STRIDE; cfp cf = CF + cam * DG_CF_STRIDE;
+  const int W = ci[DG_CI_WIDTH], H = ci[DG_CI_HEIGHT];
+  const int r0 = band * band_rows, nrows = min(band_rows, H - r0), npx = nrows * W;
   cfp tb = table + (size_t)env * (sc.nsh * RS_STRIDE + ncam * RC_STRIDE); cfp cp = tb + sc.nsh * RS_STRIDE + cam * RC_STRIDE;
   M3 Rc; _Pragma("unroll") for (int k = 0; k < 9; k++) Rc.m[k] = cp[k];
   const V3 pc = v3(cp[9], cp[10], cp[11]);
-  const float zn = cf[DG_CF_NEAR], zf = cf[DG_CF_FAR], th = tanf(0.5f * cf[DG_CF_FOV] * 0.017453292519943295f), aspect = (float)W / (float)H;
-  auto ray = [&](float c, float r) { const float xn = (c / W) * 2.0f - 1.0f, yn = 1.0f - (r / H) * 2.0f; return mul(Rc, v3(xn * th * aspect, yn * th, -1.0f)); };
-  // ---- phase 1: tile cone = axis through the tile centre, half angle to the farthest corner
-  const float c0 = tx * DG_TILE, c1 = fminf((float)(tx + 1) * DG_TILE, (float)W), r0 = ty * DG_TILE, r1 = fminf((float)(ty + 1) * DG_TILE, (float)H);
-  V3 axis = ray(0.5f * (c0 + c1), 0.5f * (r0 + r1)); axis = axis * rsqrtf(dot(axis, axis));
-  float cos_t = 1.0f;
-  { const V3 k0 = ray(c0, r0), k1 = ray(c1, r0), k2 = ray(c0, r1), k3 = ray(c1, r1);
-    cos_t = fminf(fminf(dot(k0, axis) * rsqrtf(dot(k0, k0)), dot(k1, axis) * rsqrtf(dot(k1, k1))), fminf(dot(k2, axis) * rsqrtf(dot(k2, k2)), dot(k3, axis) * rsqrtf(dot(k3, k3)))); }
-  const float sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.f));
-  int total = 0;
-  for (int base = 0; base < sc.nsh; base += 256) {
-    const int sh = base + tid; bool pass = false;
-    if (sh < sc.nsh) {
-      cfp s = tb + sh * RS_STRIDE; const V3 v = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; const float R = s[RS_BOUND], d2 = dot(v, v);
-      if (d2 <= R * R) pass = true;
-      else {
-        const float inv = rsqrtf(d2), cos_a = dot(v, axis) * inv, sin_b = R * inv, cos_b = sqrtf(fmaxf(1.0f - sin_b * sin_b, 0.f));
-        const float cos_sum = cos_t * cos_b - sin_t * sin_b, sin_sum = sin_t * cos_b + cos_t * sin_b;  // cos / sin (theta + beta)
-        pass = sin_sum < 0.f || cos_sum <= -1.0f || cos_a >= cos_sum - 1e-4f;
+  const float zn = cf[DG_CF_NEAR], zf = cf[DG_CF_FAR], th = cf[DG_CF_TAN_HALF_FOV], aspect = (float)W / (float)H;
+  // pixel (col + 0.5, row + 0.5) -> xn = 2 c / W - 1, yn = 1 - 2 r / H, dir = Rc (xn th aspect, yn th, -1) = A + c B + r C
+  const float kx = th * aspect, sx = 2.0f * kx / (float)W, sy = -2.0f * th / (float)H;
+  const V3 rc0 = v3(Rc.m[0], Rc.m[3], Rc.m[6]), rc1 = v3(Rc.m[1], Rc.m[4], Rc.m[7]), rc2 = v3(Rc.m[2], Rc.m[5], Rc.m[8]);
+  const V3 rayA = rc1 * th - rc0 * kx - rc2, rayB = rc0 * sx, rayC = rc1 * sy;
+  const float lenB = sqrtf(dot(rayB, rayB)), lenC = sqrtf(dot(rayC, rayC));
+  auto ray = [&](float c, float r) { return rayA + rayB * c + rayC * r; };
+  // conservative cone around the rectangle [c0, c1] x [q0, q1] of pixel coordinates: axis through its centre, and
+  // every ray of the rectangle is the centre ray plus at most rho, so sin(angle) <= rho / |centre ray|
+  auto cone_of = [&](float c0, float c1, float q0, float q1, V3& axis, float& cos_t, float& sin_t) {
+    const V3 a = ray(0.5f * (c0 + c1), 0.5f * (q0 + q1)); const float ia = rsqrtf(dot(a, a));
+    axis = a * ia; sin_t = fminf((0.5f * (c1 - c0) * lenB + 0.5f * (q1 - q0) * lenC) * ia, 1.0f); cos_t = sqrtf(fmaxf(1.0f - sin_t * sin_t, 0.f));
+  };
+  auto cone_pass = [&](V3 v, float R, V3 axis, float cos_t, float sin_t) {
+    const float d2 = dot(v, v);
+    if (d2 <= R * R) return true;
+    const float inv = rsqrtf(d2), cos_a = dot(v, axis) * inv, sin_b = R * inv, cos_b = sqrtf(fmaxf(1.0f - sin_b * sin_b, 0.f));
+    const float cos_sum = cos_t * cos_b - sin_t * sin_b, sin_sum = sin_t * cos_b + cos_t * sin_b;  // cos / sin (theta + beta)
+    return sin_sum < 0.f || cos_sum <= -1.0f || cos_a >= cos_sum - 1e-4f;
+  };
+  const float inv_w = 1.0f / (float)W;
+  auto row_col = [&](int p, int& row, int& col) { row = (int)(((float)p + 0.5f) * inv_w); col = p - row * W; if (col < 0) { row--; col += W; } else if (col >= W) { row++; col -= W; } };
+  // ---------------- phase A: the band's list
+  int total = 0, total_planes = 0, total_points = 0;
+  {
+    V3 baxis; float bcos, bsin; cone_of(0.f, (float)W, (float)r0, (float)(r0 + nrows), baxis, bcos, bsin);
+    for (int chunk = 0; chunk < sc.nsh; chunk += 256) {
+      const int sh = chunk + tid; bool pass = false; V3 v = v3(0.f, 0.f, 0.f); float Rb = 0.f;
+      if (sh < sc.nsh) {
+        cfp s = tb + sh * RS_STRIDE; v = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; Rb = s[RS_BOUND];
+        pass = no_cull || cone_pass(v, Rb, baxis, bcos, bsin);
+      }
+      const unsigned long long m = __ballot(pass);
+      if (lane == 0) s_wave_count[wv] = __popcll(m);
+      __syncthreads();
+      int off = total; for (int k = 0; k < wv; k++) off += s_wave_count[k];
+      if (pass) {
+        const int idx = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (idx < DG_RL_CAP) {
+          cfp s = tb + sh * RS_STRIDE; cip si = sc.SI + sh * DG_SI_STRIDE; cfp sf = sc.SF + sh * DG_SF_STRIDE; float* o = s_f[idx];
+          o[RL_V] = v.x; o[RL_V + 1] = v.y; o[RL_V + 2] = v.z; o[RL_BOUND] = Rb;
+          _Pragma("unroll") for (int q = 0; q < 9; q++) o[RL_R + q] = s[RS_R + q];
+          o[RL_P] = s[RS_P]; o[RL_P + 1] = s[RS_P + 1]; o[RL_P + 2] = s[RS_P + 2];
+          o[RL_PRM] = sf[DG_SF_PARAMS]; o[RL_PRM + 1] = sf[DG_SF_PARAMS + 1]; o[RL_PRM + 2] = sf[DG_SF_PARAMS + 2];
+          s_i[idx][RLI_TYPE] = si[DG_SI_TYPE]; s_i[idx][RLI_SHAPE] = sh; s_i[idx][RLI_NP] = si[DG_SI_TYPE] == DG_SHAPE_POINTS ? si[DG_SI_N_PLANES] : (si[DG_SI_TYPE] == DG_SHAPE_BOX ? 6 : 0); s_i[idx][RLI_PLANE_OFF] = 0;
+          s_i[idx][RLI_NPT] = si[DG_SI_TYPE] == DG_SHAPE_POINTS ? si[DG_SI_N_POINTS] : (si[DG_SI_TYPE] == DG_SHAPE_BOX ? 8 : 0); s_i[idx][RLI_PT_OFF] = 0;
+        }
+      }
+      total += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+      __syncthreads();
+    }
+    // where each surviving hull's faces go: exclusive scan of the face counts over the list (<= 96 entries: two wavefronts)
+    if (total <= DG_RL_CAP) {
+      const int np = tid < total ? s_i[tid][RLI_NP] : 0, npt = tid < total ? s_i[tid][RLI_NPT] : 0; int incl = np, incl2 = npt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(incl, o), t3 = __shfl_up(incl2, o); if (lane >= o) { incl += t2; incl2 += t3; } }
+      if (lane == 63) { s_scan[wv] = incl; s_scan2[wv] = incl2; }
+      __syncthreads();
+      int base = 0, base2 = 0; for (int k = 0; k < wv; k++) { base += s_scan[k]; base2 += s_scan2[k]; }
+      if (tid < total) { s_i[tid][RLI_PLANE_OFF] = base + incl - np; s_i[tid][RLI_PT_OFF] = base2 + incl2 - npt; }
+      total_planes = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3]; total_points = s_scan2[0] + s_scan2[1] + s_scan2[2] + s_scan2[3];
+      __syncthreads();
+    }
+  }
+  const bool overflow = total > DG_RL_CAP || total_planes > DG_RP_CAP || total_points > DG_RT_CAP;  // (then: the slow path below, straight from the tables)
+  if (!overflow) {
+    // faces of the surviving hulls and boxes -> (world normal, signed distance of the eye); one wavefront per entry at a time
+    for (int e = wv; e < total; e += 4) {
+      const int np = s_i[e][RLI_NP]; if (np == 0) continue;
+      const int sh = s_i[e][RLI_SHAPE], po = s_i[e][RLI_PLANE_OFF]; const bool box = s_i[e][RLI_TYPE] == DG_SHAPE_BOX;
+      cfp planes = PLN + 4 * sc.SI[sh * DG_SI_STRIDE + DG_SI_PLANE_OFF];
+      M3 Rl; _Pragma("unroll") for (int q = 0; q < 9; q++) Rl.m[q] = s_f[e][RL_R + q];
+      const V3 ol = tmul(Rl, pc - v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]));
+      bool outside = false;
+      for (int k = lane; k < np; k += 64) {
+        V3 n; float d0;
+        if (box) { const int ax = k >> 1; const float sg = (k & 1) ? -1.f : 1.f; n = v3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f); d0 = -s_f[e][RL_PRM + ax]; }  // face +-axis: n . x - half <= 0
+        else { n = v3(planes[4 * k], planes[4 * k + 1], planes[4 * k + 2]); d0 = planes[4 * k + 3]; }
+        const float dist = dot(n, ol) + d0; const V3 nw = mul(Rl, n);
+        s_pl[po + k][0] = nw.x; s_pl[po + k][1] = nw.y; s_pl[po + k][2] = nw.z; s_pl[po + k][3] = dist;
+        outside = outside || !(dist < -1e-6f);
+      }
+      // the eye inside a hull: no ray can ENTER it (ray_hull wants tn > 0); a box is entered from inside never either (ray_box: tn <= 0)
+      if (!__any(outside) && !no_cull && lane == 0) s_i[e][RLI_TYPE] = -1;
+      // vertices relative to the eye, for the tile-frustum test of phase B (hull points; the eight corners of a box)
+      { const int npt = s_i[e][RLI_NPT], pto = s_i[e][RLI_PT_OFF]; cfp pts = sc.PF + 3 * sc.SI[sh * DG_SI_STRIDE + DG_SI_POINT_OFF];
+        const V3 pl = v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]) - pc;
+        for (int k = lane; k < npt; k += 64) {
+          V3 q;
+          if (box) q = v3((k & 1) ? s_f[e][RL_PRM] : -s_f[e][RL_PRM], (k & 2) ? s_f[e][RL_PRM + 1] : -s_f[e][RL_PRM + 1], (k & 4) ? s_f[e][RL_PRM + 2] : -s_f[e][RL_PRM + 2]);
+          else q = v3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
+          const V3 w = pl + mul(Rl, q); s_pt[pto + k][0] = w.x; s_pt[pto + k][1] = w.y; s_pt[pto + k][2] = w.z;
+        } }
+    }
+    __syncthreads();
+  }
+  struct Px { V3 d; float idd; RayHit h; int row, col; bool inside; };
+  Px px[2];
+  const int n_entries = overflow ? sc.nsh : total;
+  // ---------------- phase B: a 16 x 8 tile per wavefront at a time (lane: column lane & 15, rows lane >> 4 and (lane >> 4) + 4)
+  const int ntx = (W + 15) >> 4, ntiles = ntx * ((nrows + 7) >> 3);
+  for (int tile = wv; tile < ntiles; tile += 4) {  // consecutive tiles (row-major) go to the four wavefronts: neighbours in time and in memory
+    const int tyi = tile / ntx, c0 = (tile - tyi * ntx) << 4, q0 = r0 + 8 * tyi, qn = min(8, r0 + nrows - q0);  // tile rows [q0, q0 + qn)
+    V3 axis; float cos_t, sin_t;
+    cone_of((float)c0, (float)min(c0 + 16, W), (float)q0, (float)(q0 + qn), axis, cos_t, sin_t);
+    // the tile's four side planes through the eye, outward normals (rays are A + c B + r C, so the plane of a column
+    // edge is spanned by its ray at row 0 and C, that of a row edge by its ray at column 0 and B)
+    const V3 eL = rayA + rayB * (float)c0, eR = rayA + rayB * (float)min(c0 + 16, W), eT = rayA + rayC * (float)q0, eB = rayA + rayC * (float)(q0 + qn);
+    V3 nL = cross(eL, rayC), nR = cross(eR, rayC), nT = cross(eT, rayB), nB = cross(eB, rayB);
+    if (dot(nL, rayB) > 0.f) nL = -nL;
+    if (dot(nR, rayB) < 0.f) nR = -nR;
+    if (dot(nT, rayC) > 0.f) nT = -nT;
+    if (dot(nB, rayC) < 0.f) nB = -nB;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int prow = (lane >> 4) + 4 * u, pcol = c0 + (lane & 15);
+      px[u].inside = prow < qn && pcol < W;
+      px[u].row = q0 + min(prow, qn - 1); px[u].col = min(pcol, W - 1);
+      px[u].d = ray(px[u].col + 0.5f, px[u].row + 0.5f); px[u].idd = __frcp_rn(dot(px[u].d, px[u].d));
+      px[u].h.t = zf; px[u].h.shape = -1; px[u].h.n = v3(0.f, 0.f, 1.f);
+    }
+    for (int base = 0; base < n_entries; base += 64) {
+      const int j = min(base + lane, n_entries - 1);
+      V3 ev; float eb;  // culling data of entry j: from the band's list, or (overflow) straight from the table
+      if (!overflow) { ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); eb = s_f[j][RL_BOUND]; }
+      else { cfp s = tb + j * RS_STRIDE; ev = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; eb = s[RS_BOUND]; }
+      const bool cand = base + lane < n_entries && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
+      for (unsigned long long mm = (diag & 2) ? 0ull : __ballot(cand); mm; mm &= mm - 1) {
+        const int jj = base + __ffsll((long long)mm) - 1;  // wave-uniform
+        if (!overflow) {
+          const float* e = s_f[jj]; const int type = s_i[jj][RLI_TYPE], k = s_i[jj][RLI_SHAPE];
+          DG_RCOUNT(type);  // 0..3: candidates after the sphere-cone test, by type
+          const V3 oc = v3(e[RL_V], e[RL_V + 1], e[RL_V + 2]); const float bound = e[RL_BOUND];
+          if ((type == DG_SHAPE_BOX || type == DG_SHAPE_POINTS) && !no_cull) {
+            // separating face for the whole tile: the eye on its outer side (s > 0) and every ray of the cone moving
+            // away from it or along it (n . d >= 0 for all d within the cone <=> n . axis >= sin_t for unit n)
+            const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP]; bool sep = false;
+            for (int f0 = 0; f0 < np; f0 += 64) { const int f = min(f0 + lane, np - 1); sep = sep || (s_pl[po + f][3] > 0.f && s_pl[po + f][0] * axis.x + s_pl[po + f][1] * axis.y + s_pl[po + f][2] * axis.z >= sin_t + 1e-5f); }
+            if (__any(sep)) continue;
+            DG_RCOUNT(4 + type);  // after the separating-face test
+            // every vertex outside one of the tile's side planes: the whole convex shape is (lane l tests vertex l)
+            const int pto = s_i[jj][RLI_PT_OFF], npt = s_i[jj][RLI_NPT]; bool inL = false, inR = false, inT = false, inB = false;
+            for (int f0 = 0; f0 < npt; f0 += 64) {
+              const bool have = f0 + lane < npt; const int f = min(f0 + lane, npt - 1); const V3 w = v3(s_pt[pto + f][0], s_pt[pto + f][1], s_pt[pto + f][2]);
+              inL = inL || (have && dot(nL, w) <= 0.f); inR = inR || (have && dot(nR, w) <= 0.f); inT = inT || (have && dot(nT, w) <= 0.f); inB = inB || (have && dot(nB, w) <= 0.f);
+            }
+            if (npt > 0 && (!__any(inL) || !__any(inR) || !__any(inT) || !__any(inB))) continue;
+            DG_RCOUNT(8 + type);  // after the frustum test
+          }
+          if (type != DG_SHAPE_BOX && !no_cull) {  // per-pixel bounding-sphere test before anything else
+            bool nr = false;
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const float tc = dot(oc, px[u].d) * px[u].idd; const V3 qv = oc - px[u].d * tc; nr = nr || dot(qv, qv) <= bound * bound; }
+            if (!__any(nr)) continue;
+          }
+          DG_RCOUNT(12 + type);  // intersected
+          if (type == DG_SHAPE_POINTS) {
+            if (!(diag & 4)) { const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP];
+#pragma unroll
+              for (int u = 0; u < 2; u++) ray_hull_world(px[u].d, &s_pl[po], np, px[u].h, k); }
+            continue;
+          }
+          M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[RL_R + q];
+          const V3 pp = v3(e[RL_P], e[RL_P + 1], e[RL_P + 2]); const float p0 = e[RL_PRM], p1 = e[RL_PRM + 1], p2 = e[RL_PRM + 2];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            if (type == DG_SHAPE_SPHERE) ray_sphere(pc, px[u].d, pp, p0, px[u].h, k);
+            else if (type == DG_SHAPE_BOX) ray_box(pc, px[u].d, R, pp, p0, p1, p2, px[u].h, k);
+            else { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * p1; ray_capsule(pc, px[u].d, pp - ax, pp + ax, p0, px[u].h, k); }
+          }
+        } else {  // more survivors than the list holds (never seen): everything from the tables, as slow as it is general
+          const int k = jj; cfp s = tb + k * RS_STRIDE; cip si = sc.SI + k * DG_SI_STRIDE; cfp sf = sc.SF + k * DG_SF_STRIDE; const int type = si[DG_SI_TYPE];
+          M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = s[RS_R + q];
+          const V3 pp = v3(s[RS_P], s[RS_P + 1], s[RS_P + 2]);
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            if (type == DG_SHAPE_SPHERE) ray_sphere(pc, px[u].d, pp, sf[DG_SF_PARAMS], px[u].h, k);
+            else if (type == DG_SHAPE_BOX) ray_box(pc, px[u].d, R, pp, sf[DG_SF_PARAMS], sf[DG_SF_PARAMS + 1], sf[DG_SF_PARAMS + 2], px[u].h, k);
+            else if (type == DG_SHAPE_CAPSULE) { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * sf[DG_SF_PARAMS + 1]; ray_capsule(pc, px[u].d, pp - ax, pp + ax, sf[DG_SF_PARAMS], px[u].h, k); }
+            else ray_hull(pc, px[u].d, R, pp, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], px[u].h, k);
+          }
+        }
       }
     }
-    const unsigned long long m = __ballot(pass); const int wv = tid >> 6, ln_ = tid & 63;
-    if (ln_ == 0) s_wave_count[wv] = __popcll(m);
-    __syncthreads();
-    int off = total; for (int k = 0; k < wv; k++) off += s_wave_count[k];
-    if (pass) { const int idx = off + __popcll(m & ((1ull << ln_) - 1ull)); if (idx < 1024) s_list[idx] = sh; }
-    total += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-    __syncthreads();
-  }
-  total = min(total, 1024);
-  (void)s_total;
-  // ---- phase 2: four pixels per thread (16 x 16 sub-tiles)
-  for (int sub = 0; sub < 4; sub++) {
-  const int col = tx * DG_TILE + (tid & 15) + 16 * (sub & 1), row = ty * DG_TILE + (tid >> 4) + 16 * (sub >> 1);
-  if (col >= W || row >= H) continue;
-  const V3 d = ray(col + 0.5f, row + 0.5f); const float idd = __frcp_rn(dot(d, d));
-  RayHit h; h.t = zf; h.shape = -1; h.n = v3(0.f, 0.f, 1.f);
-  for (int q = 0; q < total; q++) {
-    const int k = __builtin_amdgcn_readfirstlane(s_list[q]);
-    cfp s = tb + k * RS_STRIDE; cip si = sc.SI + k * DG_SI_STRIDE; cfp sf = sc.SF + k * DG_SF_STRIDE;
-    const int type = si[DG_SI_TYPE];
-    if (type == DG_SHAPE_POINTS || type == DG_SHAPE_CAPSULE) {
-      // per-pixel bounding-sphere test before the expensive ones (a hull has dozens of face planes)
-      const V3 oc = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; const float tc = dot(oc, d) * idd; const V3 qv = oc - d * tc; const float bound = s[RS_BOUND];
-      if (!__any(dot(qv, qv) <= bound * bound)) continue;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!px[u].inside) continue;
+      const RayHit& h = px[u].h;
+      const bool hit = h.shape >= 0 && h.t >= zn; const size_t o = (size_t)env * W * H + (size_t)px[u].row * W + px[u].col;
+      if (depth) depth[o] = hit ? -h.t : -zf;
+      if (seg) {
+        int vseg = -1;
+        if (hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vseg = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
+        seg[o] = vseg;
+      }
+      if (rgb) {
+        float c0r = 0.75f, c1r = 0.75f, c2r = 0.75f;
+        if (hit) {
+          cfp colr = sc.BF + sc.SI[h.shape * DG_SI_STRIDE + DG_SI_BODY] * DG_BF_STRIDE + DG_BF_COLOR;  // per-lane index: vector loads
+          const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
+          c0r = colr[0] * shd; c1r = colr[1] * shd; c2r = colr[2] * shd;
+        }
+        rgb[3 * o] = c0r; rgb[3 * o + 1] = c1r; rgb[3 * o + 2] = c2r;
+      }
     }
-    M3 R; _Pragma("unroll") for (int j = 0; j < 9; j++) R.m[j] = s[RS_R + j];
-    const V3 p = v3(s[RS_P], s[RS_P + 1], s[RS_P + 2]);
-    if (type == DG_SHAPE_SPHERE) ray_sphere(pc, d, p, sf[DG_SF_PARAMS], h, k);
-    else if (type == DG_SHAPE_BOX) ray_box(pc, d, R, p, sf[DG_SF_PARAMS], sf[DG_SF_PARAMS + 1], sf[DG_SF_PARAMS + 2], h, k);
-    else if (type == DG_SHAPE_CAPSULE) { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * sf[DG_SF_PARAMS + 1]; ray_capsule(pc, d, p - ax, p + ax, sf[DG_SF_PARAMS], h, k); }
-    else ray_hull(pc, d, R, p, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], h, k);
-  }
-  const bool hit = h.shape >= 0 && h.t >= zn; const size_t px = (size_t)env * W * H + (size_t)row * W + col;
-  if (depth) depth[px] = hit ? -h.t : -zf;
-  if (seg) {
-    int v = -1;
-    if (hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; v = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
-    seg[px] = v;
-  }
-  if (rgb) {
-    float c0r = 0.75f, c1r = 0.75f, c2r = 0.75f;
-    if (hit) {
-      cfp colr = sc.BF + sc.SI[h.shape * DG_SI_STRIDE + DG_SI_BODY] * DG_BF_STRIDE + DG_BF_COLOR;  // per-lane index: vector loads
-      const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
-      c0r = colr[0] * shd; c1r = colr[1] * shd; c2r = colr[2] * shd;
-    }
-    rgb[3 * px] = c0r; rgb[3 * px + 1] = c1r; rgb[3 * px + 2] = c2r;
-  }
   }
 }
 

@@ -492,7 +492,7 @@ class SceneBuilder:
             ('OFF_SHAPE_F', arr(shape_f, K.SF_STRIDE, np.float64)),
             ('OFF_POINT_F', arr(points, 3, np.float64)),
             ('OFF_PLANE_F', arr(planes, 4, np.float64)),
-            ('OFF_CAMERA_F', arr([[*c[5].p, *c[5].quat, c[6], c[7], c[8], 0.0, 0.0] for c in self.cameras], K.CF_STRIDE, np.float64)),
+            ('OFF_CAMERA_F', arr([[*c[5].p, *c[5].quat, c[6], c[7], c[8], float(np.tan(np.radians(0.5 * c[6]))), 0.0] for c in self.cameras], K.CF_STRIDE, np.float64)),
             ('OFF_OP_F', arr([o[1] for o in self.ops], K.OF_STRIDE, np.float64)),
             ('OFF_FLIST', np.asarray(self.flist, dtype=np.float64).reshape(-1, 1)),
         ]

@@ -171,7 +171,7 @@ enum { DG_GI_FIRST = 0, DG_GI_COUNT, DG_GI_BODY_A /* moving */, DG_GI_BODY_B /* 
 enum { DG_CI_BODY = 0 /* -1: fixed in the world */, DG_CI_FRAME /* global frame index or -1 = base */, DG_CI_WIDTH, DG_CI_HEIGHT,
        DG_CI_FLAGS, DG_CI_STRIDE };
 enum { DG_CF_POS = 0, DG_CF_QUAT = 3 /* T_parent_cam */, DG_CF_FOV = 7 /* vertical, degrees */, DG_CF_NEAR = 8, DG_CF_FAR = 9,
-       DG_CF_STRIDE = 12 };
+       DG_CF_TAN_HALF_FOV = 10 /* tan(fov / 2), so that no kernel evaluates a tangent */, DG_CF_STRIDE = 12 };
 #define DG_CAM_DEPTH 1
 #define DG_CAM_SEGMENTATION 2
 /* per-body flat colour for the (non parity) rgb output lives in the body float table */

@@ -98,3 +98,86 @@ def test_hip_render_matches_oracle():
         assert same.float().mean() > 0.995, name
         assert float((dg - dc).abs()[same].max()) < 1e-3, name
         assert float((g['rgb'].cpu() - c['rgb']).abs()[same].max()) < 1e-3, name
+
+
+@pytest.mark.gpu
+def test_gripper_camera_at_the_baseline_batch_1024_envs_200x200():
+    """BASELINE config 5 at its size: the 200 x 200 gripper camera of from_the_readme over 1 024 envs (655 MB of rgb +
+    depth per render).  Size-independent properties: bitwise repeatability, finiteness, depth in [-far, -near],
+    segmentation ids in range, rgb in [0, 1]; a sample of envs agrees with the oracle's renderer; odd image sizes
+    (rows that do not fill cache lines, a last band that is cut short) give the same picture as the oracle too."""
+    import diy_gym_amd.examples  # noqa: F401
+    import yaml
+    from diy_gym_amd.config import Configuration
+    cfg = os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml')
+    tree = yaml.safe_load(open(cfg))
+    tree['r2d2']['arm_camera']['use_segmentation_mask'] = True
+    # a second camera that actually looks at the scene (the gripper camera mostly sees the sky once R2D2 has settled)
+    tree['overview'] = {'addon': 'camera', 'xyz': [1.2, -0.9, 1.4], 'rpy': [0.9, 0.0, 0.9], 'resolution': [200, 200], 'use_segmentation_mask': True}
+    B = 1024
+    env = DIYGym(Configuration.from_dict('from_the_readme', tree), num_envs=B, device='cuda:0', seed=4)
+    lo = torch.full((B, env.layout.act_dim), -0.01, device='cuda:0')
+    gen = torch.Generator(device='cuda:0').manual_seed(0)
+    for _ in range(12):
+        env.sim.step(env._all_slots, lo + 0.02 * torch.rand(lo.shape, generator=gen, device='cuda:0'))
+    n_bodies = env.layout.n_bodies
+    for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
+        cam = env.receptors[rec].addons[name]
+        env._tick += 1
+        first = {k: v.clone() for k, v in cam.observe().items()}
+        env._tick += 1
+        again = cam.observe()
+        for k in first:
+            assert torch.equal(first[k], again[k]), (name, k)   # bitwise repeatable
+        assert first['rgb'].shape == (B, 200, 200, 3) and first['depth'].shape == (B, 200, 200)
+        assert bool(torch.isfinite(first['rgb']).all()) and bool(torch.isfinite(first['depth']).all())
+        assert float(first['depth'].max()) <= -0.01 and float(first['depth'].min()) >= -100.0
+        assert float(first['rgb'].min()) >= 0.0 and float(first['rgb'].max()) <= 1.0
+        seg = first['segmentation_mask']
+        assert int(seg.min()) >= -1 and int((seg[seg >= 0] & 0xFFFFFF).max() if (seg >= 0).any() else 0) < n_bodies
+    # the cone culling must not change a single pixel: render again with every shape tested for every pixel group
+    os.environ['DG_RENDER_NO_CULL'] = '1'
+    try:
+        for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
+            cam = env.receptors[rec].addons[name]
+            culled = {k: v.clone() for k, v in cam.observe().items()}
+            env._tick += 1
+            brute = cam.observe()
+            for k in culled:
+                assert torch.equal(culled[k], brute[k]), (name, k)
+    finally:
+        del os.environ['DG_RENDER_NO_CULL']
+    env._tick += 1
+    seen = (env.receptors['from_the_readme'].addons['overview'].observe()['segmentation_mask'] >= 0).float().mean()
+    assert float(seen) > 0.3   # the overview camera does see the table, the arm and R2D2
+    # parity on a sample: the same state in the oracle (state copied over), envs 0, 511, 1023
+    pick = [0, 511, 1023]
+    import copy
+    cpu = DIYGym(Configuration.from_dict('from_the_readme', copy.deepcopy(tree)), num_envs=len(pick), seed=4, backend_factory=OracleBackend)   # same key order = same uids
+    cpu.sim.set_state(env.sim.get_state()[pick])
+    cpu._tick += 1
+    for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
+        g = env.receptors[rec].addons[name].observe(); c = cpu.receptors[rec].addons[name].observe()
+        sg, sc = g['segmentation_mask'][pick].cpu(), c['segmentation_mask']
+        same = sg == sc
+        # the gripper camera sits a centimetre from R2D2's own fingers (surfaces at the near plane): fp32 / fp64 flips there
+        assert same.float().mean() > (0.97 if name == 'arm_camera' else 0.995), name
+        assert float((g['depth'][pick].cpu() - c['depth']).abs()[same].max()) < 2e-3, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('res', [[50, 50], [33, 33], [7, 7], [130, 130]])
+def test_hip_render_odd_sizes_match_oracle(res):
+    # rows that are not a whole number of cache lines, bands cut short by the image edge, images smaller than a pixel group
+    import copy
+    import yaml
+    from diy_gym_amd.config import Configuration
+    tree = yaml.safe_load(open(BASIC))
+    tree['camera']['use_segmentation_mask'] = True
+    tree['camera']['resolution'] = res
+    gpu = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=3, device='cuda:0', seed=2)
+    cpu = DIYGym(Configuration.from_dict('basic_env', copy.deepcopy(tree)), num_envs=3, seed=2, backend_factory=OracleBackend)
+    g = gpu.receptors['basic_env'].addons['camera'].observe(); c = cpu.receptors['basic_env'].addons['camera'].observe()
+    same = g['segmentation_mask'].cpu() == c['segmentation_mask']
+    assert same.float().mean() > 0.99
+    assert float((g['depth'].cpu() - c['depth']).abs()[same].max()) < 1e-3

@@ -1,23 +1,44 @@
+"""Render-kernel timing at BASELINE config 5's size: 1 024 envs x 200 x 200, rgb + depth (16 B per pixel)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, yaml
+import diy_gym_amd.examples
 from diy_gym_amd import DIYGym
 from diy_gym_amd.config import Configuration
-from diy_gym_amd.scene import K
 B = 1024
-def t(fn, n=10):
-    fn(); torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
-tree = yaml.safe_load(open(os.path.join(ROOT, 'tests/golden/basic_env.yaml')))
-tree['camera']['resolution'] = [200, 200]
-env = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=B, device='cuda:0')
-cam = env.addons['camera']; cam.observe(); rgb, depth, seg = cam._buffers
-ms = t(lambda: env.sim.render(cam.camera_index, rgb, depth, None))
-print('marbles top-down 200x200 x %d envs: %.3f ms -> %.0f GB/s image writes' % (B, ms, B * 200 * 200 * 16 / ms / 1e6))
-import diy_gym_amd.examples
-env2 = DIYGym(os.path.join(ROOT, 'examples/from_the_readme/from_the_readme.yaml'), num_envs=B, device='cuda:0')
-I = env2.layout.I
-SI = I[I[K.H_OFF_SHAPE_I]:I[K.H_OFF_SHAPE_I] + I[K.H_N_SHAPES] * K.SI_STRIDE].reshape(-1, K.SI_STRIDE)
-print('readme shapes', len(SI), 'types', [int((SI[:, 0] == k).sum()) for k in range(4)], 'hull planes total', I[K.H_N_PLANES], 'max per hull', SI[:, K.SI_N_PLANES].max())
+def t(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+tree = yaml.safe_load(open(os.path.join(ROOT, 'examples/from_the_readme/from_the_readme.yaml')))
+tree['overview'] = {'addon': 'camera', 'xyz': [1.2, -0.9, 1.4], 'rpy': [0.9, 0.0, 0.9], 'resolution': [200, 200]}
+env = DIYGym(Configuration.from_dict('from_the_readme', tree), num_envs=B, device='cuda:0')
+for _ in range(30): env.sim.step(env._all_slots, torch.zeros((B, env.layout.act_dim), device='cuda:0'))
+for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
+    cam = env.receptors[rec].addons[name]; cam.observe(); rgb, depth, seg = cam._buffers
+    for label, args in (('rgb+depth', (rgb, depth, None)), ('depth only', (None, depth, None))):
+        for diag in os.environ.get('DIAGS', '0').split(','):
+            os.environ['DG_RENDER_DIAG'] = diag
+            ms = t(lambda: env.sim.render(cam.camera_index, *args))
+            nbytes = B * 200 * 200 * (16 if args[0] is not None else 4)
+            print('%-10s %-10s diag %s: pose+render %.3f ms -> %.0f GB/s of image writes' % (name, label, diag, ms, nbytes / ms / 1e6), flush=True)
+
+# candidate counters per stage (diagnostic)
+import ctypes
+lib = env.sim.lib
+lib.dg_debug_render_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]
+buf = (ctypes.c_uint64 * 16)()
+os.environ['DG_RENDER_DIAG'] = '16'
+for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
+    cam = env.receptors[rec].addons[name]; rgb, depth, seg = cam._buffers
+    lib.dg_debug_render_counters(buf, 1)
+    env.sim.render(cam.camera_index, rgb, depth, None); torch.cuda.synchronize()
+    lib.dg_debug_render_counters(buf, 1)
+    c = list(buf); tiles = 13 * 25 * B
+    print(name, 'per tile: after sphere-cone [sphere box capsule hull] %s | band-0 list length %.1f | after separating face [box hull] %s | after frustum [box hull] %s | intersected [sphere box capsule hull] %s' % (
+        [round(x / tiles, 2) for x in c[0:4]], c[4] / B, [round(c[5] / tiles, 2), round(c[7] / tiles, 2)], [round(c[9] / tiles, 2), round(c[11] / tiles, 2)], [round(x / tiles, 2) for x in c[12:16]]))
+    print('   depth background fraction %.4f' % float((depth <= -99.9).float().mean()))

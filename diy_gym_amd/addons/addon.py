@@ -28,10 +28,10 @@ class AddonFactory:
     class _Registry:
         def __init__(self):
             from .controllers import AdmittanceController, InverseKinematicsController, JointController, ExternalForce
-            from .sensors import Camera, JointStateSensor, ObjectStateSensor
+            from .sensors import Camera, ForceTorqueSensor, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
             from .misc import DynamicsRandomizer, Respawn, SpawnMultiple
-            from .unsupported import ForceTorqueSensor, StuckJointCost, DrawCoords, VisualRandomizer
+            from .unsupported import StuckJointCost, DrawCoords, VisualRandomizer
             # same 17 keys as reference addon.py:36-54
             self.addons = {
                 'ik_controller': InverseKinematicsController,

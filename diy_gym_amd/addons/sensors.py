@@ -107,6 +107,47 @@ class ObjectStateSensor(Addon):
         return obs
 
 
+class ForceTorqueSensor(Addon):
+    """Reaction wrench across one joint of the parent model: ``force`` and ``torque`` (reference:
+    diy_gym/addons/sensors/force_torque_sensor.py:8-23 -- ``enableJointForceTorqueSensor`` + ``getJointState()[2]``).
+
+    What is reported [R: Bullet's joint feedback, ``I^A a + Z^A`` of the child link in its own frame]: the force and
+    the torque the PARENT side exerts on the CHILD side through the joint -- gravity, inertial loads and the contact
+    forces acting on the child side all show -- expressed in the child link's inertial frame, torque about its
+    origin.  Computed in the output phase by Newton-Euler over the child side (the rigid cluster of URDF links behind
+    the joint plus every moving link hanging off it), with the accelerations of the step's LAST substep,
+    ``(v_end - v_start) / h``, and that substep's contact impulses.  ``frame`` names the joint (fixed or movable); it
+    is required: the reference's default of -1 makes ``getJointState`` fail."""
+    def __init__(self, parent, config):
+        super().__init__(parent, config)
+        if 'frame' not in config:
+            raise ValueError("force_torque_sensor needs a 'frame' (the reference's default, joint -1, is rejected by pybullet)")
+        self.uid = parent.uid
+        self.frame_id = parent.get_frame_id(config.get('frame'))
+        if self.frame_id < 0:
+            raise ValueError('force_torque_sensor: model %r has no joint %r' % (parent.name, config.get('frame')))
+        box = lambda: spaces.Box(-10, 10, shape=(3, ), dtype='float32')
+        self.observation_space = spaces.Dict(OrderedDict(force=box(), torque=box()))
+
+    def compile(self, builder):
+        if self.uid in builder.aliases:
+            raise NotImplementedError('force_torque_sensor on an attached child model')
+        flat = self.parent.flat
+        cl = flat.ft_cluster(self.frame_id)
+        m, c, I = cl['rigid']
+        whole = self.parent.robot.joints[self.frame_id].movable
+        shapes = builder.shapes_of(self.uid, cl['urdf_links'], cl['moving'])
+        moving = [builder.global_link(self.uid, d) for d in cl['moving']]
+        self.op = builder.add_op(K.OP_OBS_FT, 'obs', body=self.uid, frame=self.frame_id, flags=K.FT_WHOLE_LINK if whole else 0,
+                                 ilist=[len(moving)] + moving + [len(shapes)] + shapes,
+                                 flist=[m, c[0], c[1], c[2], I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]], io_dim=6,
+                                 state_dim=builder.prev_velocity_slots(self.uid))
+
+    def observe(self):
+        off = self.op.io_off
+        return OrderedDict(force=self.env._obs_view(off, 3), torque=self.env._obs_view(off + 3, 3))
+
+
 class Camera(Addon):
     """RGB (+ depth, default ON; + segmentation) from a pinhole camera attached to a model frame or fixed in
     the world (reference: diy_gym/addons/sensors/camera.py:26-98).  Same config keys and defaults

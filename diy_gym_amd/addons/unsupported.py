@@ -11,8 +11,6 @@ def _stub(name, why):
     return type(name, (Addon, ), {'__init__': __init__, '__doc__': why})
 
 
-ForceTorqueSensor = _stub('force_torque_sensor', 'Bullet reports the pre-solver articulated-body wrench I^A a + Z^A across the joint in the link frame; the usual mount '
-                          'is a fixed joint, which this backend merges into its parent link at load (SURVEY 8(f) N1)')
 StuckJointCost = _stub('stuck_joint_cost', 'the reference implementation raises NameError on first use '
                        '(stuck_joint_cost.py:16-21); there is no behaviour to match')
 DrawCoords = _stub('draw_coords', 'GUI-only debug drawing')

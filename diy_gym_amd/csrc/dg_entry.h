@@ -45,6 +45,7 @@ DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
   for (int b = 0; b < sc.nb; b++) {
     if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
     if ((m++ & 1) != parity) continue;
+    if (sc.substeps == 1) save_prev_velocities(ln, b);  // the early substep is the step's last one
     ln.template dynamics_chain<6>(b, none);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV]; for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
   }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
     DG_WAVE_STAMP(0); __syncthreads();  // B0: every pose is in LDS
     if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1, diag);
     DG_WAVE_STAMP(1); __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0);
+    for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0, k == sc.substeps - 1);
     ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
     DG_WAVE_STAMP(2); __syncthreads();  // B4
     // its arm's joint-state observations (state reads only; the main wave skips them)
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
   // observations of the envs that were reset; a wavefront without one has nothing to refresh (its rows are current)
   if (obs && (mask == nullptr || __any(doit))) {
     for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
-    run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr);
+    run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_ALL, -1,
+                   doit ? (sc.hot_start > 0 ? 0 : 1) : 2);
   }
 }
 
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt,
   for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
-                 (valid && term_flag) ? term_flag + e : nullptr);
+                 (valid && term_flag) ? term_flag + e : nullptr, OUT_ALL, -1, 1 /* no contact list outside a step */);
 }
 
 template <int LANES>

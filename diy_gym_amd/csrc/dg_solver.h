@@ -859,7 +859,8 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   }
 #pragma unroll
   for (int i = 0; i < NS; i++) if (i * SL + sl < nt) blk[(unsigned)(sc.dv_base + i * SL) * W + (lane_off >> 2)] = dv[i];  // lane_off is in bytes
-  // motor impulses feed the applied-torque readout
+  // contact impulses back into their rows (force/torque sensor), motor impulses for the applied-torque readout
+  if (sl == 0) for (int c = 0; c < ncont; c++) { _Pragma("unroll") for (int d = 0; d < 3; d++) blk[(unsigned)(r0 + (3 * c + d) * rs + 2 * nt + 1) * W + colq] = acc[(3 * c + d) * EPW]; }
   for (uint64_t m = rows.motors; m; m &= m - 1) {
     const int gl = __ffsll((long long)m) - 1; int col, mo, jg, base, nv; float lm; rows.get(gl, col, mo, jg, base, nv, lm);
     blk[(unsigned)(mo + MR_ACC) * W + colq] = acc[(3 * maxc + gl) * EPW];
@@ -1120,6 +1121,11 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
   }
 #pragma unroll
   for (int i = 0; i < RN; i++) if (i < n) { W(dvo + i) = rdv[i]; W(mo0 + i * MR_STRIDE + MR_ACC) = racc[i]; }
+  if (cmax > 0 && half == 0) {  // solved contact impulses back into their rows (the force/torque sensor reads them)
+    const int rs = sc.crow_tail + 3;
+#pragma unroll
+    for (int c = 0; c < CM; c++) if (c < ncont) { _Pragma("unroll") for (int d = 0; d < 3; d++) W(sc.tr_off + (3 * c + d) * rs + sc.crow_tail + 1) = cacc[3 * c + d]; }
+  }
   if (half == 0) W(split_slots(sc)) = (float)iters_done;  // for the diagnostics column, read by the main wave after the barrier
 }
 
@@ -1144,6 +1150,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   // ops; positions have not changed since the poses of the step's start were computed
   const bool early = PAR && sc.early_dyn && index == 0;
   if (primary) {
+  if (index == sc.substeps - 1 && !early) for (int b = 0; b < sc.nb; b++) if (b != hb) save_prev_velocities(ln, b);
   if (!early) for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
@@ -1361,8 +1368,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
 
 // the helper wave's side of one substep
 template <int LANES>
-DGD void helper_substep(const Lane<LANES>& ln, bool early) {
+DGD void helper_substep(const Lane<LANES>& ln, bool early, bool last) {
   const DevScene& sc = ln.sc; const int hb = sc.helper_body; Prof<false> none;
+  if (last && !early) save_prev_velocities(ln, hb);
   if (!early) ln.kinematics(hb);
   __syncthreads();  // B1
   if (!early) {
@@ -1799,6 +1807,7 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
       ln.Sset(so + n, damp);
     }
   }
+  for (int b = 0; b < sc.nb; b++) save_prev_velocities(ln, b);  // force/torque sensors: no acceleration across a reset
   ln.Sset(DG_ST_EPISODE, (float)(episode + 1ull));
 }
 
@@ -1810,6 +1819,97 @@ DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
   return norm(pb - pa);
 }
 
+// ---- force_torque_sensor (force_torque_sensor.py:14-23) ----------------------------------------------------------
+// The body's generalised velocity at the start of the step's last substep, kept in the addon state of the first sensor
+// on the body (joint rates in link order, then base linvel3 angvel3 when floating).
+template <int LANES>
+DGD void save_prev_velocities(const Lane<LANES>& ln, int b) {
+  cip B = ln.bi(b); const int po = B[DG_BI_PREV_OFF]; if (po < 0) return;
+  const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+  for (int i = 0; i < n; i++) ln.Sset(po + i, ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_QD));
+  if (!ln.fixed(b)) for (int k = 0; k < 6; k++) ln.Sset(po + n + k, ln.S(B[DG_BI_STATE_OFF] + DG_BS_LINVEL + k));
+}
+struct LinkMotion { M3 R; V3 p, w, v, al, a; };
+// world pose, velocity and (last substep's) acceleration of link gl (-1: base) of body b; POSE must be current
+template <int LANES>
+DGD void link_motion(const Lane<LANES>& ln, int b, int gl, LinkMotion& o) {
+  const DevScene& sc = ln.sc; cip B = ln.bi(b); const int po = B[DG_BI_PREV_OFF], first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS]; const float ih = 1.0f / sc.h;
+  ln.link_world(b, -1, o.R, o.p); o.w = o.v = o.al = o.a = v3(0.f, 0.f, 0.f);
+  if (!ln.fixed(b)) {
+    const int so = B[DG_BI_STATE_OFF];
+    o.v = v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)); o.w = v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2));
+    o.a = (o.v - v3(ln.S(po + n), ln.S(po + n + 1), ln.S(po + n + 2))) * ih; o.al = (o.w - v3(ln.S(po + n + 3), ln.S(po + n + 4), ln.S(po + n + 5))) * ih;
+  }
+  if (gl < 0) return;
+  unsigned long long path = 0ull; for (int k = gl; k >= 0; k = ln.li(k)[DG_LI_PARENT]) path |= 1ull << (k - first);
+  for (int k = first; k <= gl; k++) {  // ancestors have smaller indices: the path in increasing order
+    if (!((path >> (k - first)) & 1ull)) continue;
+    M3 Rk; V3 pk; ln.link_world(b, k, Rk, pk); cfp f = ln.lf(k);
+    const float qd = ln.S(ln.li(k)[DG_LI_STATE_OFF] + DG_LS_QD), qdd = (qd - ln.S(po + (k - first))) * ih;
+    const V3 ax = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2])), r = pk - o.p;
+    const V3 a1 = o.a + cross(o.al, r) + cross(o.w, cross(o.w, r)), v1 = o.v + cross(o.w, r);
+    if (ln.li(k)[DG_LI_TYPE] == 0) { o.al = o.al + ax * qdd + cross(o.w, ax * qd); o.a = a1; o.v = v1; o.w = o.w + ax * qd; }
+    else { o.a = a1 + ax * qdd + cross(o.w, ax * qd) * 2.0f; o.v = v1 + ax * qd; }
+    o.R = Rk; o.p = pk;
+  }
+}
+// Newton-Euler for one rigid part moving with a link: force and torque (about ps) needed for its motion, gravity taken off
+template <int LANES>
+DGD void ft_add_part(const Lane<LANES>& ln, const LinkMotion& m, float mass, V3 c, const Sym3& Ic, V3 ps, V3& F, V3& T) {
+  const V3 rc = mul(m.R, c), pc = m.p + rc;
+  const V3 ac = m.a + cross(m.al, rc) + cross(m.w, cross(m.w, rc));
+  const V3 f = (ac - v3(ln.sc.gx, ln.sc.gy, ln.sc.gz)) * mass;
+  // R Ic R^T applied to a vector: R (Ic (R^T x))
+  const V3 nt = mul(m.R, mul(Ic, tmul(m.R, m.al))) + cross(m.w, mul(m.R, mul(Ic, tmul(m.R, m.w))));
+  F = F + f; T = T + nt + cross(pc - ps, f);
+}
+// Reaction wrench across the joint of frame OI_FRAME: what the parent side exerts on the child side, in the child
+// link's inertial frame, torque about its origin.  with_contacts: the last substep's contact list and solved impulses
+// are in the workspace (step kernels; the reset kernel for the envs it stepped).
+template <int LANES>
+DGD void ft_wrench(const Lane<LANES>& ln, cip oi, bool with_contacts, float* out6) {
+  const DevScene& sc = ln.sc; const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME];
+  cip il = sc.IL + oi[DG_OI_ILIST]; cfp fl = sc.FL + oi[DG_OI_FLIST]; cfp ff = sc.FF + fr * DG_FF_STRIDE;
+  const int ga = sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
+  LinkMotion ma; link_motion(ln, b, ga, ma);
+  const Q4 qo = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
+  const M3 Rs = mul(ma.R, qmat(qo)); const V3 ps = ma.p + mul(ma.R, v3(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2]));
+  V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
+  if (oi[DG_OI_FLAGS] & DG_FT_WHOLE_LINK) { float m; V3 c; Sym3 Ic; ln.link_inertia(ga, m, c, Ic); ft_add_part(ln, ma, m, c, Ic, ps, F, T); }
+  else if (fl[0] > 0.f) {
+    const float ms = ga >= 0 ? ln.mass_scale(ga) : 1.0f; const Sym3 Ic = {fl[4] * ms, fl[5] * ms, fl[6] * ms, fl[7] * ms, fl[8] * ms, fl[9] * ms};
+    ft_add_part(ln, ma, fl[0] * ms, v3(fl[1], fl[2], fl[3]), Ic, ps, F, T);
+  }
+  const int nm = il[0];
+  for (int k = 0; k < nm; k++) {
+    const int gl = il[1 + k]; float m; V3 c; Sym3 Ic; ln.link_inertia(gl, m, c, Ic);
+    LinkMotion mk; link_motion(ln, b, gl, mk); ft_add_part(ln, mk, m, c, Ic, ps, F, T);
+  }
+  if (with_contacts) {
+    const int nsh = il[1 + nm]; cip shp = il + 2 + nm; const int ncont = (int)ln.L(sc.cont_off), rs = sc.crow_tail + 3; const float ih = 1.0f / sc.h;
+    for (int c = 0; c < sc.max_contacts; c++) {
+      if (!__any(c < ncont)) break;
+      if (c >= ncont) continue;
+      const int co = sc.cont_off + 1 + c * CL_STRIDE, pair = (int)ln.L(co + CL_PAIR);
+      const int sa = sc.PI[pair * DG_PI_STRIDE + DG_PI_A], sb = sc.PI[pair * DG_PI_STRIDE + DG_PI_B];  // per-lane index: vector loads
+      bool inA = false, inB = false;
+      for (int q = 0; q < nsh; q++) { inA = inA || shp[q] == sa; inB = inB || shp[q] == sb; }
+      if (inA == inB) continue;
+      // the rows push the pair's first DYNAMIC side along +dir and the other along -dir (build_contact_rows): side A is
+      // that first side unless it is static
+      const int ba = sc.SI[sa * DG_SI_STRIDE + DG_SI_BODY]; const bool a_dyn = !(ln.fixed(ba) && ln.bi(ba)[DG_BI_N_LINKS] == 0);
+      const V3 n = ln.L3(co + CL_N), p = ln.L3(co + CL_P); V3 t1, t2; tangent_basis(n, t1, t2);
+      const int ro = sc.tr_off + 3 * c * rs + sc.crow_tail + 1;
+      const V3 imp = n * ln.L(ro) + t1 * ln.L(ro + rs) + t2 * ln.L(ro + 2 * rs);
+      (void)a_dyn;
+      const V3 f = imp * ((inA ? 1.0f : -1.0f) * ih);
+      F = F - f; T = T - cross(p - ps, f);
+    }
+  }
+  const V3 Fl = tmul(Rs, F), Tl = tmul(Rs, T);
+  out6[0] = Fl.x; out6[1] = Fl.y; out6[2] = Fl.z; out6[3] = Tl.x; out6[4] = Tl.y; out6[5] = Tl.z;
+}
+
 // observe / reward / terminal ops; POSE must be current for every body.
 // `part` lets the four wavefronts of the helper-wave kernel share the output phase (they write disjoint columns):
 //   OUT_ALL everything; OUT_JOINT_OF: the joint-state ops of body `pb` (they read nothing but the state);
@@ -1817,8 +1917,10 @@ DGD float reach_dist(const Lane<LANES>& ln, cip oi) {
 //   OUT_REW_TERM: reward and terminal ops and the collapsed reward / terminal.
 enum { OUT_ALL = 0, OUT_JOINT_OF, OUT_JOINT_NOT_OF, OUT_OBS_REST, OUT_REW_TERM };
 template <int LANES>
+// ft_mode (force/torque sensor columns): 0 after a step -- the last substep's contacts count; 1 plain observe -- no
+// contact term; 2 leave them as they are (lanes a masked reset did not touch).
 DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag,
-                        int part = OUT_ALL, int pb = -1) {
+                        int part = OUT_ALL, int pb = -1, int ft_mode = 0) {
   const DevScene& sc = ln.sc; float rsum = 0.f; uint64_t groups = 0ull; bool any = false;
   // a reach_target addon emits a reward op and a terminal op on the same pair of frames: the distance is computed once
   int rk_a = -2, rk_b = -2, rk_c = -2, rk_d = -2; float rk_dist = 0.f;
@@ -1873,6 +1975,8 @@ DGD void run_output_ops(const Lane<LANES>& ln, float* obs, float* rew, uint8_t* 
       }
     } else if (code == DG_OP_OBS_ADDON_STATE) {
       if (obs) for (int k = 0; k < oi[DG_OI_N]; k++) obs[io + k] = ln.S(sc.addon_off + oi[DG_OI_STATE_OFF] + k);
+    } else if (code == DG_OP_OBS_FT) {
+      if (ft_mode != 2) { float w6[6]; ft_wrench(ln, oi, ft_mode == 0, w6); if (obs) { _Pragma("unroll") for (int k = 0; k < 6; k++) obs[io + k] = w6[k]; } }
     } else if (code == DG_OP_REW_REACH) { float r = -reach(oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
     else if (code == DG_OP_REW_ELECTRICITY) {
       cip B = ln.bi(oi[DG_OI_BODY]); float acc = 0.f;

@@ -252,6 +252,23 @@ class SceneBuilder:
                              T_parent_cam, float(fov), float(near), float(far)))
         return len(self.cameras) - 1
 
+    def prev_velocity_slots(self, body):
+        """Addon-state floats a force_torque_sensor on ``body`` needs for the body's velocities at the start of the last
+        substep; 0 when an earlier sensor on the same body already owns them."""
+        b = self.resolve(body)[0]
+        if any(row[K.OI_CODE] == K.OP_OBS_FT and row[K.OI_BODY] == b for row, _ in self.ops):
+            return 0
+        flat = self.bodies[b][0]
+        return len(flat.links) + (0 if flat.fixed_base else 6)
+
+    def shapes_of(self, body, urdf_links, moving_dofs):
+        """Global indices of the shapes of ``body`` that belong to the given pybullet link indices or sit on one of the
+        given moving links (local DoF indices)."""
+        b = self.resolve(body)[0]
+        base = sum(len(x[0].shapes) for x in self.bodies[:b])
+        flat = self.bodies[b][0]
+        return [base + i for i, sh in enumerate(flat.shapes) if sh.urdf_link in urdf_links or sh.link in moving_dofs]
+
     def link_base(self, body):
         return sum(len(b[0].links) for b in self.bodies[:body])
 
@@ -331,7 +348,7 @@ class SceneBuilder:
             frozen = (not dynamic) and b not in respawned
             flags = (K.BODY_FIXED if flat.fixed_base else 0) | (K.BODY_FROZEN if frozen else 0)
             # frozen bodies have no per-env state at all: their pose is the load pose in the body table
-            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off, -1])
+            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off, -1, -1])
             if not frozen:
                 state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
             I = flat.base_inertia
@@ -422,6 +439,9 @@ class SceneBuilder:
                         raise ValueError('two dynamics_randomizer addons on the same joint')
                     link_i[gl_][K.LI_MASS_SCALE] = base + k
                 body_i[row[K.OI_BODY]][K.BI_DYN_OFF] = base + len(links)
+            if row[K.OI_CODE] == K.OP_OBS_FT and row[K.OI_STATE_OFF] >= 0:  # the sensor that owns its body's saved velocities
+                if body_i[row[K.OI_BODY]][K.BI_PREV_OFF] < 0:
+                    body_i[row[K.OI_BODY]][K.BI_PREV_OFF] = addon_off + row[K.OI_STATE_OFF]
 
         # candidate collision pairs: different bodies, at least one of them able to move,
         # and a narrow-phase routine exists for the pair (no box-box)

@@ -318,15 +318,21 @@ class FlatBody:
         self.links = []
         self.frames = []  # index == pybullet joint/link index
         self.shapes = []
+        # what every URDF link contributed and where, keyed by the pybullet index of its parent joint: (anchor moving
+        # link, mass, COM in the anchor frame, inertia about that COM in anchor axes) -- the force/torque sensor needs
+        # the rigid cluster on the child side of one joint, which the merged links no longer show
+        self.parts = {}
         # accumulators: link index (-1 base) -> [m, h(3), I_O(3x3)]
         acc = {-1: [0.0, np.zeros(3), np.zeros((3, 3))]}
 
-        def add_inertia(anchor, T_anchor_link, link, mass, inertia):
+        def add_inertia(anchor, T_anchor_link, link, mass, inertia, joint_index=None):
             if mass <= 0.0:
                 return
             Tc = T_anchor_link * Transform(link.inertial_origin.R, link.inertial_origin.p * s)
             c = Tc.p
             Ic = Tc.R @ (inertia * (s * s)) @ Tc.R.T
+            if joint_index is not None:
+                self.parts[joint_index] = (anchor, float(mass), c.copy(), Ic.copy())
             a = acc[anchor]
             a[0] += mass
             a[1] += mass * c
@@ -388,7 +394,7 @@ class FlatBody:
             else:
                 anchor, T_anchor_child = p_anchor, T_joint
             anchor_of[j.child] = (anchor, T_anchor_child)
-            add_inertia(anchor, T_anchor_child, child, child.mass, child.inertia)
+            add_inertia(anchor, T_anchor_child, child, child.mass, child.inertia, j.index)
             add_shapes(anchor, T_anchor_child, child, j.index)
             T_com = T_anchor_child * Transform(child.inertial_origin.R, child.inertial_origin.p * s)
             self.frames.append(FlatFrame(j.name, anchor, T_anchor_child, T_com))
@@ -468,6 +474,50 @@ class FlatBody:
                 self.frames.append(FlatFrame(fr.name, fr.link + link_off, fr.T, fr.T_com))
         self.frames.append(FlatFrame(child.base_name + '__attached_base', anchor, T_attach, T_attach * child.T_base_report))
         return link_off, frame_off, len(self.frames) - 1
+
+    def ft_cluster(self, joint_index):
+        """Everything on the CHILD side of URDF joint ``joint_index`` (pybullet numbering), for the force/torque sensor:
+
+        ``anchor``   moving link the joint's child link is part of (-1 = base),
+        ``rigid``    (mass, com, inertia about the com) of the URDF links rigidly attached on the child side -- the
+                     joint's child link and everything reached from it through fixed joints only -- in the anchor
+                     link's frame; the whole moving link when the joint itself is the link's (movable) joint,
+        ``moving``   moving links hanging off that rigid cluster (their whole subtrees are on the child side too),
+        ``urdf_links`` pybullet link indices of the rigid cluster (shapes owned by them belong to the child side).
+        """
+        robot = self.robot
+        if not 0 <= joint_index < len(robot.joints):
+            raise ValueError('joint index %d out of range' % joint_index)
+        if joint_index >= len(self.frames) or len(self.frames) != len(robot.joints):
+            raise NotImplementedError('force/torque sensing across the joints of an attached child model')
+        J = robot.joints[joint_index]
+        anchor = self.frames[joint_index].link
+        cluster, moving = [], []
+        stack = [J]
+        while stack:
+            j = stack.pop()
+            cluster.append(j.index)
+            for cj in robot.links[j.child].child_joints:
+                if cj.movable:
+                    moving.append(cj.q_index)
+                else:
+                    stack.append(cj)
+        m, h, IO = 0.0, np.zeros(3), np.zeros((3, 3))
+        for ji in cluster:
+            if ji in self.parts:
+                _, pm, pc, pI = self.parts[ji]
+                m += pm; h += pm * pc; IO += pI + pm * (np.dot(pc, pc) * np.eye(3) - np.outer(pc, pc))
+        if m > 0.0:
+            c = h / m
+            Ic = IO - m * (np.dot(c, c) * np.eye(3) - np.outer(c, c))
+        else:
+            c, Ic = np.zeros(3), np.zeros((3, 3))
+        # every moving link below: the listed ones and their descendants
+        sub = set(moving)
+        for i, fl in enumerate(self.links):
+            if fl.parent in sub:
+                sub.add(i)
+        return dict(anchor=anchor, rigid=(m, c, 0.5 * (Ic + Ic.T)), moving=sorted(sub), urdf_links=sorted(cluster))
 
     @property
     def num_dofs(self):

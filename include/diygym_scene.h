@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 6
+#define DG_VERSION 7
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -105,6 +105,8 @@ enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_E
                             it has no per-env state (DG_BI_STATE_OFF = -1) and its pose is DG_BF_INIT_* */
 enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF,
        DG_BI_DYN_OFF /* state offset of the body's per-env angular damping (dynamics_randomizer), or -1: DG_HF_ANG_DAMPING */,
+       DG_BI_PREV_OFF /* state offset where the body's generalised velocity at the START of a step's last substep is kept
+                         (joint rates in link order, then base linvel3 angvel3 if floating) for force_torque_sensor, or -1 */,
        DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)
@@ -199,6 +201,10 @@ enum {
   DG_OP_OBS_JOINT_STATE = 32,  /* joint_state_sensor.py:47-57 */
   DG_OP_OBS_OBJECT_STATE = 33, /* object_state_sensor.py:49-75 */
   DG_OP_OBS_ADDON_STATE = 34,  /* drone_pilot.py:39-40 */
+  DG_OP_OBS_FT = 35,           /* force_torque_sensor.py:14-23: reaction wrench across joint FRAME, 6 columns (force, torque).
+                                  ILIST = [n_moving, moving links on the child side..., n_shapes, shapes on the child side...],
+                                  FLIST = mass com[3] inertia[6] of the rigid cluster on the child side (anchor link frame),
+                                  FLAGS & DG_FT_WHOLE_LINK: the joint is the anchor link's own (movable) joint */
   /* reward phase */
   DG_OP_REW_REACH = 48,        /* reach_target.py:32-33 */
   DG_OP_REW_ELECTRICITY = 49,  /* electricity_cost.py:15-18 */
@@ -236,6 +242,8 @@ enum { DG_JC_POSITION = 0, DG_JC_VELOCITY = 1, DG_JC_TORQUE = 2 };
 /* DG_OP_OBS_OBJECT_STATE flags */
 #define DG_OS_ROTATION 1
 #define DG_OS_VELOCITY 2
+/* DG_OP_OBS_FT flags */
+#define DG_FT_WHOLE_LINK 1
 /* DG_OP_RESPAWN flags */
 #define DG_RS_ONCE 1
 

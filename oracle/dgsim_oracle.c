@@ -244,6 +244,8 @@ typedef struct {
   v3 n; /* world normal, from B towards A */
   double dist; /* signed distance (negative = penetration) */
   double mu;
+  int shape_a, shape_b;      /* global shape indices */
+  v3 t1, t2; double imp[3];  /* friction directions and the solved impulses (normal, t1, t2), filled in after the sweeps */
 } Contact;
 
 struct dgo_world {
@@ -253,6 +255,7 @@ struct dgo_world {
   double* state; /* [B][state_dim] */
   double* mcfg;  /* [nl][DG_MC_STRIDE] */
   int* last_contacts; int* last_iters;
+  Contact* last_cs; /* [B][MAXC]: contacts and impulses of each env's most recent substep (force_torque_sensor) */
 };
 
 /* per-body workspace for one env */
@@ -312,6 +315,7 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
   w->mcfg = (double*)calloc((size_t)(w->sc.nl > 0 ? w->sc.nl : 1) * DG_MC_STRIDE, sizeof(double));
   w->last_contacts = (int*)calloc(num_envs, sizeof(int));
   w->last_iters = (int*)calloc(num_envs, sizeof(int));
+  w->last_cs = (Contact*)calloc((size_t)num_envs * MAXC, sizeof(Contact));
   /* every movable joint starts with pybullet's default velocity motor: target 0,
    * kd 1, kp 0, fixed impulse budget per substep [R] */
   for (int l = 0; l < w->sc.nl; l++) {
@@ -345,7 +349,7 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
 }
 void dgo_destroy(dgo_world* w) {
   if (!w) return;
-  free(w->sc.I); free(w->sc.F); free(w->state); free(w->mcfg); free(w->last_contacts); free(w->last_iters); free(w);
+  free(w->sc.I); free(w->sc.F); free(w->state); free(w->mcfg); free(w->last_contacts); free(w->last_iters); free(w->last_cs); free(w);
 }
 int32_t dgo_state_dim(const dgo_world* w) { return w->sc.state_dim; }
 double* dgo_state(dgo_world* w) { return w->state; }
@@ -529,11 +533,11 @@ static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, double
 }
 
 /* ----------------------------------------------------------- collision */
-typedef struct { int type, body, llink /* local */, glink; m3 R; v3 p; m3 Rl; v3 pl; /* frame the hull points live in */ const double* prm; double mu; int poff, npts; } WShape;
+typedef struct { int id, type, body, llink /* local */, glink; m3 R; v3 p; m3 Rl; v3 pl; /* frame the hull points live in */ const double* prm; double mu; int poff, npts; } WShape;
 
 static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
   const int32_t* si = s->SI + sh * DG_SI_STRIDE; const double* sf = s->SF + sh * DG_SF_STRIDE;
-  o->type = si[DG_SI_TYPE]; o->body = si[DG_SI_BODY]; o->glink = si[DG_SI_LINK];
+  o->id = sh; o->type = si[DG_SI_TYPE]; o->body = si[DG_SI_BODY]; o->glink = si[DG_SI_LINK];
   const BodyWS* ws = &wsb[o->body];
   o->llink = o->glink < 0 ? -1 : o->glink - ws->first;
   m3 Rl; v3 pl; link_world(ws, o->llink, &Rl, &pl);
@@ -546,7 +550,8 @@ static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
 static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, double dist) {
   if (*nc >= maxc) return;
   Contact* c = &cs[(*nc)++];
-  c->body_a = a->body; c->link_a = a->llink; c->body_b = b->body; c->link_b = b->llink;
+  c->body_a = a->body; c->link_a = a->llink; c->body_b = b->body; c->link_b = b->llink; c->shape_a = a->id; c->shape_b = b->id;
+  c->imp[0] = c->imp[1] = c->imp[2] = 0.0;
   c->p = vscale(vadd(pa, pb), 0.5); c->n = n; c->dist = dist; c->mu = a->mu * b->mu; /* Bullet combines friction by product [R] */
 }
 /* sphere (centre c, radius r) against box shape bx: returns 1 and contact data when dist < margin */
@@ -719,8 +724,14 @@ static int make_contact_row(const Scene* s, const double* st, BodyWS* wsb, const
 /* one substep of length h for env state st (Bullet btMultiBodyDynamicsWorld::
  * internalSingleStepSimulation order [R]: collide at the current poses, forward
  * dynamics, velocity update, constraint solve, position update) */
-static void substep(dgo_world* w, int env) {
+static void substep(dgo_world* w, int env, int last) {
   Scene* s = &w->sc; double* st = env_state(w, env); double h = s->h;
+  if (last) /* force_torque_sensor: generalised velocities at the start of the step's last substep */
+    for (int b = 0; b < s->nb; b++) {
+      const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; if (po < 0) continue;
+      for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) st[po + i] = st[link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF] + DG_LS_QD];
+      if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) st[po + bi[DG_BI_N_LINKS] + k] = st[bi[DG_BI_STATE_OFF] + DG_BS_LINVEL + k];
+    }
   BodyWS* wsb = (BodyWS*)malloc(sizeof(BodyWS) * (size_t)s->nb);
   Row* rows = (Row*)malloc(sizeof(Row) * MAXROWS); int nr = 0;
   Contact cs[MAXC];
@@ -791,13 +802,14 @@ static void substep(dgo_world* w, int env) {
     r->lo = 0; r->hi = 1e300; crow[k] = nr++;
   }
   (void)first_normal;
+  int frow[MAXC][2];
   for (int k = 0; k < nc; k++) {
+    frow[k][0] = frow[k][1] = -1; tangent_basis(cs[k].n, &cs[k].t1, &cs[k].t2);
     if (crow[k] < 0 || cs[k].mu <= 0) continue;
-    v3 t1, t2; tangent_basis(cs[k].n, &t1, &t2);
     for (int d = 0; d < 2; d++) {
       Row* r = &rows[nr];
-      if (!make_contact_row(s, st, wsb, &cs[k], d == 0 ? t1 : t2, r)) continue;
-      r->normal_row = crow[k]; r->mu = cs[k].mu; nr++;
+      if (!make_contact_row(s, st, wsb, &cs[k], d == 0 ? cs[k].t1 : cs[k].t2, r)) continue;
+      r->normal_row = crow[k]; r->mu = cs[k].mu; frow[k][d] = nr++;
     }
   }
   /* projected Gauss-Seidel with the residual early-out (pybullet solverResidualThreshold [R]) */
@@ -818,6 +830,11 @@ static void substep(dgo_world* w, int env) {
     if (maxres <= thr) { it++; break; }
   }
   w->last_iters[env] = it;
+  for (int k = 0; k < nc; k++) { /* solved impulses of this substep's contacts, for the force/torque sensor */
+    cs[k].imp[0] = crow[k] >= 0 ? rows[crow[k]].acc : 0.0;
+    cs[k].imp[1] = frow[k][0] >= 0 ? rows[frow[k][0]].acc : 0.0; cs[k].imp[2] = frow[k][1] >= 0 ? rows[frow[k][1]].acc : 0.0;
+    w->last_cs[(size_t)env * MAXC + k] = cs[k];
+  }
   for (int k = 0; k < nr; k++) if (rows[k].motor_link >= 0) st[link_i(s, rows[k].motor_link)[DG_LI_STATE_OFF] + DG_LS_APPLIED] = rows[k].acc / h;
   /* apply velocity changes, integrate positions (btMultiBody::stepPositionsMultiDof [R]) */
   double vmax = s->F[DG_HF_MAX_COORD_VEL];
@@ -1079,6 +1096,11 @@ static void run_reset_ops(dgo_world* w, int env) {
       }
     }
   }
+  for (int b = 0; b < s->nb; b++) { /* force_torque_sensor: no acceleration across a reset */
+    const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; if (po < 0) continue;
+    for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) st[po + i] = st[link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF] + DG_LS_QD];
+    if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) st[po + bi[DG_BI_N_LINKS] + k] = st[bi[DG_BI_STATE_OFF] + DG_BS_LINVEL + k];
+  }
   st[DG_ST_EPISODE] = (double)(episode + 1);
 }
 static double reach_dist(const Scene* s, const double* st, const int32_t* oi) { /* reach_target.py:21-30 */
@@ -1088,7 +1110,83 @@ static double reach_dist(const Scene* s, const double* st, const int32_t* oi) { 
   frame_state(s, st, oi[DG_OI_BODY], oi[DG_OI_FRAME], oi[DG_OI_FRAME] < 0, NULL, &b);
   return vnorm(vsub(b.p, a.p));
 }
-static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+/* ---- force_torque_sensor.py:14-23 -------------------------------------------------------------------------------
+ * Reaction wrench across the joint of frame `fr`: what the parent side exerts on the child side, by Newton-Euler in the
+ * world frame over the child side with the accelerations of the last substep, (v_end - v_start) / h, minus gravity and
+ * that substep's contact forces on the child side; reported in the child link's inertial frame, torque about its origin
+ * [R: Bullet's joint feedback is I^A a + Z^A of the child link in its own (inertial) frame]. */
+typedef struct { m3 R; v3 p, w, v, al, a; } LinkMotion;
+static void link_motion(const Scene* s, const double* st, int b, const BodyWS* ws, int lk /* local, -1 base */, LinkMotion* o) {
+  const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; double h = s->h;
+  o->R = ws->R0; o->p = ws->p0; o->w = o->v = o->al = o->a = V(0, 0, 0);
+  if (!ws->fixed) {
+    const double* bs = st + bi[DG_BI_STATE_OFF]; const double* pv = st + po + ws->n;
+    o->v = V(bs[DG_BS_LINVEL], bs[DG_BS_LINVEL + 1], bs[DG_BS_LINVEL + 2]); o->w = V(bs[DG_BS_ANGVEL], bs[DG_BS_ANGVEL + 1], bs[DG_BS_ANGVEL + 2]);
+    o->a = vscale(vsub(o->v, V(pv[0], pv[1], pv[2])), 1.0 / h); o->al = vscale(vsub(o->w, V(pv[3], pv[4], pv[5])), 1.0 / h);
+  }
+  int path[MAXL], np = 0; for (int k = lk; k >= 0; k = ws->parent[k]) path[np++] = k;
+  for (int t = np - 1; t >= 0; t--) {
+    int j = path[t]; int gl = ws->first + j; const double* lf = link_f(s, gl);
+    double qd = st[link_i(s, gl)[DG_LI_STATE_OFF] + DG_LS_QD], qdd = (qd - st[po + j]) / h;
+    v3 ax = mv(&ws->Rw[j], V(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2])), r = vsub(ws->pw[j], o->p);
+    v3 a1 = vadd(o->a, vadd(vcross(o->al, r), vcross(o->w, vcross(o->w, r)))), v1 = vadd(o->v, vcross(o->w, r));
+    if (link_i(s, gl)[DG_LI_TYPE] == 0) { o->al = vadd(o->al, vadd(vscale(ax, qdd), vcross(o->w, vscale(ax, qd)))); o->a = a1; o->v = v1; o->w = vadd(o->w, vscale(ax, qd)); }
+    else { o->a = vadd(a1, vadd(vscale(ax, qdd), vscale(vcross(o->w, vscale(ax, qd)), 2.0))); o->v = vadd(v1, vscale(ax, qd)); }
+    o->R = ws->Rw[j]; o->p = ws->pw[j];
+  }
+}
+static void ft_add_part(const Scene* s, const LinkMotion* m, double mass, v3 c, const m3* Ic, v3 ps, v3* F, v3* T) {
+  v3 rc = mv(&m->R, c), pc = vadd(m->p, rc);
+  v3 ac = vadd(m->a, vadd(vcross(m->al, rc), vcross(m->w, vcross(m->w, rc))));
+  v3 f = vscale(vsub(ac, s->g), mass);
+  m3 Rt; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[i][j] = m->R.m[j][i];
+  m3 t = mmul(&m->R, Ic), Iw = mmul(&t, &Rt);
+  v3 nt = vadd(mv(&Iw, m->al), vcross(m->w, mv(&Iw, m->w)));
+  *F = vadd(*F, f); *T = vadd(*T, vadd(nt, vcross(vsub(pc, ps), f)));
+}
+static void ft_wrench(dgo_world* w, int env, const int32_t* oi, int with_contacts, double* out6) {
+  Scene* s = &w->sc; const double* st = env_state(w, env); int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME];
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); body_kinematics(s, st, b, ws, NULL);
+  const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST]; const double* ff = s->FF + fr * DG_FF_STRIDE;
+  int ga = s->FI[fr * DG_FI_STRIDE + DG_FI_LINK], la = ga < 0 ? -1 : ga - ws->first;
+  LinkMotion ma; link_motion(s, st, b, ws, la, &ma);
+  qt qo = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]}; m3 Ro = qmat(qo);
+  m3 Rs = mmul(&ma.R, &Ro); v3 ps = vadd(ma.p, mv(&ma.R, V(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2])));
+  v3 F = V(0, 0, 0), T = V(0, 0, 0);
+  if (oi[DG_OI_FLAGS] & DG_FT_WHOLE_LINK) {
+    const double* lf = link_f(s, ga); double ms = link_mass_scale(s, st, ga); m3 Ic = msym6(lf + DG_LF_INERTIA);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
+    ft_add_part(s, &ma, lf[DG_LF_MASS] * ms, V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]), &Ic, ps, &F, &T);
+  } else if (fl[0] > 0.0) {
+    double ms = ga >= 0 ? link_mass_scale(s, st, ga) : 1.0; m3 Ic = msym6(fl + 4);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
+    ft_add_part(s, &ma, fl[0] * ms, V(fl[1], fl[2], fl[3]), &Ic, ps, &F, &T);
+  }
+  int nm = il[0];
+  for (int k = 0; k < nm; k++) {
+    int gl = il[1 + k]; const double* lf = link_f(s, gl); double ms = link_mass_scale(s, st, gl); m3 Ic = msym6(lf + DG_LF_INERTIA);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
+    LinkMotion mk; link_motion(s, st, b, ws, gl - ws->first, &mk);
+    ft_add_part(s, &mk, lf[DG_LF_MASS] * ms, V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]), &Ic, ps, &F, &T);
+  }
+  if (with_contacts) {
+    int nsh = il[1 + nm]; const int32_t* shp = il + 2 + nm;
+    for (int k = 0; k < w->last_contacts[env]; k++) {
+      const Contact* c = &w->last_cs[(size_t)env * MAXC + k]; int inA = 0, inB = 0;
+      for (int q = 0; q < nsh; q++) { if (shp[q] == c->shape_a) inA = 1; if (shp[q] == c->shape_b) inB = 1; }
+      if (inA == inB) continue;
+      /* the rows push side A along +dir and side B along -dir */
+      v3 f = vscale(vadd(vscale(c->n, c->imp[0]), vadd(vscale(c->t1, c->imp[1]), vscale(c->t2, c->imp[2]))), (inA ? 1.0 : -1.0) / s->h);
+      F = vsub(F, f); T = vsub(T, vcross(vsub(c->p, ps), f));
+    }
+  }
+  v3 Fl = mtv(&Rs, F), Tl = mtv(&Rs, T);
+  out6[0] = Fl.x; out6[1] = Fl.y; out6[2] = Fl.z; out6[3] = Tl.x; out6[4] = Tl.y; out6[5] = Tl.z;
+  free(ws);
+}
+/* ft_mode: 0 = after a step (the last substep's contacts count), 1 = plain observe (no contact term), 2 = leave the
+ * force/torque columns as they are (envs a masked reset did not touch) */
+static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag, int ft_mode) {
   Scene* s = &w->sc; const double* st = env_state(w, env);
   double rsum = 0; int gany[64]; memset(gany, 0, sizeof gany); int any = 0;
   for (int op = 0; op < s->nops; op++) {
@@ -1115,6 +1213,8 @@ static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint
       }
     } else if (code == DG_OP_OBS_ADDON_STATE) {
       for (int k = 0; k < oi[DG_OI_N]; k++) if (obs) obs[io + k] = st[s->addon_off + oi[DG_OI_STATE_OFF] + k];
+    } else if (code == DG_OP_OBS_FT) {
+      if (obs && ft_mode != 2) ft_wrench(w, env, oi, ft_mode == 0, obs + io);
     } else if (code == DG_OP_REW_REACH) { double r = -reach_dist(s, st, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
     else if (code == DG_OP_REW_ELECTRICITY) { /* electricity_cost.py:15-18 */
       const int32_t* bi = body_i(s, oi[DG_OI_BODY]); double acc = 0;
@@ -1141,18 +1241,22 @@ static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint
 
 static void sim_step(dgo_world* w, int env) {
   Scene* s = &w->sc; double* st = env_state(w, env);
-  for (int k = 0; k < s->substeps; k++) substep(w, env);
+  for (int k = 0; k < s->substeps; k++) substep(w, env, k == s->substeps - 1);
   /* external wrenches and joint torques last for one stepSimulation [R] */
   for (int b = 0; b < s->nb; b++) { if (body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue; double* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
   for (int l = 0; l < s->nl; l++) st[link_i(s, l)[DG_LI_STATE_OFF] + DG_LS_TORQUE] = 0.0;
 }
 
-int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+static int observe_all(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag, int ft_mode, const uint8_t* fresh) {
   Scene* s = &w->sc;
   for (int e = 0; e < w->B; e++)
     run_output_ops(w, e, obs ? obs + (size_t)e * s->obs_dim : NULL, rew ? rew + (size_t)e * s->rew_dim : NULL,
-                   term ? term + (size_t)e * s->term_dim : NULL, rew_sum ? rew_sum + e : NULL, term_flag ? term_flag + e : NULL);
+                   term ? term + (size_t)e * s->term_dim : NULL, rew_sum ? rew_sum + e : NULL, term_flag ? term_flag + e : NULL,
+                   (fresh && !fresh[e]) ? 2 : ft_mode);
   return 0;
+}
+int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+  return observe_all(w, obs, rew, term, rew_sum, term_flag, 1, NULL);
 }
 /* reference diy_gym.py:130-148 */
 int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
@@ -1164,7 +1268,7 @@ int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
     run_reset_ops(w, e);
     for (int k = 0; k < s->hot_start; k++) sim_step(w, e);
   }
-  if (obs) dgo_observe(w, obs, NULL, NULL, NULL, NULL);
+  if (obs) observe_all(w, obs, NULL, NULL, NULL, NULL, s->hot_start > 0 ? 0 : 1, mask);
   return 0;
 }
 /* reference diy_gym.py:187-209 */
@@ -1188,7 +1292,7 @@ int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* 
     st[DG_ST_STEP] += 1.0;
     sim_step(w, e);
   }
-  return dgo_observe(w, obs, rew, term, rew_sum, term_flag);
+  return observe_all(w, obs, rew, term, rew_sum, term_flag, 0, NULL);
 }
 
 /* --------------------------------------------------------------- camera */

@@ -204,9 +204,9 @@ def test_flat_env_step_with_timer_auto_reset_matches_oracle_over_three_episodes(
     for step in range(1, 24):
         act = lo + (hi - lo) * torch.rand((B, A), generator=gen)
         act_dev = act.to('cuda:0')
-        mem = torch.cuda.memory_allocated()
+        allocs = torch.cuda.memory_stats()['allocation.all.allocated']
         g_obs, g_rew, g_term, g_info = gpu.step(act_dev)
-        assert torch.cuda.memory_allocated() == mem   # the step (and its auto-reset) allocated nothing on the device
+        assert torch.cuda.memory_stats()['allocation.all.allocated'] == allocs   # the step (and its auto-reset) made no device allocation
         c_obs, c_rew, c_term, _ = cpu.step(act)
         # zero-copy: the returned tensors ARE the backend's persistent buffers, and a step allocates nothing
         assert g_obs.data_ptr() == gpu.sim.obs.data_ptr() and g_rew.data_ptr() == gpu.sim.rew_sum.data_ptr()

@@ -446,3 +446,83 @@ def test_dynamics_randomizer_needs_a_movable_joint(tmp_path):
     cfg.write_text('ball:\n  model: sphere2.urdf\n  rand: {addon: dynamics_randomizer}\n')
     with pytest.raises(ValueError, match='no movable joint'):
         DIYGym(str(cfg), num_envs=1, backend_factory=OracleBackend)
+
+
+# ---------------------------------------------------------------- force_torque_sensor (reference force_torque_sensor.py:14-23)
+def _pendulum_tool(tmp_path, extra='', B=1):
+    cfg = tmp_path / 'pend_tool.yaml'
+    cfg.write_text('render: no\n%spend:\n  model: %s\n  xyz: [0, 0, 0]\n  wrist: {addon: force_torque_sensor, frame: mount}\n'
+                   '  shoulder: {addon: force_torque_sensor, frame: hinge}\n' % (extra, os.path.join(G, 'urdf', 'pendulum_tool.urdf')))
+    return DIYGym(str(cfg), num_envs=B, backend_factory=OracleBackend, engine=NODAMP)
+
+
+def test_force_torque_sensor_static_load_is_weight_at_the_right_lever_arm(tmp_path):
+    env = _pendulum_tool(tmp_path)
+    qo, q = link_q(env, 0, 0), 0.8
+    st = env.sim.get_state(); st[0, qo] = q; env.sim.set_state(st)
+    env.sim.set_motor_cfg(np.array([[0.0, 1.0, 1e4]]))  # a strong velocity motor holds the joint
+    for _ in range(30):
+        env.sim.step(0)
+    obs = env.observe()['pend']
+    g, c, s_ = 9.81, np.cos(q), np.sin(q)
+    Rt = np.array([[c, 0, -s_], [0, 1, 0], [s_, 0, c]])  # world -> link axes (rotation by q about y, transposed)
+    # across the FIXED joint: the parent holds the tool's weight; about the tool's own COM that force has no lever arm
+    assert np.allclose(obs['wrist']['force'], Rt @ [0, 0, 0.3 * g], atol=2e-3)
+    assert np.allclose(obs['wrist']['torque'], 0.0, atol=2e-4)
+    # across the hinge: rod + tool (1.3 kg); torque about the ROD's COM = tool weight x 0.6 m lever, about the y axis
+    assert np.allclose(obs['shoulder']['force'], Rt @ [0, 0, 1.3 * g], atol=5e-3)
+    assert np.allclose(obs['shoulder']['torque'], [0, 0.6 * s_ * 0.3 * g, 0], atol=2e-3)
+    # ... whose component along the hinge axis, taken about the hinge, is what the motor reports as its effort
+    lever = 0.5 * s_ * 1.0 * g + 1.1 * s_ * 0.3 * g
+    assert abs(abs(env.sim.get_state()[0, qo + K.LS_APPLIED]) - lever) < 2e-2
+
+
+def test_force_torque_sensor_swinging_pendulum_matches_newton_euler_closed_form(tmp_path):
+    env = _pendulum_tool(tmp_path)
+    qo = link_q(env, 0, 0)
+    st = env.sim.get_state(); st[0, qo] = 1.2; env.sim.set_state(st)
+    env.sim.set_motor_cfg(np.array([[0.0, 1.0, 0.0]]))  # motor off: free swing
+    for _ in range(60):
+        env.sim.step(0)
+    obs = env.observe(_refresh=False)['pend']
+    q, qd = env.sim.get_state()[0, qo:qo + 2]
+    g = 9.81
+    # hinge-axis inertia and gravity torque of rod + tool about the hinge
+    I_h = (0.02 + 1.0 * 0.5**2) + (0.001 + 0.3 * 1.1**2)
+    qdd = -(1.0 * 0.5 + 0.3 * 1.1) * g * np.sin(q) / I_h
+    def part(m, L):  # force needed to move a point mass on the rod at distance L (world x, z), minus gravity
+        t = np.array([-np.cos(q), 0, np.sin(q)]) * L   # d(position)/dq for position = (-L sin q, 0, 1 - L cos q)
+        n = np.array([np.sin(q), 0, np.cos(q)]) * L    # -d2(position)/dq2 ... centripetal direction
+        return m * (t * qdd + n * qd * qd + np.array([0, 0, g]))
+    F_world = part(1.0, 0.5) + part(0.3, 1.1)
+    c, s_ = np.cos(q), np.sin(q)
+    Rt = np.array([[c, 0, -s_], [0, 1, 0], [s_, 0, c]])
+    assert np.allclose(obs['shoulder']['force'], Rt @ F_world, rtol=0, atol=0.02 * np.linalg.norm(F_world))
+    assert np.allclose(obs['wrist']['force'], Rt @ part(0.3, 1.1), rtol=0, atol=0.02 * np.linalg.norm(F_world))
+
+
+def test_force_torque_sensor_sees_contact_forces_on_the_child_side(tmp_path):
+    # the pendulum leans on a box top with its tool sphere (motor off): the wrist then carries the tool's weight MINUS the support
+    box = ('prop:\n  model: %s\n  use_fixed_base: yes\n  xyz: [-0.7, 0, 0.0]\n' % os.path.join(G, 'urdf', 'ft_prop.urdf'))
+    (tmp_path / 'x').mkdir()
+    env = _pendulum_tool(tmp_path, extra=box)
+    qo = link_q(env, 1, 0)
+    st = env.sim.get_state(); st[0, qo] = 0.95; env.sim.set_state(st)
+    env.sim.set_motor_cfg(np.array([[0.0, 1.0, 0.0]]))
+    for _ in range(400):
+        env.sim.step(0)
+    s = env.sim.get_state()[0]
+    q, qd = s[qo], s[qo + 1]
+    assert abs(qd) < 2e-3 and env.sim.contacts(0) == 1          # at rest on the prop
+    obs = env.observe(_refresh=False)['pend']
+    g = 9.81
+    # moment balance about the hinge: N x_contact = (m_rod x_rod + m_tool x_tool) g with a vertical support force
+    # (the sphere touches the horizontal top face; friction keeps it from sliding but carries no load at rest)
+    x_rod, x_tool = 0.5 * np.sin(q), 1.1 * np.sin(q)
+    N = (1.0 * x_rod + 0.3 * x_tool) * g / x_tool
+    c, s_ = np.cos(q), np.sin(q)
+    Rt = np.array([[c, 0, -s_], [0, 1, 0], [s_, 0, c]])
+    F = Rt.T @ np.asarray(obs['wrist']['force'], dtype=np.float64)[0]
+    assert abs(F[2] - (0.3 * g - N)) < 0.03 * N and abs(F[0]) < 0.03 * N
+    Fh = Rt.T @ np.asarray(obs['shoulder']['force'], dtype=np.float64)[0]
+    assert abs(Fh[2] - (1.3 * g - N)) < 0.03 * N

@@ -23,6 +23,7 @@ CONFIGS = {
     'touching': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching.yaml'),
     'touching_ik': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching_ik.yaml'),
     'randomized': os.path.join(ROOT, 'tests', 'golden', 'ur_randomized.yaml'),
+    'touching_ft': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching_ft.yaml'),
 }
 
 
@@ -90,7 +91,10 @@ def test_initial_state_and_reset_match():
         # after the constructor's reset (respawn + rest joints + 1 hot-start step).  Velocities of resting
         # bodies are determined to the solver's residual threshold (sqrt(1e-7) = 3e-4 m/s); efforts are O(100 N m)
         assert np.allclose(gpu.sim.get_state(), cpu.sim.get_state(), rtol=1e-4, atol=5e-4), name
-        assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 5e-4, name
+        ft = _ft_columns(gpu)   # (force/torque readings are O(1000) N in the touching scene: relative to the vector's size)
+        keep = torch.ones(gpu.sim.obs.shape[1], dtype=torch.bool); keep[ft] = False
+        assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs()[:, keep].max()) < 5e-4, name
+        assert _ft_error(gpu.sim.obs.cpu(), cpu.sim.obs, ft) < 2e-3, name
 
 
 def test_ur_high_5_joint_variant_100_steps():
@@ -319,6 +323,107 @@ def test_dynamics_randomizer_three_episodes():
     assert len(scales) == 3 and not np.allclose(scales[0], scales[1]) and not np.allclose(scales[1], scales[2])   # re-drawn every episode
     ms = scales[0][:, :6]
     assert ms.min() > 0 and len(np.unique(np.round(ms[:, 0], 6))) >= 35                                       # every env its own draw (a few sit at the clamp)
+
+
+def _ft_columns(env):
+    cols = []
+    for r in env.receptors.values():
+        for a in r.addons.values():
+            if type(a).__name__ == 'ForceTorqueSensor':
+                cols += list(range(a.op.io_off, a.op.io_off + 6))
+    return cols
+
+
+def _ft_error(g, c, ft):
+    """Largest difference of a force (torque) reading relative to the size of that force (torque) VECTOR: a wrench of
+    1 000 N along x is not known to better than ~1e-5 of that in fp32, whatever its other components are."""
+    worst = 0.0
+    for k in range(0, len(ft), 3):
+        cols = ft[k:k + 3]
+        worst = max(worst, float(((g[:, cols] - c[:, cols]).abs().max(1).values / (1.0 + c[:, cols].norm(dim=1))).max()))
+    return worst
+
+
+@pytest.mark.parametrize('env_var,threshold,tol', [(None, 1e-13, 5e-3), ('DG_NO_HELPER_WAVE', 1e-13, 5e-3), ('DG_NO_SPLIT_CONTACTS', 1e-13, 5e-3),
+                                                   (None, 1e-7, 3e-2)])
+def test_force_torque_sensor_on_arms_in_contact(env_var, threshold, tol):
+    """force_torque_sensor (reference force_torque_sensor.py:14-23) across a fixed flange joint and across movable joints
+    of two UR5s whose forearms touch: Newton-Euler over the child side with the last substep's accelerations, minus
+    that substep's contact forces.  Wrenches are O(100 N m) and carry the solver's residual like motor efforts do, so
+    they are compared relative to the size of the force / torque vector: 5e-3 with the solver run to convergence (threshold 1e-13), 3e-2 at
+    pybullet's 1e-7 early-out, where the accelerations (velocity differences over h = 1/480 s) amplify the residual.
+    Three solver paths: arm-per-half-wavefront sweeps (contact impulses written back from registers), the
+    single-wavefront kernel, the streamed single-wave sweeps.
+    Blind to: Bullet reports I^A a + Z^A of its own solver state [R]; ours is the Newton-Euler equivalent."""
+    if env_var:
+        os.environ[env_var] = '1'
+    try:
+        gpu, cpu = make_pair('touching_ft', 37, residual_threshold=threshold)
+    finally:
+        if env_var:
+            del os.environ[env_var]
+    ft = _ft_columns(gpu)
+    assert len(ft) == 18
+    gen = torch.Generator().manual_seed(0)
+    lo, hi = action_bounds(gpu)
+    d = gpu.sim.enable_diagnostics()
+    touched = 0
+    for step in range(25):
+        act = (lo + (hi - lo) * torch.rand((37, lo.numel()), generator=gen)) * 0.3
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        g, c = gpu.sim.obs.cpu(), cpu.sim.obs
+        keep = torch.ones(g.shape[1], dtype=torch.bool); keep[ft] = False
+        assert float((g - c).abs()[:, keep].max()) < 3e-3, step
+        assert _ft_error(g, c, ft) < tol, (step, _ft_error(g, c, ft))
+        touched += int((d[:, 0] > 0).sum())
+    assert touched > 100                                   # contacts were there while the sensors were read
+    assert float(cpu.sim.obs[:, ft].abs().max()) > 5.0     # and the wrenches are not trivially zero
+
+
+def test_force_torque_sensor_pendulum_on_a_prop(tmp_path):
+    # the known-answer scene of tests/test_oracle_kat.py (pendulum leaning on a block through its tool sphere), batched
+    G = os.path.join(ROOT, 'tests', 'golden', 'urdf')
+    cfg = tmp_path / 'pend_tool.yaml'
+    cfg.write_text('render: no\nprop:\n  model: %s\n  use_fixed_base: yes\n  xyz: [-0.7, 0, 0.0]\n'
+                   'pend:\n  model: %s\n  xyz: [0, 0, 0]\n  wrist: {addon: force_torque_sensor, frame: mount}\n'
+                   '  shoulder: {addon: force_torque_sensor, frame: hinge}\n  q: {addon: joint_state_sensor}\n'
+                   % (os.path.join(G, 'ft_prop.urdf'), os.path.join(G, 'pendulum_tool.urdf')))
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    B = 33
+    eng = dict(residual_threshold=1e-13)  # converged sweeps: the impact and resting impulses are then well defined
+    gpu = DIYGym(str(cfg), num_envs=B, device='cuda:0', engine=eng); cpu = DIYGym(str(cfg), num_envs=B, backend_factory=OracleBackend, engine=eng)
+    L = gpu.layout
+    qo = L.link_state_off[0]
+    # the tool starts 2..20 cm above the block top (z = 0.25) and drops onto it
+    st = cpu.sim.get_state(); st[:, qo] = np.linspace(0.9, 1.1, B); cpu.sim.set_state(st); gpu.sim.set_state(st)
+    cfg_m = np.array([[0.0, 1.0, 0.0]]); gpu.sim.set_motor_cfg(cfg_m); cpu.sim.set_motor_cfg(cfg_m)   # motor off: it swings, lands, rests
+    d = gpu.sim.enable_diagnostics()
+    ft = _ft_columns(gpu)
+    for step in range(300):
+        gpu.sim.step(0); cpu.sim.step(0)
+        if step % 20 == 19:
+            # while they swing freely the readings are unique (the landing itself is an impulse spike whose substep can
+            # differ between fp32 and fp64, and is skipped)
+            free = [e for e in range(B) if cpu.sim.contacts(e) == 0 and int(d[e, 0]) == 0]
+            if free:
+                g, c = gpu.sim.obs.cpu()[free], cpu.sim.obs[free]
+                assert _ft_error(g, c, ft) < 5e-3 and float((g[:, :2] - c[:, :2]).abs().max()) < 2e-3, step   # columns: q, qd | shoulder 6 | wrist 6
+    assert [cpu.sim.contacts(e) for e in range(B)] == [1] * B and d[:, 0].tolist() == [1] * B     # everyone rests on the block
+    # At rest the ONE joint is held by THREE contact rows (normal + two friction directions): how the support splits
+    # between them is not unique (the oracle's own envs differ), but its moment about the hinge is -- it balances
+    # gravity.  Recover the contact force from the wrist reading (weight of the tool minus the reading) and compare
+    # that moment; it must also equal the gravity moment of rod + tool.
+    gq = gpu.sim.obs.cpu().numpy().astype(np.float64); cq = cpu.sim.obs.numpy().astype(np.float64)
+    def contact_moment(o):
+        q = o[:, 0]; c_, s_ = np.cos(q), np.sin(q)
+        fx = c_ * o[:, 8] + s_ * o[:, 10]; fz = -s_ * o[:, 8] + c_ * o[:, 10]        # wrist force, link axes -> world (rotation by q about y)
+        cx, cz = -fx, 0.3 * 9.81 - fz                                               # force of the block on the tool
+        px, pz = -1.1 * s_, -1.1 * c_ - 0.05                                        # contact point from the hinge
+        return pz * cx - px * cz, q
+    mg, q = contact_moment(gq); mc, _ = contact_moment(cq)
+    gravity = -(1.0 * 0.5 + 0.3 * 1.1) * 9.81 * np.sin(q)
+    assert np.abs(mg - mc).max() < 2e-2 * np.abs(gravity).max() and np.abs(mg + gravity).max() < 3e-2 * np.abs(gravity).max()
 
 
 def test_frame_state_getter_matches_oracle():

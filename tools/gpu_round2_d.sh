@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout -k 10 60 tools/micro/valu_issue3 2>&1 | tee gpurun_out/r2_micro_valu3.log
+timeout -k 10 120 python tools/gpu_ft_debug.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2_ft_debug.log

@@ -47,7 +47,8 @@ WORKLOADS = {
     'r2d2_maze': ('examples/r2d2_maze/r2d2_maze.yaml', 'r2d2_maze: R2D2 stand-in (mass 50, 4 velocity-driven wheels) among 119 fixed walls, tools/generate_maze.py --seed 7'),
     'from_the_readme': ('examples/from_the_readme/from_the_readme.yaml', 'from_the_readme.yaml: Jaco + table + 1:10 R2D2; the 200x200 gripper camera (rgb + depth) is rendered inside every timed step'),
     'marbles': ('tests/golden/basic_env_nocam.yaml', 'reference test fixture basic_env.yaml minus the camera: 3 marbles + plane + external_force'),
-    'ur5_gripper': ('tests/golden/ur5_gripper.yaml', 'UR5 with the two-finger gripper asset (12-DoF tree), joint_controller'),
+    'ur5_gripper': ('tests/golden/ur5_gripper.yaml', 'UR5 with the two-finger gripper asset (12-DoF tree) next to a ground plane, joint_controller: random targets lay the arm on the ground (contact-rich)'),
+    'ur5_child_gripper': ('tests/golden/ur5_child_gripper.yaml', 'UR5 with the robotiq_2f gripper attached as a child model (12-DoF tree, no ground): the contact-free arm + gripper case'),
 }
 DEFAULT_ENVS = {'r2d2_maze': 4096, 'from_the_readme': 1024}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec

@@ -111,7 +111,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   const int32_t* BI = I + I[DG_H_OFF_BODY_I]; const int32_t* LI = I + I[DG_H_OFF_LINK_I]; const int32_t* OI = I + I[DG_H_OFF_OP_I];
   // ---- LDS plan (slots per lane)
   std::vector<int32_t> plan((size_t)nb * PLB_STRIDE + (size_t)nl * PLL_STRIDE);
-  plan.reserve(plan.size() + (size_t)I[DG_H_N_PAIRS] + 1);  // pair descriptors are appended below; PLB / PLL must stay valid
+  plan.reserve(plan.size() + (size_t)I[DG_H_N_PAIRS] + 4 * (size_t)I[DG_H_N_GROUPS] + 1);  // pair descriptors are appended below; PLB / PLL must stay valid
   int32_t* PLB = plan.data(); int32_t* PLL = plan.data() + (size_t)nb * PLB_STRIDE;
   int slot = 0, nvmax = 0, nmax = 0; bool any_float = false;
   for (int b = 0; b < nb; b++) {
@@ -221,6 +221,22 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       const int sa = swap ? sB : sA, sb = swap ? sA : sB, ta = swap ? tB : tA, tb = swap ? tA : tB;
       plan.push_back(sa | (sb << 12) | (ta << 24) | (tb << 26) | ((swap ? 1 : 0) << 28));
     } }
+  // group descriptors (broad phase), device-only: centre and reach of the group's static shape when that shape is frozen in
+  // the world -- [x y z reach], reach = bound of the moving body + margin + extent of the shape; reach < 0: the narrow
+  // phase works the group's bounds out from the tables (a moving partner)
+  const size_t gd_off = plan.size();
+  { const int32_t* GIh = I + I[DG_H_OFF_GROUP_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I]; const double* SFh = F + I[DG_H_OFF_SHAPE_F]; const double* BFh = F + I[DG_H_OFF_BODY_F];
+    for (int g = 0; g < I[DG_H_N_GROUPS]; g++) {
+      const int32_t* gi = GIh + g * DG_GI_STRIDE; const int ss = gi[DG_GI_STATIC_SHAPE]; float d[4] = {0.f, 0.f, 0.f, -1.f};
+      if (ss >= 0 && (SIh[ss * DG_SI_STRIDE + DG_SI_FLAGS] & DG_SHAPE_WORLD)) {
+        const double* sf = SFh + ss * DG_SF_STRIDE; const int st = SIh[ss * DG_SI_STRIDE + DG_SI_TYPE];
+        const float p0 = (float)sf[DG_SF_PARAMS], p1 = (float)sf[DG_SF_PARAMS + 1], p2 = (float)sf[DG_SF_PARAMS + 2];
+        const float ext = st == DG_SHAPE_SPHERE ? p0 : st == DG_SHAPE_BOX ? sqrtf(p0 * p0 + p1 * p1 + p2 * p2) : p0 + p1;
+        d[0] = (float)sf[DG_SF_POS]; d[1] = (float)sf[DG_SF_POS + 1]; d[2] = (float)sf[DG_SF_POS + 2];
+        d[3] = (float)BFh[gi[DG_GI_BODY_A] * DG_BF_STRIDE + DG_BF_BOUND] + (float)F[DG_HF_CONTACT_MARGIN] + ext;
+      }
+      for (int k = 0; k < 4; k++) { int32_t bits; memcpy(&bits, &d[k], 4); plan.push_back(bits); }
+    } }
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
   // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
   cip dI = (cip)w->d_blob_i; cfp dF = (cfp)w->d_blob_f;
@@ -229,7 +245,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.GI = dI + I[DG_H_OFF_GROUP_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
-  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off;
+  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off);
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
@@ -277,6 +293,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       if (dense && nt == PLB[sc.reg_body[0] * PLB_STRIDE + PLB_NV] + PLB[sc.reg_body[1] * PLB_STRIDE + PLB_NV] && !getenv("DG_NO_SPLIT_CONTACTS")) sc.split_pgs = 2;
     }
   }
+  if (!w->par && getenv("DG_NO_REG_ROWS")) sc.split_pgs = -1;  // ablation: the sliced sweeps keep their rows in LDS
   // a fourth wavefront for the second half of the pair table, if its contact list still fits LDS
   sc.coll_split = 0; sc.cont2_off = 0;
   if (sc.coll_wave && lanes == 64 && I[DG_H_N_PAIRS] >= 8 && !getenv("DG_NO_COLLIDE_SPLIT")) {

@@ -17,7 +17,7 @@
 namespace dg {
 
 constexpr int L = DG_LANES;
-constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 16 || DG_LANES == 8 || DG_LANES == 4 || DG_LANES == -16);
+constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 32 || DG_LANES == 16 || DG_LANES == 8 || DG_LANES == 4 || DG_LANES == -16);
 
 void DGL(l_step)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, float* gws);
 hipError_t DGL(l_prepare_step)(int lds);

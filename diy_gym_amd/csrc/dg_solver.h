@@ -129,19 +129,39 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
   // moving body); skipped as a whole when the bounding spheres are apart in every lane of the wave
   int cached_body = -1; V3 cpos = v3(0.f, 0.f, 0.f);
   const int lane = threadIdx.x & 63;
+  // Group descriptors TBL at a time in lane tables (one vector load per table, v_readlane per group): with one
+  // wavefront per SIMD a chain of dependent scalar loads per group -- group -> shape -> parameters -- was a third of a
+  // maze step's narrow phase (120 groups, almost all of them culled).
+  float gx = 0.f, gy = 0.f, gz = 0.f, gr = -1.f; int gfirst = 0, gcount = 0, gba = 0;
+  auto rlf = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
   for (int g = 0; g < sc.ngroups; g++) {
-    cip gi = sc.GI + g * DG_GI_STRIDE; const int ba = gi[DG_GI_BODY_A], bb = gi[DG_GI_BODY_B], ss = gi[DG_GI_STATIC_SHAPE];
-    if (gi[DG_GI_FIRST] >= pair_hi || gi[DG_GI_FIRST] + gi[DG_GI_COUNT] <= pair_lo) continue;
+    cip gi = sc.GI + g * DG_GI_STRIDE;
+    int g_first, g_count, ba; float ox, oy, oz, orr;
+    if constexpr (TBL > 0) {
+      if ((g & (TBL - 1)) == 0) {  // (only the first TBL lanes are guaranteed active)
+        const int gg = min(g + lane, sc.ngroups - 1); cfp gd = sc.GD + 4 * gg; cip gj = sc.GI + gg * DG_GI_STRIDE;
+        gx = gd[0]; gy = gd[1]; gz = gd[2]; gr = gd[3]; gfirst = gj[DG_GI_FIRST]; gcount = gj[DG_GI_COUNT]; gba = gj[DG_GI_BODY_A];
+      }
+      const int l = g & (TBL - 1);
+      g_first = __builtin_amdgcn_readlane(gfirst, l); g_count = __builtin_amdgcn_readlane(gcount, l); ba = __builtin_amdgcn_readlane(gba, l);
+      ox = rlf(gx, l); oy = rlf(gy, l); oz = rlf(gz, l); orr = rlf(gr, l);
+    } else { g_first = gi[DG_GI_FIRST]; g_count = gi[DG_GI_COUNT]; ba = gi[DG_GI_BODY_A]; cfp gd = sc.GD + 4 * g; ox = gd[0]; oy = gd[1]; oz = gd[2]; orr = gd[3]; }
+    if (g_first >= pair_hi || g_first + g_count <= pair_lo) continue;
     if (ba != cached_body) { cpos = ln.base_pos(ba); cached_body = ba; }
-    V3 other; float reach = sc.BF[ba * DG_BF_STRIDE + DG_BF_BOUND] + margin;
-    if (ss >= 0) {
-      cip si = sc.SI + ss * DG_SI_STRIDE; cfp sf = sc.SF + ss * DG_SF_STRIDE; const int st = si[DG_SI_TYPE];
-      reach += st == DG_SHAPE_SPHERE ? sf[DG_SF_PARAMS] : st == DG_SHAPE_BOX ? sqrtf(sf[DG_SF_PARAMS] * sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1] * sf[DG_SF_PARAMS + 1] + sf[DG_SF_PARAMS + 2] * sf[DG_SF_PARAMS + 2]) : sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1];
-      if (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) other = v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]);
-      else { WShape w; shape_world(ln, ss, w); other = w.p; }
-    } else { other = ln.base_pos(bb); reach += sc.BF[bb * DG_BF_STRIDE + DG_BF_BOUND]; }
-    { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
-  const int first = max(gi[DG_GI_FIRST], pair_lo), count = min(gi[DG_GI_FIRST] + gi[DG_GI_COUNT], pair_hi) - first;  // this wave's share
+    if (orr >= 0.f) {  // frozen static partner: everything needed is in the descriptor
+      const V3 dc = cpos - v3(ox, oy, oz); if (!__any(dot(dc, dc) < orr * orr)) continue;
+    } else {
+      const int bb = gi[DG_GI_BODY_B], ss = gi[DG_GI_STATIC_SHAPE];
+      V3 other; float reach = sc.BF[ba * DG_BF_STRIDE + DG_BF_BOUND] + margin;
+      if (ss >= 0) {
+        cip si = sc.SI + ss * DG_SI_STRIDE; cfp sf = sc.SF + ss * DG_SF_STRIDE; const int st = si[DG_SI_TYPE];
+        reach += st == DG_SHAPE_SPHERE ? sf[DG_SF_PARAMS] : st == DG_SHAPE_BOX ? sqrtf(sf[DG_SF_PARAMS] * sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1] * sf[DG_SF_PARAMS + 1] + sf[DG_SF_PARAMS + 2] * sf[DG_SF_PARAMS + 2]) : sf[DG_SF_PARAMS] + sf[DG_SF_PARAMS + 1];
+        if (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) other = v3(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2]);
+        else { WShape w; shape_world(ln, ss, w); other = w.p; }
+      } else { other = ln.base_pos(bb); reach += sc.BF[bb * DG_BF_STRIDE + DG_BF_BOUND]; }
+      { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
+    }
+  const int first = max(g_first, pair_lo), count = min(g_first + g_count, pair_hi) - first;  // this wave's share
   constexpr int CH = TBL > 0 ? TBL : 1;
   for (int c0 = 0; c0 < count; c0 += CH) {
     const int n = min(CH, count - c0);
@@ -710,6 +730,137 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
   return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
 }
 
+// ---- the same sliced sweeps with EVERY row in registers ------------------------------------------------------------
+// A row of the LDS version costs ~340-470 cycles (seven LDS reads, address arithmetic, an impulse store that the next
+// reads queue behind, per-row branches) for ~25 instructions of arithmetic, and a step of a contact scene is 10 000+
+// strictly sequential rows.  Here the rows a lane needs -- its slice of every M^-1 column, of every contact row's J and R,
+// right-hand sides, reciprocal diagonals, limits -- are loaded ONCE per substep, the accumulated impulses live in
+// registers, and a sweep is straight-line code over NLR links and CB contacts (absent rows have zero limits / zero data,
+// so they are no-ops without a branch; only the joint-limit block, rarely active, is guarded per row).  Preconditions
+// (checked by the caller): NTB / SL <= 2 entries per lane, at most NLR links, at most CB contacts in any env of the wave.
+// (A hybrid for bigger scenes -- impulses in registers, contact rows re-read from LDS -- was tried for from_the_readme,
+// 18 links / 25 contacts: 450+ live registers, slower than the LDS sweeps; not kept.)
+template <int LANES, int NTB, int NLR, int CB, bool PROF>
+DGD int pgs_dense_sliced_regs(const Lane<LANES>& ln, int ncont_primary, uint64_t limit_rows, Prof<PROF>& prof) {
+  constexpr int SL = 64 / LANES, LOG = SL == 16 ? 4 : SL == 8 ? 3 : SL == 4 ? 2 : 1, NS = NTB / SL;
+  static_assert(NTB % SL == 0 && NS >= 1 && NS <= 2, "register-resident sweeps hold at most two entries of a vector per lane");
+  const DevScene& sc = ln.sc; const int nt = sc.nt, rs = sc.crow_tail + 3;
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
+  const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
+  const int envq = blockIdx.x * LANES + q; const bool validq = envq < sc.num_envs; const int eq = validq ? envq : sc.num_envs - 1;
+  const Lane<LANES> lq(sc, ln.mt, ln.lds - lane + q, ln.st - ln.env + eq, eq, validq);
+  const int ncont = __shfl(ncont_primary, q);
+  float* const ls = lq.lds + sl * LANES;  // this lane's slice: slot (o + i SL) through ls is DoF i SL + sl of vector o
+  auto group_sum = [&](float x) { return SL == 16 ? group_sum16(x) : SL == 8 ? group_sum8(x) : SL == 4 ? group_sum4(x) : group_sum2(x); };
+  float dv[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) dv[i] = 0.f;
+  // ---- per link: slice of the M^-1 column, diagonal, motor and limit rows
+  const LinkRows<LANES, true> rows(lq);
+  float lR[NLR][NS], ldg[NLR], lrd[NLR], mb[NLR], mlim[NLR], macc[NLR], lb[2][NLR], la[2][NLR]; int lji[NLR]; bool lmine[NLR];
+#pragma unroll
+  for (int gl = 0; gl < NLR; gl++) {
+    const bool have = gl < sc.nl; int col, mo, j, base, nv; float lim; rows.get(have ? gl : 0, col, mo, j, base, nv, lim);
+#pragma unroll
+    for (int i = 0; i < NS; i++) { const int k = i * SL + sl; const float v = ls[(col - base + i * SL) * LANES]; lR[gl][i] = (have && k >= base && k < base + nv) ? v : 0.f; }
+    const float dg = lq.L(col + j - base);
+    ldg[gl] = have ? dg : 1.f; lrd[gl] = have ? frcp(dg) : 0.f;
+    mb[gl] = have ? lq.L(mo + MR_B) : 0.f; mlim[gl] = (have && ((rows.motors >> gl) & 1ull)) ? lim : 0.f; macc[gl] = 0.f;
+    lb[0][gl] = lq.L(mo + MR_LO_B); la[0][gl] = have ? lq.L(mo + MR_LO_ACC) : -1.f; lb[1][gl] = lq.L(mo + MR_HI_B); la[1][gl] = have ? lq.L(mo + MR_HI_ACC) : -1.f;
+    lji[gl] = j >> LOG; lmine[gl] = (j & (SL - 1)) == sl;
+  }
+  // DoF j of the velocity change, known to every lane of the group
+  auto dv_of = [&](int gl) { const float mine = (NS == 1 || lji[gl] == 0) ? dv[0] : dv[NS - 1]; return group_sum(lmine[gl] ? mine : 0.f); };
+  // ---- contact rows: J pre-divided by the diagonal (delta = b' - J' . dv), R, right-hand side, diagonal, impulse
+  float cJ[3 * CB][NS], cR[3 * CB][NS], cb[3 * CB], cdg[3 * CB], cacc[3 * CB], cmu[CB];
+#pragma unroll
+  for (int c = 0; c < CB; c++) {
+    const bool has = c < ncont; const int cc = has ? c : 0;
+    cmu[c] = has ? lq.L(sc.cont_off + 1 + cc * CL_STRIDE + CL_MU) : 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int r = 3 * c + d, ro = sc.tr_off + (3 * cc + d) * rs;
+      const float dg = lq.L(ro + 2 * nt + 2), rd = (has && dg > 1e-18f) ? frcp(dg) : 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        const bool in = has && (i * SL + sl) < nt;
+        const float jj = ls[(ro + i * SL) * LANES], rr = ls[(ro + nt + i * SL) * LANES];
+        cJ[r][i] = in ? jj * rd : 0.f; cR[r][i] = in ? rr : 0.f;
+      }
+      cb[r] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdg[r] = has ? dg : 0.f; cacc[r] = 0.f;
+    }
+  }
+  float maxres = 0.f; bool live = validq; int iters_done = 0;
+  auto contact_row = [&](int r, float lo, float hi, float lv) {
+    float jp = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; i++) jp += cJ[r][i] * dv[i];
+    const float nacc = fminf(fmaxf(cacc[r] + (cb[r] - group_sum(jp)), lo), hi);
+    const float delta = (nacc - cacc[r]) * lv; cacc[r] += delta;
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += cR[r][i] * delta;
+    const float res = delta * cdg[r]; maxres = fmaxf(maxres, res * res);
+  };
+  for (int it = 0; it < sc.iters; it++) {
+    maxres = 0.f; const float lv = live ? 1.f : 0.f;
+#pragma unroll
+    for (int gl = 0; gl < NLR; gl++) {  // motor rows, link by link (oracle order); a link without a motor has limit 0
+      const float nacc = __builtin_amdgcn_fmed3f(macc[gl] + (mb[gl] - dv_of(gl)) * lrd[gl], -mlim[gl], mlim[gl]);
+      const float delta = (nacc - macc[gl]) * lv; macc[gl] += delta;
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += lR[gl][i] * delta;
+      const float res = delta * ldg[gl]; maxres = fmaxf(maxres, res * res);
+    }
+    if (limit_rows) {  // joint-limit rows: only those some lane has active (the flag cannot change during the sweeps)
+#pragma unroll
+      for (int gl = 0; gl < NLR; gl++) {
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+          if (!((limit_rows >> (2 * gl + side)) & 1ull)) continue;
+          const float sg = side == 0 ? 1.f : -1.f; const bool act = la[side][gl] >= 0.f;
+          const float nacc = fmaxf(la[side][gl] + (lb[side][gl] - sg * dv_of(gl)) * lrd[gl], 0.f);
+          const float delta = act ? (nacc - la[side][gl]) * lv : 0.f; la[side][gl] += delta;
+          const float sd = sg * delta;
+#pragma unroll
+          for (int i = 0; i < NS; i++) dv[i] += lR[gl][i] * sd;
+          const float res = delta * ldg[gl]; maxres = fmaxf(maxres, res * res);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) contact_row(3 * c, 0.f, 3.0e38f, lv);  // contact normals, then the friction pairs
+#pragma unroll
+    for (int c = 0; c < CB; c++) { const float lim = cmu[c] * cacc[3 * c]; contact_row(3 * c + 1, -lim, lim, lv); contact_row(3 * c + 2, -lim, lim, lv); }
+    if (live) iters_done = it + 1;
+    live = live && !(maxres <= thr);
+    if (!__any(live)) break;
+  }
+  prof.stamp(PS_PGS_CONTACT);
+#pragma unroll
+  for (int i = 0; i < NS; i++) if (i * SL + sl < nt) ls[(sc.dv_base + i * SL) * LANES] = dv[i];
+  if (sl == 0) {  // one lane per env: motor impulses for the applied-torque readout, contact impulses for the force/torque sensor
+#pragma unroll
+    for (int gl = 0; gl < NLR; gl++) if (gl < sc.nl && ((rows.motors >> gl) & 1ull)) { int col, mo, j, base, nv; float lim; rows.get(gl, col, mo, j, base, nv, lim); lq.L(mo + MR_ACC) = macc[gl]; }
+#pragma unroll
+    for (int c = 0; c < CB; c++) if (c < ncont) { _Pragma("unroll") for (int d = 0; d < 3; d++) lq.L(sc.tr_off + (3 * c + d) * rs + 2 * nt + 1) = cacc[3 * c + d]; }
+  }
+  return __shfl(iters_done, (lane << LOG) & 63);  // primary lane e reads the count of env e's group
+}
+// picks the register-resident instantiation that covers the scene's links and this wavefront's contacts; false: none does
+template <int LANES, int NTB, bool PROF>
+DGD bool pgs_sliced_regs_dispatch(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof, int& iters_done) {
+  constexpr int SL = 64 / LANES;
+  if constexpr (NTB % SL != 0 || NTB / SL > 2 || NTB / SL < 1) return false;
+  else {
+    const int nl = ln.sc.nl;
+    if (nl > 16 || wave_max_cont > 12 || (limit_rows >> 32) != 0ull) return false;
+#define DG_REGS(NLR, CB) do { iters_done = pgs_dense_sliced_regs<LANES, NTB, NLR, CB, PROF>(ln, ncont, limit_rows, prof); return true; } while (0)
+    if (nl <= 8) { if (wave_max_cont <= 4) DG_REGS(8, 4); if (wave_max_cont <= 8) DG_REGS(8, 8); DG_REGS(8, 12); }
+    if (wave_max_cont <= 4) DG_REGS(16, 4); if (wave_max_cont <= 8) DG_REGS(16, 8); DG_REGS(16, 12);
+#undef DG_REGS
+  }
+}
+
 // ---- sliced sweeps for the global-workspace mode (LANES == -16) ---------------------------------------------------
 // Rows stream from the L2-resident scratch buffer, whose latency is ~10x that of LDS: loads run D rows ahead of the
 // solves, which requires the loop to be free of global stores (vmcnt orders loads behind them) -- so the accumulated
@@ -1218,12 +1369,13 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     limit_rows = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(limit_rows >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)limit_rows);
   }
   if (SLICED && all_dense) {
+    const bool try_regs = sc.split_pgs != -1;  // (dg_world_create: DG_NO_REG_ROWS sets -1 for ablation / tests)
     if constexpr (SLICED && LANES == 4) {  // 16 lanes per env: the padded DoF count is 16 or 32
-      if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
-      else iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      if (sc.nt <= 16) { if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof); }
+      else if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
     } else if constexpr (SLICED && LANES > 0) {
-      if (sc.nt <= 8) iters_done = pgs_dense_sliced<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
-      else if (sc.nt <= 16) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
+      if (sc.nt <= 8) { if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 8, PROF>(ln, ncont, wave_max_cont, limit_rows, prof); }
+      else if (sc.nt <= 16) { if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof); }
       else if (sc.nt <= 24) iters_done = pgs_dense_sliced<LANES, 24, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
       else iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
     } else if constexpr (SLICED) {

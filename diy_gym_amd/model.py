@@ -53,6 +53,15 @@ class Model(Receptor):
             raise ValueError('Could not find URDF: ' + urdf)  # reference model.py:63
 
         self.robot = UrdfRobot(full)
+        if parent is not None and 'child_frame' in config:
+            # Child model attached by one of its LINKS (reference model.py:71-77: createConstraint pins the child link of
+            # joint `child_frame` to the parent frame).  The child is described from that link instead of its URDF root
+            # (UrdfRobot.rerooted: same mechanism, same joint coordinates); the rest of it hangs from there.  Joint
+            # indices of the child then follow the re-rooted tree.
+            names = self.robot.joint_names
+            if config.get('child_frame') not in names:
+                raise ValueError('child_frame: model %r has no joint %r' % (config.name, config.get('child_frame')))
+            self.robot = self.robot.rerooted(self.robot.joints[names.index(config.get('child_frame'))].child)
         self.flat = FlatBody(self.robot, scale=scale, fixed_base=use_fixed_base,
                              mass_override=config.get('mass') if 'mass' in config else None,
                              mesh_loader=mesh.load_convex, max_hull_points=self.env.max_hull_points)
@@ -63,9 +72,6 @@ class Model(Receptor):
             # parent with a fixed constraint whose pivot is this model's xyz / rpy in the parent frame.  Here the
             # coupling is rigid -- the child is merged into the parent's body (FlatBody.attach) and ``uid`` is an
             # alias the scene builder resolves to (parent body, link / frame offsets).
-            if 'child_frame' in config:
-                raise NotImplementedError('child_frame: only the base of a child model can be attached (the tree would '
-                                          'have to be re-rooted at that link)')
             parent_frame_id = parent.get_frame_id(config.get('parent_frame')) if 'parent_frame' in config else -1
             self.uid = self.env.builder.attach_child(parent.uid, parent_frame_id, self.flat, self.position, self.orientation)
         self.color = config.get('color') if 'color' in config else None  # visual only (camera rgb)

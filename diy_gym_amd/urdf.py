@@ -219,19 +219,65 @@ class UrdfRobot:
             raise ValueError('%s: expected exactly one root link, found %r' % (path, roots))
         self.root = roots[0]
 
-        # depth-first numbering, children in file order
+        self._number_joints()  # depth-first numbering, children in file order
+
+    def _number_joints(self):
+        """pybullet's numbering: depth-first from the root, children in file order; q_index counts movable joints."""
         self.joints = []
         stack = list(reversed(self.links[self.root].child_joints))
         q = 0
         while stack:
             j = stack.pop()
             j.index = len(self.joints)
+            j.q_index = -1
             if j.movable:
                 j.q_index = q
                 q += 1
             self.joints.append(j)
             stack.extend(reversed(self.links[j.child].child_joints))
         self.num_dofs = q
+
+    def rerooted(self, new_root):
+        """The same mechanism described from link ``new_root`` (a copy; this robot is untouched).  Used for child
+        models attached by one of their links (``child_frame``, reference model.py:71-77): the tree then hangs from
+        that link.  Every joint on the path old root -> new root is reversed: the old parent becomes the child, its
+        link frame moves to the joint (so that the URDF rule 'child frame = joint frame' still holds; everything
+        attached to it is re-expressed), the axis changes sign so that the joint coordinate keeps its meaning, sign
+        and limits.  Joint numbering follows the new tree."""
+        import copy
+        if new_root not in self.links:
+            raise ValueError('no link %r' % new_root)
+        r = copy.deepcopy(self)
+        if new_root == r.root:
+            return r
+        path = []  # joints from the new root up to the old root
+        link = r.links[new_root]
+        while link.parent_joint is not None:
+            path.append(link.parent_joint)
+            link = r.links[link.parent_joint.parent]
+        shift_of_child = Transform()  # how the frame of the joint's (old) child was re-expressed: x_new = S x_old
+        for j in path:
+            P, C = r.links[j.parent], r.links[j.child]
+            S = j.origin.inverse()  # P's frame moves to this joint: x_in_new_P_frame = origin^-1 x_in_old_P_frame
+            P.inertial_origin = S * P.inertial_origin
+            for sh in P.collisions:
+                sh.origin = S * sh.origin
+            for cj in P.child_joints:
+                if cj is not j:
+                    cj.origin = S * cj.origin  # (the upstream path joint, if any, is P's PARENT joint and is handled in its own turn)
+            P.child_joints = [cj for cj in P.child_joints if cj is not j]
+            C.child_joints.append(j)
+            # the reversed joint: its frame sits where C's old frame was, seen from C's (possibly moved) new frame
+            j.origin = shift_of_child
+            j.parent, j.child = C.name, P.name
+            j.axis = -j.axis
+            C.parent_joint = None if C.name == new_root else C.parent_joint
+            P.parent_joint = j
+            shift_of_child = S
+        r.links[new_root].parent_joint = None
+        r.root = new_root
+        r._number_joints()
+        return r
 
     @property
     def joint_names(self):

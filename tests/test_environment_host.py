@@ -188,14 +188,68 @@ def test_child_model_is_bolted_to_the_parent_frame():
     assert xyz.shape == (2, 3) and torch.isfinite(xyz).all() and torch.isfinite(quat).all()
 
 
-def test_child_frame_attachment_is_rejected_with_a_reason(tmp_path):
+def test_child_frame_attaches_the_child_by_that_link(tmp_path):
+    """``child_frame`` (reference model.py:71-77): the CHILD LINK of that joint is what gets pinned to the parent frame;
+    the rest of the child -- including its URDF root -- hangs from it (the child is re-rooted at that link)."""
     import yaml
+    from diy_gym_amd.mathx import Transform, mat_from_quat
     cfg = yaml.safe_load(open(os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml')))
-    cfg['arm']['gripper']['child_frame'] = 'finger_joint'
+    cfg['arm']['gripper']['child_frame'] = 'left_inner_finger_joint'
     path = tmp_path / 'c.yaml'
     yaml.safe_dump(cfg, open(path, 'w'))
-    with pytest.raises(NotImplementedError):
-        DIYGym(str(path), num_envs=1, backend_factory=OracleBackend)
+    env = DIYGym(str(path), num_envs=2, backend_factory=OracleBackend)
+    arm = env.models['arm']; grip = arm.models['gripper']
+    assert env.layout.n_bodies == 1 and env.layout.n_links == 6 + 6
+    assert grip.robot.root == 'left_inner_finger' and grip.robot.joint_names[0] != 'finger_joint'   # numbering follows the new tree
+    for _ in range(10):
+        env.step(env.action_space.sample())
+    body, _, _, basef = env.builder.resolve(grip.uid)
+    pe = env.sim.frame_state64(arm.uid, arm.get_frame_id('ee_fixed_joint'), com=True)
+    pg = env.sim.frame_state64(body, basef, com=True)      # inertial frame of the pinned link
+    for e in range(2):
+        Te = Transform(mat_from_quat(pe[e][3:7]), pe[e][:3]); Tg = Transform(mat_from_quat(pg[e][3:7]), pg[e][:3])
+        rel = Te.inverse() * Tg
+        assert np.allclose(rel.p, [0.0, 0.0, 0.02], atol=1e-9)
+        assert np.allclose(rel.R, [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-5)
+    # same total mass as the base-attached variant: nothing of the child is lost by re-rooting
+    ref = DIYGym(os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'), num_envs=1, backend_factory=OracleBackend)
+    assert abs(sum(fl.mass for fl in env.builder.bodies[0][0].links) - sum(fl.mass for fl in ref.builder.bodies[0][0].links)) < 1e-9
+
+
+def test_rerooted_urdf_is_the_same_mechanism():
+    """UrdfRobot.rerooted: for random joint values every link's inertial frame sits, relative to the new root, exactly where the
+    original description puts it (serial arm, gripper tree, tree with a prismatic joint)."""
+    from diy_gym_amd.mathx import Transform
+    from diy_gym_amd.urdf import UrdfRobot
+
+    def rot(axis, q):
+        a = axis / np.linalg.norm(axis); Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(q) * Kx + (1 - np.cos(q)) * Kx @ Kx
+
+    def fk(robot, qs):
+        T = {robot.root: Transform()}
+        for j in robot.joints:
+            m = Transform(rot(j.axis, qs[j.name])) if j.type in ('revolute', 'continuous') else Transform(p=j.axis * qs[j.name]) if j.type == 'prismatic' else Transform()
+            T[j.child] = T[j.parent] * j.origin * m
+        return {n: T[n] * robot.links[n].inertial_origin for n in T}
+
+    rng = np.random.default_rng(0)
+    data = os.path.join(ROOT, 'diy_gym_amd', 'data')
+    for path, roots in ((os.path.join(data, 'ur5', 'ur5_robot.urdf'), ['wrist_2_link', 'ee_link']),
+                        (os.path.join(data, 'robotiq_2f', 'gripper.urdf'), ['right_inner_finger', 'left_inner_knuckle']),
+                        (os.path.join(ROOT, 'tests', 'golden', 'urdf', 'cart_tree.urdf'), ['arm_b', 'tip'])):
+        r = UrdfRobot(path)
+        for nr in roots:
+            rr = r.rerooted(nr)
+            assert sorted(rr.links) == sorted(r.links) and len(rr.joints) == len(r.joints) and rr.num_dofs == r.num_dofs and rr.root == nr
+            assert r.root != nr and UrdfRobot(path).root == r.root            # the original is untouched
+            for _ in range(4):
+                qs = {j.name: rng.uniform(-1, 1) if j.movable else 0.0 for j in r.joints}
+                A, B = fk(r, qs), fk(rr, qs)
+                ia, ib = A[nr].inverse(), B[nr].inverse()
+                assert max(np.abs((ia * A[n]).matrix() - (ib * B[n]).matrix()).max() for n in A) < 1e-12
+            lim = {j.name: (j.lower, j.upper, j.effort) for j in r.joints}
+            assert {j.name: (j.lower, j.upper, j.effort) for j in rr.joints} == lim
 
 
 def test_child_model_on_a_floating_parent_merges_inertia(tmp_path):

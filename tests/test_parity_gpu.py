@@ -136,6 +136,23 @@ def test_child_model_gripper_40_steps():
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
 
 
+def test_child_model_attached_by_one_of_its_links_40_steps(tmp_path):
+    """``child_frame`` (reference model.py:71-77): the gripper hangs from the UR5's flange by its left inner finger -- the
+    child is re-rooted at that link, its former base swings on the reversed joints.  A 12-DoF tree, no contacts.
+    Blind to: the rigid merge itself (Bullet couples parent and child with a soft, iterated fixed constraint)."""
+    import yaml
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    cfg = yaml.safe_load(open(CONFIGS['child']))
+    cfg['arm']['gripper']['child_frame'] = 'left_inner_finger_joint'
+    path = tmp_path / 'by_finger.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'), sort_keys=False)
+    gpu = DIYGym(str(path), num_envs=5, device='cuda:0', seed=5); cpu = DIYGym(str(path), num_envs=5, seed=5, backend_factory=OracleBackend)
+    w = rollout(gpu, cpu, 40)
+    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+
+
 def test_arms_in_contact_30_steps():
     # Blind to: mesh-vs-mesh contacts through fitted capsules (Bullet uses GJK/EPA on the hulls) and no warm starting.
     # the two arms start with crossed forearms: contacts between two register-chain bodies, so the three-wavefront

@@ -30,8 +30,8 @@ class AddonFactory:
             from .controllers import AdmittanceController, InverseKinematicsController, JointController, ExternalForce
             from .sensors import Camera, ForceTorqueSensor, JointStateSensor, ObjectStateSensor
             from .rewards import ReachTarget, ElectricityCost, TimePenalty
-            from .misc import DynamicsRandomizer, Respawn, SpawnMultiple
-            from .unsupported import StuckJointCost, DrawCoords, VisualRandomizer
+            from .misc import DynamicsRandomizer, Respawn, SpawnMultiple, VisualRandomizer
+            from .unsupported import StuckJointCost, DrawCoords
             # same 17 keys as reference addon.py:36-54
             self.addons = {
                 'ik_controller': InverseKinematicsController,

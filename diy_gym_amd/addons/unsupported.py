@@ -14,4 +14,3 @@ def _stub(name, why):
 StuckJointCost = _stub('stuck_joint_cost', 'the reference implementation raises NameError on first use '
                        '(stuck_joint_cost.py:16-21); there is no behaviour to match')
 DrawCoords = _stub('draw_coords', 'GUI-only debug drawing')
-VisualRandomizer = _stub('visual_randomizer', 'GUI-only cosmetics; downloads a dataset over HTTP in the reference')

@@ -14,7 +14,7 @@
 
 namespace dg {
 
-enum { RS_R = 0, RS_P = 9, RS_C = 12, RS_BOUND = 15, RS_STRIDE = 16, RC_STRIDE = 12 };
+enum { RS_R = 0, RS_P = 9, RS_C = 12, RS_BOUND = 15, RS_COLOR = 16 /* rgb of the owning body in this env */, RS_STRIDE = 20, RC_STRIDE = 12 };
 
 template <int LANES>
 __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws) {
@@ -38,6 +38,8 @@ __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, fl
 #pragma unroll
     for (int k = 0; k < 9; k++) o[RS_R + k] = R.m[k];
     o[RS_P] = p.x; o[RS_P + 1] = p.y; o[RS_P + 2] = p.z; o[RS_C] = w.p.x; o[RS_C + 1] = w.p.y; o[RS_C + 2] = w.p.z; o[RS_BOUND] = bound;
+    { const int co = ln.bi(w.body)[DG_BI_COLOR_OFF]; cfp bc = ln.bf(w.body) + DG_BF_COLOR;  // per-env colour of a visual_randomizer, else the configured one
+      _Pragma("unroll") for (int k = 0; k < 3; k++) o[RS_COLOR + k] = co >= 0 ? ln.S(co + k) : bc[k]; }
   }
   for (int c = 0; c < ncam; c++) {
     cip ci = CI + c * DG_CI_STRIDE; cfp cf = CF + c * DG_CF_STRIDE;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
       if (rgb) {
         float c0r = 0.75f, c1r = 0.75f, c2r = 0.75f;
         if (hit) {
-          cfp colr = sc.BF + sc.SI[h.shape * DG_SI_STRIDE + DG_SI_BODY] * DG_BF_STRIDE + DG_BF_COLOR;  // per-lane index: vector loads
+          cfp colr = tb + h.shape * RS_STRIDE + RS_COLOR;  // per-lane index: vector loads from the env's table
           const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
           c0r = colr[0] * shd; c1r = colr[1] * shd; c2r = colr[2] * shd;
         }

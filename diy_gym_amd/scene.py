@@ -348,7 +348,7 @@ class SceneBuilder:
             frozen = (not dynamic) and b not in respawned
             flags = (K.BODY_FIXED if flat.fixed_base else 0) | (K.BODY_FROZEN if frozen else 0)
             # frozen bodies have no per-env state at all: their pose is the load pose in the body table
-            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off, -1, -1])
+            body_i.append([flags, first, len(flat.links), -1 if frozen else state_off, -1, -1, -1])
             if not frozen:
                 state_off += (K.BS_FIXED_END if flat.fixed_base else K.BS_FLOAT_END) + K.EXT_STRIDE
             I = flat.base_inertia
@@ -439,6 +439,8 @@ class SceneBuilder:
                         raise ValueError('two dynamics_randomizer addons on the same joint')
                     link_i[gl_][K.LI_MASS_SCALE] = base + k
                 body_i[row[K.OI_BODY]][K.BI_DYN_OFF] = base + len(links)
+            if row[K.OI_CODE] == K.OP_RANDOMIZE_COLOR:
+                body_i[row[K.OI_BODY]][K.BI_COLOR_OFF] = addon_off + row[K.OI_STATE_OFF]
             if row[K.OI_CODE] == K.OP_OBS_FT and row[K.OI_STATE_OFF] >= 0:  # the sensor that owns its body's saved velocities
                 if body_i[row[K.OI_BODY]][K.BI_PREV_OFF] < 0:
                     body_i[row[K.OI_BODY]][K.BI_PREV_OFF] = addon_off + row[K.OI_STATE_OFF]

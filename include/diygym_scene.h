@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 7
+#define DG_VERSION 8
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -107,6 +107,7 @@ enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF,
        DG_BI_DYN_OFF /* state offset of the body's per-env angular damping (dynamics_randomizer), or -1: DG_HF_ANG_DAMPING */,
        DG_BI_PREV_OFF /* state offset where the body's generalised velocity at the START of a step's last substep is kept
                          (joint rates in link order, then base linvel3 angvel3 if floating) for force_torque_sensor, or -1 */,
+       DG_BI_COLOR_OFF /* state offset of the body's per-env rgb (visual_randomizer), or -1: DG_BF_COLOR */,
        DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)
@@ -197,6 +198,8 @@ enum {
                                   Addon state: N mass scales, then the angular damping.  Guards (the reference formula goes
                                   negative for U < 1): |log U| for the mass, scale clamped to [f4, f5]; damping >= 0.  Drawn
                                   twice at an env's first reset (the reference draws at construction and again in reset()) */
+  DG_OP_RANDOMIZE_COLOR = 19,    /* visual_randomizer.py:40-46, without its texture data set: a flat rgb per env and
+                                    episode, U(0,1)^3 from the counter RNG, kept in 3 floats of addon state (camera rgb only) */
   /* observe phase */
   DG_OP_OBS_JOINT_STATE = 32,  /* joint_state_sensor.py:47-57 */
   DG_OP_OBS_OBJECT_STATE = 33, /* object_state_sensor.py:49-75 */

@@ -339,6 +339,10 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
     }
     for (int op = 0; op < w->sc.nops; op++) { /* dynamics_randomizer state before its first draw: URDF masses, default damping */
       const int32_t* oi = w->sc.OI + op * DG_OI_STRIDE;
+      if (oi[DG_OI_CODE] == DG_OP_RANDOMIZE_COLOR) { /* the configured colour until the first draw */
+        for (int k = 0; k < 3; k++) st[w->sc.addon_off + oi[DG_OI_STATE_OFF] + k] = body_f(&w->sc, oi[DG_OI_BODY])[DG_BF_COLOR + k];
+        continue;
+      }
       if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;
       double* ps = st + w->sc.addon_off + oi[DG_OI_STATE_OFF];
       for (int k = 0; k < oi[DG_OI_N]; k++) ps[k] = 1.0;
@@ -1079,6 +1083,9 @@ static void run_reset_ops(dgo_world* w, int env) {
     } else if (code == DG_OP_RESET_JOINTS) { /* joint_controller.py:36-38 */
       const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { double* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
+    } else if (code == DG_OP_RANDOMIZE_COLOR) { /* visual_randomizer.py:40-46 (flat colour instead of a texture) */
+      double* ps = st + s->addon_off + oi[DG_OI_STATE_OFF]; const uint64_t ge = (uint64_t)(w->env_base + env);
+      for (int k = 0; k < 3; k++) ps[k] = rng_uniform(w->seed, ge, episode + 1, (uint64_t)op, (uint64_t)k);
     } else if (code == DG_OP_RANDOMIZE_DYNAMICS) { /* dynamics_randomizer.py:24-32 */
       const double* fl = s->FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N]; double* ps = st + s->addon_off + oi[DG_OI_STATE_OFF];
       const uint64_t ge = (uint64_t)(w->env_base + env);
@@ -1394,7 +1401,8 @@ int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t
       if (rgb) {
         double c[3] = {0.75, 0.75, 0.75};
         if (hit) {
-          const double* col4 = body_f(s, s->SI[h.shape * DG_SI_STRIDE + DG_SI_BODY]) + DG_BF_COLOR;
+          const int hb_ = s->SI[h.shape * DG_SI_STRIDE + DG_SI_BODY]; const int co_ = body_i(s, hb_)[DG_BI_COLOR_OFF];
+          const double* col4 = co_ >= 0 ? st + co_ : body_f(s, hb_) + DG_BF_COLOR;  /* per-env colour of a visual_randomizer */
           double nl = vdot(h.n, light); double sh = 0.4 + 0.6 * (nl > 0 ? nl : 0);
           for (int k = 0; k < 3; k++) c[k] = col4[k] * sh;
         }

@@ -181,3 +181,48 @@ def test_hip_render_odd_sizes_match_oracle(res):
     same = g['segmentation_mask'].cpu() == c['segmentation_mask']
     assert same.float().mean() > 0.99
     assert float((g['depth'].cpu() - c['depth']).abs()[same].max()) < 1e-3
+
+
+def test_visual_randomizer_recolours_the_model_per_env_and_episode(tmp_path):
+    """visual_randomizer (reference visual_randomizer.py:14-46) without its texture data set: a flat colour per env and
+    episode, seen by the camera's rgb only."""
+    import yaml
+    tree = yaml.safe_load(open(BASIC))
+    tree['red_marble']['look'] = {'addon': 'visual_randomizer'}
+    from diy_gym_amd.config import Configuration
+    env = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=4, seed=3, backend_factory=OracleBackend)
+    look = env.models['red_marble'].addons['look']
+    c0 = look.colors().clone()
+    assert c0.shape == (4, 3) and float(c0.min()) >= 0.0 and float(c0.max()) <= 1.0 and len({tuple(r.tolist()) for r in c0}) == 4
+    obs = env.observe()['basic_env']['camera']
+    rgb, depth = np.asarray(obs['rgb']), np.asarray(obs['depth'])
+    ref = DIYGym(BASIC, num_envs=4, seed=3, backend_factory=OracleBackend).observe()['basic_env']['camera']
+    assert np.array_equal(depth, np.asarray(ref['depth']))                      # geometry untouched
+    changed = np.abs(rgb - np.asarray(ref['rgb'])).max(-1) > 1e-6
+    assert changed.any() and changed.mean() < 0.2                                 # only the marble's pixels
+    for e in range(4):   # the marble's pixels carry the drawn colour (times the shading factor)
+        px = rgb[e][changed[e]]
+        ratio = px / np.maximum(c0[e].numpy()[None, :], 1e-6)
+        assert np.allclose(ratio, ratio[:, :1], atol=1e-4)
+    env.reset(torch.tensor([1, 0, 0, 1], dtype=torch.uint8))
+    c1 = look.colors()
+    assert [bool((c1[i] != c0[i]).any()) for i in range(4)] == [True, False, False, True]
+
+
+@pytest.mark.gpu
+def test_visual_randomizer_hip_matches_oracle(tmp_path):
+    import copy
+    import yaml
+    from diy_gym_amd.config import Configuration
+    tree = yaml.safe_load(open(BASIC))
+    tree['red_marble']['look'] = {'addon': 'visual_randomizer'}
+    tree['plane']['look'] = {'addon': 'visual_randomizer'}
+    gpu = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=6, device='cuda:0', seed=2)
+    cpu = DIYGym(Configuration.from_dict('basic_env', copy.deepcopy(tree)), num_envs=6, seed=2, backend_factory=OracleBackend)
+    for _ in range(2):
+        g = gpu.receptors['basic_env'].addons['camera'].observe(); c = cpu.receptors['basic_env'].addons['camera'].observe()
+        assert np.allclose(gpu.models['plane'].addons['look'].colors().numpy(), cpu.models['plane'].addons['look'].colors().numpy(), atol=1e-6)
+        same = (g['depth'].cpu() - c['depth']).abs() < 1e-3
+        assert same.float().mean() > 0.99 and float((g['rgb'].cpu() - c['rgb']).abs()[same].max()) < 2e-3
+        mask = torch.tensor([1, 0, 1, 0, 1, 1], dtype=torch.uint8)
+        gpu.reset(mask.to('cuda:0')); cpu.reset(mask)

@@ -377,15 +377,20 @@ struct Lane {
       Sset(so + DG_BS_ANGVEL + 2, S(so + DG_BS_ANGVEL + 2) + h * dww.z);
     }
     prof.stamp(3 /* PS_ABA */);
-    // ---- M^-1 by unit impulse responses; column col of generalized coords (base 6 first when floating).
-    // p (bias) reuses AW_PA, link accelerations reuse AW_V.
+    // ---- M^-1 by unit impulse responses; column col of generalised coordinates (base 6 first when floating).
+    // p (bias) reuses AW_PA, link accelerations reuse AW_V.  M^-1 is symmetric, so only its lower triangle is computed:
+    // the response to an impulse on joint j is propagated inward along j's ancestors only and outward over the links
+    // 0..j only (every entry to the right of the diagonal is the mirror image of one computed by a later column), and
+    // a base column needs nothing but its 6 x 6 block.  Roughly half the work of propagating every column through
+    // every link.
     for (int col = 0; col < nv; col++) {
       const int jdof = col - nb6;  // joint index or negative for a base coordinate
       S6 p0 = {v3(0, 0, 0), v3(0, 0, 0)};
       if (jdof >= 0) {
-        // inward from the driven joint; links above it carry no bias
-        for (int i = 0; i < n; i++) { S6 z = {v3(0, 0, 0), v3(0, 0, 0)}; L6set(aw(i) + AW_PA, z); }
-        for (int i = jdof; i >= 0; i--) {
+        // inward from the driven joint along its ancestors; every other link carries no bias
+        for (int i = 0; i <= jdof; i++) L(aw(i) + AW_UU) = 0.0f;
+        for (int i = jdof; i >= 0; ) { const int par = li(first + i)[DG_LI_PARENT]; S6 z = {v3(0, 0, 0), v3(0, 0, 0)}; L6set(aw(i) + AW_PA, z); i = par < 0 ? -1 : par - first; }
+        for (int i = jdof; i >= 0; ) {
           int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i);
           S6 p = L6(o + AW_PA); S6 Sx = subspace(gl);
           float u = (i == jdof ? 1.0f : 0.0f) - dot(Sx, p);
@@ -395,10 +400,8 @@ struct Lane {
             S6 pf = xforce_to_parent(LM(o + AW_E), L3(o + AW_R), pa);
             if (par < 0) p0 = p0 + pf; else L6add(aw(par - first) + AW_PA, pf);
           }
+          i = par < 0 ? -1 : par - first;
         }
-        for (int i = jdof + 1; i < n; i++) L(aw(i) + AW_UU) = 0.0f;
-      } else {
-        for (int i = 0; i < n; i++) L(aw(i) + AW_UU) = 0.0f;
       }
       S6 a0c = {v3(0, 0, 0), v3(0, 0, 0)};
       if (!fx) {
@@ -412,7 +415,7 @@ struct Lane {
 #pragma unroll
         for (int k = 0; k < 6; k++) L(mo + col * nv + k) = x[k];
       }
-      for (int i = 0; i < n; i++) {
+      for (int i = 0; i <= jdof; i++) {  // (none for a base column)
         int gl = first + i, par = li(gl)[DG_LI_PARENT]; int o = aw(i);
         S6 ap = par < 0 ? a0c : L6(aw(par - first) + AW_V);
         S6 a1 = xmotion(LM(o + AW_E), L3(o + AW_R), ap);
@@ -421,6 +424,7 @@ struct Lane {
         L(mo + col * nv + nb6 + i) = qdd;
       }
     }
+    for (int r = 0; r < nv; r++) for (int c = r + 1; c < nv; c++) L(mo + r * nv + c) = L(mo + c * nv + r);  // mirror the lower triangle
     prof.stamp(4 /* PS_MINV */);
   }
 

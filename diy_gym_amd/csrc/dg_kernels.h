@@ -189,15 +189,23 @@ struct Lane {
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
     LRset(plb(b)[PLB_R0], R0);
-#pragma unroll 3
-    for (int i = 0; i < n; i++) {
-      int gl = first + i, par = li(gl)[DG_LI_PARENT];
-      float q = qoff >= 0 ? L(qoff + i) : S(li(gl)[DG_LI_STATE_OFF] + DG_LS_Q);
-      M3 Rpc; V3 r; joint_xform(gl, q, Rpc, r);
-      M3 Rp; V3 pp;
-      if (par < 0) { Rp = R0; pp = p0; } else { int o = pll(par)[PLL_POSE]; Rp = LR(o); pp = L3(o + 6); }
-      int o = pll(gl)[PLL_POSE];
-      LRset(o, mul(Rp, Rpc)); L3set(o + 6, pp + mul(Rp, r));
+    // joint angles eight links at a time, all loads issued before the first transform: a link at a time pays one
+    // scalar-table round trip plus one global round trip per link (cold at the start of a step: ~1.4 k cycles each)
+    constexpr int KCH = 8;
+    for (int i0 = 0; i0 < n; i0 += KCH) {
+      float qv[KCH];
+#pragma unroll
+      for (int j = 0; j < KCH; j++) { const int i = min(i0 + j, n - 1); qv[j] = qoff >= 0 ? L(qoff + i) : S(li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q); }
+#pragma unroll
+      for (int j = 0; j < KCH; j++) {
+        const int i = i0 + j; if (i >= n) break;
+        int gl = first + i, par = li(gl)[DG_LI_PARENT];
+        M3 Rpc; V3 r; joint_xform(gl, qv[j], Rpc, r);
+        M3 Rp; V3 pp;
+        if (par < 0) { Rp = R0; pp = p0; } else { int o = pll(par)[PLL_POSE]; Rp = LR(o); pp = L3(o + 6); }
+        int o = pll(gl)[PLL_POSE];
+        LRset(o, mul(Rp, Rpc)); L3set(o + 6, pp + mul(Rp, r));
+      }
     }
   }
 

@@ -1759,7 +1759,7 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
       const float sn = fsqrt(sx * sx + sy * sy + sz * sz), an = atan2f(sn, 0.5f * (tr - 1.0f)), k = sn > 1e-12f ? fdiv(an, sn) : 1.0f;
       dS[3] = sx * k; dS[4] = sy * k; dS[5] = sz * k;
     }
-    float U[21], Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0[N];
+    float U[21], Jv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0[N], cols[N][6];
 #pragma unroll
     for (int k = 0; k < 21; k++) U[k] = 0.f;
     auto column = [&](int i, float* col) {
@@ -1776,7 +1776,7 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
           if (q[i] < nLo[i]) v0[i] += g1 * (nLo[i] - q[i]) * nIrg[i];
         }
         if (FULL || i <= eel) {
-          float col[6]; column(i, col);
+          float* col = cols[i]; column(i, col);  // kept for the back-substitution below (36 registers instead of 54 instructions)
 #pragma unroll
           for (int r = 0; r < 6; r++) {
             Jv[r] += col[r] * v0[i];
@@ -1801,9 +1801,8 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
       if (FULL || i < n) {
         float t = 0.f;
         if (FULL || i <= eel) {
-          float col[6]; column(i, col);
 #pragma unroll
-          for (int r = 0; r < 6; r++) t += col[r] * y[r];
+          for (int r = 0; r < 6; r++) t += cols[i][r] * y[r];
         }
         dth[i] = t + v0[i]; mx = fmaxf(mx, fabsf(dth[i]));
       }

@@ -89,8 +89,10 @@ def test_initial_state_and_reset_match():
     for name in CONFIGS:
         gpu, cpu = make_pair(name, 5)
         # after the constructor's reset (respawn + rest joints + 1 hot-start step).  Velocities of resting
-        # bodies are determined to the solver's residual threshold (sqrt(1e-7) = 3e-4 m/s); efforts are O(100 N m)
-        assert np.allclose(gpu.sim.get_state(), cpu.sim.get_state(), rtol=1e-4, atol=5e-4), name
+        # bodies are determined to the solver's residual threshold (sqrt(1e-7) = 3e-4 m/s); efforts are O(100 N m) and,
+        # for arms resting against each other, carry that velocity residual times the controller's damping gain
+        # (measured 1.3e-4 relative on the touching scene, tools/gpu_reset_diff.py)
+        assert np.allclose(gpu.sim.get_state(), cpu.sim.get_state(), rtol=3e-4, atol=5e-4), name
         ft = _ft_columns(gpu)   # (force/torque readings are O(1000) N in the touching scene: relative to the vector's size)
         keep = torch.ones(gpu.sim.obs.shape[1], dtype=torch.bool); keep[ft] = False
         assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs()[:, keep].max()) < 5e-4, name

@@ -246,7 +246,7 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
 
 // builds the three rows of contact slot c for the lanes whose contact belongs to (uniform) pair `pair`
 template <int LANES>
-DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, bool vel_in_lds) {
+DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, bool vel_in_lds, int d_lo = 0, int d_hi = 3) {
   const DevScene& sc = ln.sc; const int nvm = sc.nv_max, tl = sc.crow_tail, rs = crow_stride(tl);
   cip sa = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE; cip sb = sc.SI + sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE;
   const int ba = sa[DG_SI_BODY], la = sa[DG_SI_LINK], bb = sb[DG_SI_BODY], lb = sb[DG_SI_LINK];
@@ -257,7 +257,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
   V3 t1, t2; tangent_basis(n, t1, t2);
   const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
   ln.L(co + CL_MU) = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
-  for (int d = 0; d < 3; d++) {
+  for (int d = d_lo; d < d_hi; d++) {  // (lane-sliced callers give each lane of an env's group one direction)
     V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
     int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
     for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;  // rows are swept branch-free: pad with zeros
@@ -1347,6 +1347,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
   if (vel_dense && wave_max_cont > 0)
     for (int b = 0; b < sc.nb; b++) if (!(ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) ln.gen_vel_store(b, ln.plb(b)[PLB_DV]);
+  if constexpr (!SLICED) {
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
     bool todo = has;
@@ -1359,7 +1360,34 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     }
   }
   prof.stamp(PS_ROWS);
+  }
   }  // primary
+  if constexpr (SLICED) {
+    // Lane-sliced modes: the SL lanes of an env's group (the grouping of the sweeps: lane = env * SL + slice) share the
+    // row construction -- four lanes per contact, one direction each (the fourth idles), SL / 4 contacts at a time;
+    // two lanes per env: one contact each, all three directions.  Same arithmetic per row as the one-lane loop.
+    constexpr int EPW = envs_per_wave(LANES), SL = 64 / EPW, LOG = SL == 16 ? 4 : SL == 8 ? 3 : SL == 4 ? 2 : 1;
+    constexpr int CPI = SL >= 4 ? SL / 4 : SL;  // contacts per env per pass
+    const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
+    const int envq = blockIdx.x * EPW + q; const bool validq = envq < sc.num_envs; const int eq = validq ? envq : sc.num_envs - 1;
+    const Lane<LANES> lq(sc, ln.mt, ln.lds - lane + q, ln.st - ln.env + eq, eq, validq);
+    const int ncq = __shfl(ncont, q), wmc = __builtin_amdgcn_readfirstlane(wave_max_cont);
+    const bool vd = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
+    const int csub = SL >= 4 ? sl >> 2 : sl, d_lo = SL >= 4 ? (sl & 3) : 0, d_hi = SL >= 4 ? ((sl & 3) < 3 ? (sl & 3) + 1 : 0) : 3;
+    for (int c0 = 0; c0 < wmc; c0 += CPI) {
+      const int c = c0 + csub; const bool has = c < ncq && d_lo < d_hi;
+      const int mypair = has ? (int)lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
+      bool todo = has;
+      while (__any(todo)) {
+        const int leader = __ffsll((long long)__ballot(todo)) - 1;
+        const int pair = __shfl(mypair, leader);
+        const bool mine = todo && mypair == pair;
+        build_contact_rows(lq, c, pair, mine, vd, d_lo, d_hi);
+        todo = todo && !mine;
+      }
+    }
+    prof.stamp(PS_ROWS);
+  }
   // ---- projected Gauss-Seidel
   bool split_now = false;
   if constexpr (PAR) split_now = split_decide_main(ln, wave_max_cont, limit_mask, limit_rows);

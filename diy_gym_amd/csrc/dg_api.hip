@@ -237,6 +237,20 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       }
       for (int k = 0; k < 4; k++) { int32_t bits; memcpy(&bits, &d[k], 4); plan.push_back(bits); }
     } }
+  // shape frame descriptors, device-only, for narrow-phase lanes that each test a different shape: [LDS slot of the pose
+  // of the shape's link (rotation columns, position at + 6) or of its body's base rotation | state offset of the base
+  // position (base shapes) or -1 | first hull point | hull points]; slot -1: frozen in the world
+  const size_t sd_off = plan.size();
+  { const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
+    for (int s = 0; s < I[DG_H_N_SHAPES]; s++) {
+      const int32_t* si = SIh + s * DG_SI_STRIDE; const int b = si[DG_SI_BODY], gl = si[DG_SI_LINK];
+      const bool world = (si[DG_SI_FLAGS] & DG_SHAPE_WORLD) != 0;
+      const int32_t rslot = world ? -1 : gl >= 0 ? plan[(size_t)nb * PLB_STRIDE + (size_t)gl * PLL_STRIDE + PLL_POSE] : plan[(size_t)b * PLB_STRIDE + PLB_R0];
+      plan.push_back(rslot);
+      plan.push_back((world || gl >= 0) ? -1 : BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF]);
+      plan.push_back(si[DG_SI_POINT_OFF]); plan.push_back(si[DG_SI_N_POINTS]);
+    } }
+  PLB = plan.data(); PLL = plan.data() + (size_t)nb * PLB_STRIDE;  // (the appends above may have moved the vector)
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
   // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
   cip dI = (cip)w->d_blob_i; cfp dF = (cfp)w->d_blob_f;
@@ -245,7 +259,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.GI = dI + I[DG_H_OFF_GROUP_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
-  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off);
+  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off); sc.SD = sc.PLB + sd_off;
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];

@@ -48,6 +48,7 @@ struct DevScene {
   int coll_split, cont2_off;  // with coll_wave: a fourth wavefront tests the second half of the pair table into its own contact list at cont2_off
   int coll_wave;  // helper-wave step kernel: a third wavefront runs the narrow phase (every moving body has register-resident dynamics)
   cfp GD;   // per pair group, device-only: [x y z reach] of a frozen static partner (reach < 0: none), see dg_world_create
+  cip SD;   // per shape, device-only: [pose slot | base position state offset or -1 | first hull point | hull points], see dg_world_create
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;

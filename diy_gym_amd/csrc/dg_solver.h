@@ -113,8 +113,12 @@ enum { SC_C = 0, SC_H = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
 // Only the candidate pairs [pair_lo, pair_hi) are tested and their contacts go to the list at `list` (the helper-wave
 // kernel cuts the pair table in two for two wavefronts; pair order, hence contact order, is kept by appending the
 // second list to the first).
-template <int LANES, int TBL>
-DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff, int list = -1) {
+// SLC > 1 (lane-sliced step kernels): the call is made by all 64 lanes, `ln` is the lane's ENV column in the sweeps'
+// grouping (lane = env * SLC + sl) -- the SLC lanes of an env do everything identically (same values to the same LDS
+// slots) except the pairs of a group against a box frozen in the world (the ground plane, every wall), which they
+// test SLC at a time, one pair per lane, and then append to the env's list in pair order.
+template <int LANES, int TBL, int SLC = 1>
+DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff, int list = -1, int sl = 0) {
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
   if (list < 0) list = sc.cont_off;
   if (sc.npairs == 0) { ln.L(list) = 0.f; return 0; }
@@ -162,6 +166,75 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
       { const V3 dc = cpos - other; if (!__any(dot(dc, dc) < reach * reach)) continue; }
     }
   const int first = max(g_first, pair_lo), count = min(g_first + g_count, pair_hi) - first;  // this wave's share
+  if constexpr (SLC > 1) {
+    const int ss = gi[DG_GI_STATIC_SHAPE];
+    if (orr >= 0.f && sc.SI[ss * DG_SI_STRIDE + DG_SI_TYPE] == DG_SHAPE_BOX) {
+      WShape b; shape_world(ln, ss, b);  // (the same box for every pair of the group)
+      for (int c0 = 0; c0 < count; c0 += SLC) {
+        const bool act = c0 + sl < count; const int pi = first + (act ? c0 + sl : 0), d = sc.PD[pi];
+        const int sa = d & 4095, ta = (d >> 24) & 3; const float flip = (d >> 28) & 1 ? -1.f : 1.f;
+        const int oa = sc.tr_off + sa * SC_STRIDE;
+        const V3 ca = ln.L3(oa + SC_C);
+        // up to four contacts per pair, in fixed slots (sphere: 0; capsule: its two ends; hull: its four deepest corners)
+        float hp[4][3], hn[4][3], hd[4]; unsigned hv = 0u;
+        auto keep = [&](int j, const Hit& h, bool ok) {
+          if (h.hit && ok) hv |= 1u << j;
+          const V3 m = (h.pa + h.pb) * 0.5f, nn = h.n * flip;
+          hp[j][0] = m.x; hp[j][1] = m.y; hp[j][2] = m.z; hn[j][0] = nn.x; hn[j][1] = nn.y; hn[j][2] = nn.z; hd[j] = h.dist;
+        };
+        if (act && sphere_box(ca, ln.L(oa + SC_BOUND), b, margin).hit) {  // bounding sphere of the round shape against the box
+          const V3 ha = ln.L3(oa + SC_H); const V3 a0 = ca - ha, a1 = ca + ha; const float ra = ln.L(oa + SC_R);
+          if (ta == DG_SHAPE_SPHERE) keep(0, sphere_box(a0, ra, b, margin), true);
+          else if (ta == DG_SHAPE_CAPSULE) {
+            keep(0, sphere_box(a0, ra, b, margin), true);
+            if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) keep(1, sphere_box(a1, ra, b, margin), true);
+          } else if (ta == DG_SHAPE_POINTS) {
+            cip sd = sc.SD + 4 * sa; const int rslot = sd[0], soff = sd[1], poff = sd[2], npts = sd[3];
+            M3 Rl; V3 pl;
+            if (rslot < 0) { M3 Id = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; Rl = Id; pl = v3(0.f, 0.f, 0.f); }
+            else { Rl = ln.LR(rslot); pl = soff >= 0 ? v3(ln.S(soff), ln.S(soff + 1), ln.S(soff + 2)) : ln.L3(rslot + 6); }
+            int bi4[4] = {-1, -1, -1, -1}; float bd4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+            for (int k2 = 0; k2 < npts; k2++) {
+              cfp pp = sc.PF + 3 * (poff + k2);
+              Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
+              if (!h.hit) continue;
+              bool placed = false;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                if (!placed && h.dist < bd4[j]) {
+#pragma unroll
+                  for (int m = 3; m > j; m--) { bd4[m] = bd4[m - 1]; bi4[m] = bi4[m - 1]; }
+                  bd4[j] = h.dist; bi4[j] = k2; placed = true;
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              cfp pp = sc.PF + 3 * (poff + (bi4[j] < 0 ? 0 : bi4[j]));
+              keep(j, sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin), bi4[j] >= 0);
+            }
+          }
+        }
+        if (!__any(hv != 0u)) continue;
+        // append in pair order: slice j's contacts before slice j + 1's; every lane of the env keeps the same count
+        for (int j = 0; j < SLC; j++) {
+          const unsigned fl = (unsigned)__shfl((int)hv, (int)((threadIdx.x & 63 & ~(SLC - 1)) | j));
+          if (!__any(fl != 0u)) continue;
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            if (((fl >> t) & 1u) && cnt < sc.max_contacts) {
+              if (sl == j) {
+                const int o = list + 1 + cnt * CL_STRIDE;
+                ln.L(o + CL_PAIR) = (float)pi; ln.L3set(o + CL_P, v3(hp[t][0], hp[t][1], hp[t][2])); ln.L3set(o + CL_N, v3(hn[t][0], hn[t][1], hn[t][2])); ln.L(o + CL_DIST) = hd[t];
+              }
+              cnt++;
+            }
+          }
+        }
+      }
+      continue;
+    }
+  }
   constexpr int CH = TBL > 0 ? TBL : 1;
   for (int c0 = 0; c0 < count; c0 += CH) {
     const int n = min(CH, count - c0);
@@ -1300,13 +1373,22 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   // early: the narrow-phase wavefront already ran this (first) substep's narrow phase and dynamics during the update
   // ops; positions have not changed since the poses of the step's start were computed
   const bool early = PAR && sc.early_dyn && index == 0;
+  // lane-sliced modes: this lane's env in the grouping of the sweeps (lane = env * SL + slice), see pgs_dense_sliced
+  constexpr int EPW = envs_per_wave(LANES), SLN = SLICED ? 64 / EPW : 1, SLOG = SLN == 16 ? 4 : SLN == 8 ? 3 : SLN == 4 ? 2 : SLN == 2 ? 1 : 0;
+  const int qlane = threadIdx.x & 63, qsl = qlane & (SLN - 1), qe = qlane >> SLOG;
+  const int qenv = blockIdx.x * EPW + qe; const bool qvalid = qenv < sc.num_envs; const int qec = qvalid ? qenv : sc.num_envs - 1;
+  const Lane<LANES> lq(sc, ln.mt, SLICED ? ln.lds - qlane + qe : ln.lds, SLICED ? ln.st - ln.env + qec : ln.st, SLICED ? qec : ln.env, SLICED ? qvalid : ln.valid);
   if (primary) {
   if (index == sc.substeps - 1 && !early) for (int b = 0; b < sc.nb; b++) if (b != hb) save_prev_velocities(ln, b);
   if (!early) for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
+  }
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
+  if constexpr (SLICED) collide<LANES, 64, SLN>(lq, 0, 0x7fffffff, -1, qsl);  // every lane: the env's group shares the pairs
+  if (primary) {
   const bool own_collide = !(PAR && sc.coll_wave);  // else the third wavefront is doing it right now
-  if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (SLICED ? envs_per_wave(LANES) : (PAR ? 64 : 0))>(ln);
+  if constexpr (SLICED) ncont = (int)ln.L(sc.cont_off);
+  else if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (PAR ? 64 : 0)>(ln);
   prof.stamp(PS_COLLIDE);
   if (!early) for (int b = 0; b < sc.nb; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
@@ -1366,12 +1448,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     // Lane-sliced modes: the SL lanes of an env's group (the grouping of the sweeps: lane = env * SL + slice) share the
     // row construction -- four lanes per contact, one direction each (the fourth idles), SL / 4 contacts at a time;
     // two lanes per env: one contact each, all three directions.  Same arithmetic per row as the one-lane loop.
-    constexpr int EPW = envs_per_wave(LANES), SL = 64 / EPW, LOG = SL == 16 ? 4 : SL == 8 ? 3 : SL == 4 ? 2 : 1;
-    constexpr int CPI = SL >= 4 ? SL / 4 : SL;  // contacts per env per pass
-    const int lane = threadIdx.x, sl = lane & (SL - 1), q = lane >> LOG;
-    const int envq = blockIdx.x * EPW + q; const bool validq = envq < sc.num_envs; const int eq = validq ? envq : sc.num_envs - 1;
-    const Lane<LANES> lq(sc, ln.mt, ln.lds - lane + q, ln.st - ln.env + eq, eq, validq);
-    const int ncq = __shfl(ncont, q), wmc = __builtin_amdgcn_readfirstlane(wave_max_cont);
+    constexpr int SL = SLN, CPI = SL >= 4 ? SL / 4 : SL;  // contacts per env per pass
+    const int sl = qsl;
+    const int ncq = __shfl(ncont, qe), wmc = __builtin_amdgcn_readfirstlane(wave_max_cont);
     const bool vd = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
     const int csub = SL >= 4 ? sl >> 2 : sl, d_lo = SL >= 4 ? (sl & 3) : 0, d_hi = SL >= 4 ? ((sl & 3) < 3 ? (sl & 3) + 1 : 0) : 3;
     for (int c0 = 0; c0 < wmc; c0 += CPI) {

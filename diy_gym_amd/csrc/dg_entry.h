@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, valid);
   Prof<PROF> prof; prof.start();
   if (primary) {
-    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+    for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
     prof.stamp(PS_KIN);
     if (actions) run_update_ops(ln, actions + (size_t)e * sc.act_dim, mask, -1, -1, diag);
     ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   }
   sim_step<LANES, PROF, false, SLICED, LANES == 64 || LANES == 0>(ln, diag, prof, smem, gws);
   if (!primary) return;
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
   prof.stamp(PS_KIN);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
 template <int LANES>
 DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
   const DevScene& sc = ln.sc; Prof<false> none; int m = 0;
-  for (int b = 0; b < sc.nb; b++) {
+  for (int b = 0; b < sc.nba; b++) {
     if (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0) continue;
     if ((m++ & 1) != parity) continue;
     if (sc.substeps == 1) save_prev_velocities(ln, b);  // the early substep is the step's last one
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
   Prof<PROF> prof; prof.start();
-  for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
+  for (int b = 0; b < sc.nba; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B0
   prof.stamp(PS_KIN);
   if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body, diag);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   __syncthreads();  // B0': the helper's motor targets are in the state
   prof.stamp(PS_UPDATE);
   sim_step<64, PROF, true>(ln, diag, prof);
-  for (int b = 0; b < sc.nb; b++) if (b != sc.helper_body) ln.kinematics(b);
+  for (int b = 0; b < sc.nba; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B4: the helper's body too
   prof.stamp(PS_KIN);
   // the output phase is shared: this wave emits the joint states of its bodies, the helper its arm's, the third
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
   }
   // observations of the envs that were reset; a wavefront without one has nothing to refresh (its rows are current)
   if (obs && (mask == nullptr || __any(doit))) {
-    for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+    for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
     run_output_ops(ln, valid ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_ALL, -1,
                    doit ? (sc.hot_start > 0 ? 0 : 1) : 2);
   }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void observe_kernel(DevScene sc, MotorTable mt,
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
   Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, false);  // never stores state
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
   run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr,
                  (valid && term) ? term + (size_t)e * sc.term_dim : nullptr, (valid && rew_sum) ? rew_sum + e : nullptr,
                  (valid && term_flag) ? term_flag + e : nullptr, OUT_ALL, -1, 1 /* no contact list outside a step */);

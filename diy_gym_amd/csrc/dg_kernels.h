@@ -51,6 +51,8 @@ struct DevScene {
   cip SD;   // per shape, device-only: [pose slot | base position state offset or -1 | first hull point | hull points], see dg_world_create
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
+  int32_t nba;  // 1 + the last body that is not frozen in the world: per-body loops of the step stop here (a maze is one robot + 120 frozen walls)
+  int32_t nsha; // 1 + the last shape that is not an analytic box (the narrow phase caches a segment per round shape)
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan

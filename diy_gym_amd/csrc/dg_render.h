@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, fl
   const int lane = threadIdx.x; if (lane >= ACTIVE) return;
   const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
   Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + env, env, false);
-  for (int b = 0; b < sc.nb; b++) ln.kinematics(b);
+  for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
   float* out = table + (size_t)env * (sc.nsh * RS_STRIDE + ncam * RC_STRIDE);
   for (int sh = 0; sh < sc.nsh; sh++) {
     WShape w; shape_world(ln, sh, w); cip si = sc.SI + sh * DG_SI_STRIDE; float* o = out + sh * RS_STRIDE;

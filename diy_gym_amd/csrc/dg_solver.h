@@ -122,7 +122,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
   if (list < 0) list = sc.cont_off;
   if (sc.npairs == 0) { ln.L(list) = 0.f; return 0; }
-  for (int sh = 0; sh < sc.nsh; sh++) {
+  for (int sh = 0; sh < sc.nsha; sh++) {
     const int type = sc.SI[sh * DG_SI_STRIDE + DG_SI_TYPE]; if (type == DG_SHAPE_BOX) continue;
     WShape w; shape_world(ln, sh, w); V3 e0 = w.p, e1 = w.p;
     if (type != DG_SHAPE_SPHERE) seg_ends(w, e0, e1);
@@ -1379,8 +1379,8 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   const int qenv = blockIdx.x * EPW + qe; const bool qvalid = qenv < sc.num_envs; const int qec = qvalid ? qenv : sc.num_envs - 1;
   const Lane<LANES> lq(sc, ln.mt, SLICED ? ln.lds - qlane + qe : ln.lds, SLICED ? ln.st - ln.env + qec : ln.st, SLICED ? qec : ln.env, SLICED ? qvalid : ln.valid);
   if (primary) {
-  if (index == sc.substeps - 1 && !early) for (int b = 0; b < sc.nb; b++) if (b != hb) save_prev_velocities(ln, b);
-  if (!early) for (int b = 0; b < sc.nb; b++) if (b != hb) ln.kinematics(b);
+  if (index == sc.substeps - 1 && !early) for (int b = 0; b < sc.nba; b++) if (b != hb) save_prev_velocities(ln, b);
+  if (!early) for (int b = 0; b < sc.nba; b++) if (b != hb) ln.kinematics(b);
   }
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
@@ -1390,7 +1390,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if constexpr (SLICED) ncont = (int)ln.L(sc.cont_off);
   else if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (PAR ? 64 : 0)>(ln);
   prof.stamp(PS_COLLIDE);
-  if (!early) for (int b = 0; b < sc.nb; b++) {
+  if (!early) for (int b = 0; b < sc.nba; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
     if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof);
     const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
@@ -1428,7 +1428,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   const bool vel_dense = sc.dense && sc.nt >= 1 && sc.reg_body[0] < 0;
   wave_max_cont = [&] { int m = ncont; for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o)); return m; }();
   if (vel_dense && wave_max_cont > 0)
-    for (int b = 0; b < sc.nb; b++) if (!(ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) ln.gen_vel_store(b, ln.plb(b)[PLB_DV]);
+    for (int b = 0; b < sc.nba; b++) if (!(ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) ln.gen_vel_store(b, ln.plb(b)[PLB_DV]);
   if constexpr (!SLICED) {
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
@@ -1537,7 +1537,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   auto lds_to_regs = [&](int k) { const int b = sc.reg_body[k]; if (b < 0) return; const int dvo = ln.plb(b)[PLB_DV];
     _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) rdv[k][i] = ln.L(dvo + i); };
   bool has_generic = false;
-  for (int b = 0; b < sc.nb; b++) if (ln.bi(b)[DG_BI_N_LINKS] > 0 && b != sc.reg_body[0] && b != sc.reg_body[1]) has_generic = true;
+  for (int b = 0; b < sc.nba; b++) if (ln.bi(b)[DG_BI_N_LINKS] > 0 && b != sc.reg_body[0] && b != sc.reg_body[1]) has_generic = true;
   const float thr_abs = sqrtf(thr);  // the register rows track |residual|; same test as residual^2 <= thr
   for (int it = 0; it < sc.iters; it++) {
     float maxres = 0.f, maxabs = 0.f;
@@ -1560,14 +1560,14 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
         }
       }
     }
-    if (has_generic) for (int b = 0; b < sc.nb; b++) {
+    if (has_generic) for (int b = 0; b < sc.nba; b++) {
       const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || b == sc.reg_body[0] || b == sc.reg_body[1]) continue;
       if (ln.fixed(b) && n <= 8) maxres = fmaxf(maxres, pgs_rows_small<LANES, 8, false>(ln, b, live));
       else maxres = fmaxf(maxres, pgs_rows_generic<LANES, false>(ln, b, live));
     }
     prof.stamp(PS_PGS_MOTOR);
     if (limit_mask) {
-      for (int b = 0; b < sc.nb; b++) {
+      for (int b = 0; b < sc.nba; b++) {
         const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || !((limit_mask >> (b & 63)) & 1ull)) continue;
         if (b == sc.reg_body[0]) regs_to_lds(0);
         if (b == sc.reg_body[1]) regs_to_lds(1);
@@ -1620,7 +1620,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     if (index == 0) { d[DG_DIAG_PGS_ITERS_FIRST] = iters_done; d[DG_DIAG_CONTACTS_FIRST] = ncont; }
   }
   // ---- apply velocity changes and integrate positions
-  for (int b = 0; b < sc.nb; b++) if (!(split_now && b == hb)) integrate_body(ln, b);  // split sweeps: the helper integrates its own body
+  for (int b = 0; b < sc.nba; b++) if (!(split_now && b == hb)) integrate_body(ln, b);  // split sweeps: the helper integrates its own body
   }  // primary
   if (PAR) __syncthreads();  // B3: positions integrated; the helper may start the next substep
 }
@@ -1653,7 +1653,7 @@ DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, fl
   const DevScene& sc = ln.sc;
   for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof, smem, gws, k); prof.stamp(PS_INTEGRATE); }
   if (SLICED && (int)threadIdx.x >= envs_per_wave(LANES)) return;
-  for (int b = 0; b < sc.nb; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
+  for (int b = 0; b < sc.nba; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }
 
@@ -2068,7 +2068,7 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
       ln.Sset(so + n, damp);
     }
   }
-  for (int b = 0; b < sc.nb; b++) save_prev_velocities(ln, b);  // force/torque sensors: no acceleration across a reset
+  for (int b = 0; b < sc.nba; b++) save_prev_velocities(ln, b);  // force/torque sensors: no acceleration across a reset
   ln.Sset(DG_ST_EPISODE, (float)(episode + 1ull));
 }
 

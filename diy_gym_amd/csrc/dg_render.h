@@ -133,27 +133,47 @@ __device__ unsigned long long g_render_count[16];  // diagnostic build-in counte
 #define DG_RP_CAP 1024   /* hull faces per band   */
 #define DG_RT_CAP 1024   /* hull points / box corners per band */
 enum { RL_V = 0 /* centre - eye */, RL_BOUND = 3, RL_R = 4, RL_P = 13, RL_PRM = 16, RL_STRIDE = 20 };  // floats per entry; ints alongside
-enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_STRIDE };
-DGD void ray_hull_world(V3 d, const float (*pl)[4], int np, RayHit& h, int sh) {
-  // faces as (world normal n, s = signed distance of the eye): the ray eye + t d crosses the face at t = -s / (n . d).
-  // Entry = the latest crossing of a front face (n . d < 0), exit = the earliest of a back face; a ray parallel to a
-  // face it lies outside of misses.  The entry face is tracked by index (its normal is fetched once at the end).
-  float tn = -3.0e38f, tf = 3.0e38f; int kn = 0; bool miss = np == 0;
-  for (int k = 0; k < np; k++) {
-    const float den = pl[k][0] * d.x + pl[k][1] * d.y + pl[k][2] * d.z, dist = pl[k][3];
-    const float t = -dist * __frcp_rn(den);
-    const bool par = fabsf(den) < 1e-30f, front = den < 0.f;
-    miss = miss || (par && dist > 0.f);
-    const bool later = front && !par && t > tn; tn = later ? t : tn; kn = later ? k : kn;
-    tf = (!front && !par) ? fminf(tf, t) : tf;
+enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_NOUT /* faces with the eye on their outer side: stored first */, RLI_STRIDE };
+// Two rays (the lane's two pixels) against one convex hull whose faces are (world normal n, s = signed distance of the
+// eye), the `nout` faces with the eye on their OUTER side (s > 0) first.  The ray eye + t d crosses a face at
+// t = -s / (n . d).  A ray can only ENTER through an outer-side face it approaches (n . d < 0); an outer-side face it
+// does not approach is never crossed inwards -- a miss.  So the first pass (outer-side faces) settles the entry point
+// and most misses, and the second pass (the other faces: exit = the earliest crossing with n . d > 0) is skipped by
+// the whole wavefront when no ray is still in play.  Same arithmetic and the same entry face as a single loop over
+// the faces in their original order (the partition is stable).
+DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int np, RayHit (&h)[2], int sh) {
+  float tn[2] = {-3.0e38f, -3.0e38f}, tf[2] = {3.0e38f, 3.0e38f}; int kn[2] = {0, 0}; bool miss[2] = {np == 0, np == 0};
+  for (int k = 0; k < nout; k++) {
+    const float nx = pl[k][0], ny = pl[k][1], nz = pl[k][2], dist = pl[k][3];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float den = nx * d[u].x + ny * d[u].y + nz * d[u].z, t = -dist * __frcp_rn(den);
+      const bool par = fabsf(den) < 1e-30f, front = den < 0.f && !par;
+      miss[u] = miss[u] || !front;
+      const bool later = front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k : kn[u];
+    }
   }
-  if (miss || tn > tf || tn <= 0.f || tn >= h.t) return;
-  h.t = tn; h.n = v3(pl[kn][0], pl[kn][1], pl[kn][2]); h.shape = sh;
+  bool alive[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) alive[u] = !miss[u] && tn[u] > 0.f && tn[u] < h[u].t;
+  if (!__any(alive[0] || alive[1])) return;
+  for (int k = nout; k < np; k++) {
+    const float nx = pl[k][0], ny = pl[k][1], nz = pl[k][2], dist = pl[k][3];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float den = nx * d[u].x + ny * d[u].y + nz * d[u].z, t = -dist * __frcp_rn(den);
+      const bool back = den > 0.f && !(fabsf(den) < 1e-30f);
+      tf[u] = back ? fminf(tf[u], t) : tf[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) if (alive[u] && !(tn[u] > tf[u])) { h[u].t = tn[u]; h[u].n = v3(pl[kn[u]][0], pl[kn[u]][1], pl[kn[u]][2]); h[u].shape = sh; }
 }
 __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF, cfp PLN, int cam, int ncam, cfp table, float* rgb, float* depth, int32_t* seg,
                                                       int band_rows, int nbands, int diag) {
   const int no_cull = diag & 1;  // diagnostics (DG_RENDER_DIAG): 1 test every shape for every pixel group, 2 skip every intersection, 4 skip hulls
   __shared__ float s_f[DG_RL_CAP][RL_STRIDE]; __shared__ int s_i[DG_RL_CAP][RLI_STRIDE]; __shared__ float s_pl[DG_RP_CAP][4]; __shared__ float s_pt[DG_RT_CAP][3];
+  __shared__ float s_bb[DG_RL_CAP][4];  // image-space bounds of each entry, in pixel coordinates: [c min, c max, r min, r max]
   __shared__ int s_wave_count[4]; __shared__ int s_scan[4], s_scan2[4];
   const int env = blockIdx.x / nbands, band = blockIdx.x - env * nbands, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   cip ci = CI + cam * DG_CI_STRIDE; cfp cf = CF + cam * DG_CF_STRIDE;
@@ -229,32 +249,78 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
   const bool overflow = total > DG_RL_CAP || total_planes > DG_RP_CAP || total_points > DG_RT_CAP;  // (then: the slow path below, straight from the tables)
   if (!overflow) {
     // faces of the surviving hulls and boxes -> (world normal, signed distance of the eye); one wavefront per entry at a time
+    // A point w (relative to the eye) at depth z = -rc2 . w > 0 is seen by the ray of pixel coordinates
+    // c = (x / z + kx) / sx, r = (y / z - th) / sy; a convex shape wholly in front of the eye projects inside the box of
+    // its projected vertices.  Anything that reaches behind the eye keeps an unbounded box (the tests of phase B deal
+    // with it).  Half a pixel of padding covers the rounding of the projection.
+    const float isx = 1.0f / sx, isy = 1.0f / sy, BIG = 3.0e38f;
+    auto to_c = [&](float tx) { return (tx + kx) * isx; };
+    auto to_r = [&](float ty) { return (ty - th) * isy; };  // (sy < 0: r decreases with ty)
     for (int e = wv; e < total; e += 4) {
-      const int np = s_i[e][RLI_NP]; if (np == 0) continue;
+      const int np = s_i[e][RLI_NP];
+      if (np == 0) {  // sphere / capsule: the camera-aligned cube around its bounding sphere
+        if (lane == 0) {
+          const V3 v = v3(s_f[e][RL_V], s_f[e][RL_V + 1], s_f[e][RL_V + 2]); const float Rb = s_f[e][RL_BOUND];
+          const float x = dot(rc0, v), y = dot(rc1, v), z = -dot(rc2, v);
+          float b0 = -BIG, b1 = BIG, b2 = -BIG, b3 = BIG;
+          if (z - Rb > 1e-5f) {
+            const float in = 1.0f / (z - Rb), ifar = 1.0f / (z + Rb);
+            const float xh = x + Rb, xl = x - Rb, yh = y + Rb, yl = y - Rb;
+            const float txh = xh >= 0.f ? xh * in : xh * ifar, txl = xl >= 0.f ? xl * ifar : xl * in;
+            const float tyh = yh >= 0.f ? yh * in : yh * ifar, tyl = yl >= 0.f ? yl * ifar : yl * in;
+            b0 = to_c(txl) - 0.5f; b1 = to_c(txh) + 0.5f; b2 = to_r(tyh) - 0.5f; b3 = to_r(tyl) + 0.5f;
+          }
+          s_bb[e][0] = b0; s_bb[e][1] = b1; s_bb[e][2] = b2; s_bb[e][3] = b3;
+        }
+        continue;
+      }
       const int sh = s_i[e][RLI_SHAPE], po = s_i[e][RLI_PLANE_OFF]; const bool box = s_i[e][RLI_TYPE] == DG_SHAPE_BOX;
       cfp planes = PLN + 4 * sc.SI[sh * DG_SI_STRIDE + DG_SI_PLANE_OFF];
       M3 Rl; _Pragma("unroll") for (int q = 0; q < 9; q++) Rl.m[q] = s_f[e][RL_R + q];
       const V3 ol = tmul(Rl, pc - v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]));
       bool outside = false;
-      for (int k = lane; k < np; k += 64) {
-        V3 n; float d0;
+      auto face = [&](int k, V3& n, float& dist) {
+        float d0;
         if (box) { const int ax = k >> 1; const float sg = (k & 1) ? -1.f : 1.f; n = v3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f); d0 = -s_f[e][RL_PRM + ax]; }  // face +-axis: n . x - half <= 0
         else { n = v3(planes[4 * k], planes[4 * k + 1], planes[4 * k + 2]); d0 = planes[4 * k + 3]; }
-        const float dist = dot(n, ol) + d0; const V3 nw = mul(Rl, n);
-        s_pl[po + k][0] = nw.x; s_pl[po + k][1] = nw.y; s_pl[po + k][2] = nw.z; s_pl[po + k][3] = dist;
-        outside = outside || !(dist < -1e-6f);
+        dist = dot(n, ol) + d0;
+      };
+      // stable partition: the faces that have the eye on their outer side (dist > 0) first, the others behind them
+      int nout = 0;
+      for (int k0 = 0; k0 < np; k0 += 64) { V3 n; float dist = -1.f; if (k0 + lane < np) face(k0 + lane, n, dist); nout += __popcll(__ballot(dist > 0.f)); }
+      int at_out = 0, at_in = nout;
+      for (int k0 = 0; k0 < np; k0 += 64) {
+        const bool have = k0 + lane < np; V3 n = v3(0.f, 0.f, 1.f); float dist = -1.f; if (have) face(k0 + lane, n, dist);
+        const bool out = have && dist > 0.f, in = have && !out;
+        const unsigned long long mo = __ballot(out), mi = __ballot(in), below = (1ull << lane) - 1ull;
+        if (have) {
+          const int at = out ? at_out + __popcll(mo & below) : at_in + __popcll(mi & below); const V3 nw = mul(Rl, n);
+          s_pl[po + at][0] = nw.x; s_pl[po + at][1] = nw.y; s_pl[po + at][2] = nw.z; s_pl[po + at][3] = dist;
+          outside = outside || !(dist < -1e-6f);
+        }
+        at_out += __popcll(mo); at_in += __popcll(mi);
       }
+      if (lane == 0) s_i[e][RLI_NOUT] = nout;
       // the eye inside a hull: no ray can ENTER it (ray_hull wants tn > 0); a box is entered from inside never either (ray_box: tn <= 0)
       if (!__any(outside) && !no_cull && lane == 0) s_i[e][RLI_TYPE] = -1;
       // vertices relative to the eye, for the tile-frustum test of phase B (hull points; the eight corners of a box)
       { const int npt = s_i[e][RLI_NPT], pto = s_i[e][RLI_PT_OFF]; cfp pts = sc.PF + 3 * sc.SI[sh * DG_SI_STRIDE + DG_SI_POINT_OFF];
         const V3 pl = v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]) - pc;
+        float txl = BIG, txh = -BIG, tyl = BIG, tyh = -BIG; bool behind = false;
         for (int k = lane; k < npt; k += 64) {
           V3 q;
           if (box) q = v3((k & 1) ? s_f[e][RL_PRM] : -s_f[e][RL_PRM], (k & 2) ? s_f[e][RL_PRM + 1] : -s_f[e][RL_PRM + 1], (k & 4) ? s_f[e][RL_PRM + 2] : -s_f[e][RL_PRM + 2]);
           else q = v3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
           const V3 w = pl + mul(Rl, q); s_pt[pto + k][0] = w.x; s_pt[pto + k][1] = w.y; s_pt[pto + k][2] = w.z;
-        } }
+          const float z = -dot(rc2, w); behind = behind || !(z > 1e-5f);
+          const float iz = 1.0f / fmaxf(z, 1e-5f), tx = dot(rc0, w) * iz, ty = dot(rc1, w) * iz;
+          txl = fminf(txl, tx); txh = fmaxf(txh, tx); tyl = fminf(tyl, ty); tyh = fmaxf(tyh, ty);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { txl = fminf(txl, __shfl_xor(txl, o)); txh = fmaxf(txh, __shfl_xor(txh, o)); tyl = fminf(tyl, __shfl_xor(tyl, o)); tyh = fmaxf(tyh, __shfl_xor(tyh, o)); }
+        const bool unbounded = __any(behind) || npt == 0;
+        if (lane == 0) { s_bb[e][0] = unbounded ? -BIG : to_c(txl) - 0.5f; s_bb[e][1] = unbounded ? BIG : to_c(txh) + 0.5f; s_bb[e][2] = unbounded ? -BIG : to_r(tyh) - 0.5f; s_bb[e][3] = unbounded ? BIG : to_r(tyl) + 0.5f; }
+      }
     }
     __syncthreads();
   }
@@ -288,7 +354,9 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
       V3 ev; float eb;  // culling data of entry j: from the band's list, or (overflow) straight from the table
       if (!overflow) { ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); eb = s_f[j][RL_BOUND]; }
       else { cfp s = tb + j * RS_STRIDE; ev = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; eb = s[RS_BOUND]; }
-      const bool cand = base + lane < n_entries && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
+      // the entry's image-space box against the tile's rectangle first (four compares), then the sphere-cone test
+      const bool boxed = overflow || no_cull || (s_bb[j][1] >= (float)c0 && s_bb[j][0] <= (float)min(c0 + 16, W) && s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
+      const bool cand = base + lane < n_entries && boxed && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
       for (unsigned long long mm = (diag & 2) ? 0ull : __ballot(cand); mm; mm &= mm - 1) {
         const int jj = base + __ffsll((long long)mm) - 1;  // wave-uniform
         if (!overflow) {
@@ -298,8 +366,8 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
           if ((type == DG_SHAPE_BOX || type == DG_SHAPE_POINTS) && !no_cull) {
             // separating face for the whole tile: the eye on its outer side (s > 0) and every ray of the cone moving
             // away from it or along it (n . d >= 0 for all d within the cone <=> n . axis >= sin_t for unit n)
-            const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP]; bool sep = false;
-            for (int f0 = 0; f0 < np; f0 += 64) { const int f = min(f0 + lane, np - 1); sep = sep || (s_pl[po + f][3] > 0.f && s_pl[po + f][0] * axis.x + s_pl[po + f][1] * axis.y + s_pl[po + f][2] * axis.z >= sin_t + 1e-5f); }
+            const int po = s_i[jj][RLI_PLANE_OFF], nout = s_i[jj][RLI_NOUT]; bool sep = false;  // (only a face with the eye outside can separate)
+            for (int f0 = 0; f0 < nout; f0 += 64) { const int f = min(f0 + lane, nout - 1); sep = sep || (s_pl[po + f][3] > 0.f && s_pl[po + f][0] * axis.x + s_pl[po + f][1] * axis.y + s_pl[po + f][2] * axis.z >= sin_t + 1e-5f); }
             if (__any(sep)) continue;
             DG_RCOUNT(4 + type);  // after the separating-face test
             // every vertex outside one of the tile's side planes: the whole convex shape is (lane l tests vertex l)
@@ -319,9 +387,9 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
           }
           DG_RCOUNT(12 + type);  // intersected
           if (type == DG_SHAPE_POINTS) {
-            if (!(diag & 4)) { const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP];
-#pragma unroll
-              for (int u = 0; u < 2; u++) ray_hull_world(px[u].d, &s_pl[po], np, px[u].h, k); }
+            if (!(diag & 4)) { const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP], nout = s_i[jj][RLI_NOUT];
+              const V3 dd[2] = {px[0].d, px[1].d}; RayHit hh[2] = {px[0].h, px[1].h};
+              ray_hull_world2(dd, &s_pl[po], nout, np, hh, k); px[0].h = hh[0]; px[1].h = hh[1]; }
             continue;
           }
           M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[RL_R + q];

@@ -19,8 +19,8 @@
 using namespace dg;
 
 namespace dg {
-extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_8, g_launch_table_4, g_launch_table_0, g_launch_table_g16;
-const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : lanes == 8 ? g_launch_table_8 : lanes == 4 ? g_launch_table_4 : lanes == -16 ? g_launch_table_g16 : g_launch_table_0; }
+extern const LaunchTable g_launch_table_64, g_launch_table_32, g_launch_table_16, g_launch_table_8, g_launch_table_4, g_launch_table_1, g_launch_table_0, g_launch_table_g16;
+const LaunchTable& launch_table(int lanes) { return lanes == 64 ? g_launch_table_64 : lanes == 32 ? g_launch_table_32 : lanes == 16 ? g_launch_table_16 : lanes == 8 ? g_launch_table_8 : lanes == 4 ? g_launch_table_4 : lanes == 1 ? g_launch_table_1 : lanes == -16 ? g_launch_table_g16 : g_launch_table_0; }
 }  // namespace dg
 
 static thread_local std::string g_err;
@@ -165,13 +165,22 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   slot += tr + 8;  // + padding for the chunked vector helpers
   const int total = slot;
   int lanes = 64; const int LDS_MAX = 160 * 1024;
-  if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16 || v == 8 || v == 4) lanes = v; }
+  if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16 || v == 8 || v == 4 || v == 1) lanes = v; }
   // all-dense scenes (every row indexed by global DoF, no register-chain body) can put spare lanes to work in the
   // Gauss-Seidel sweeps, so for them 8 and 4 envs per wavefront are worth having; other scenes stop at 16
   bool has_reg = false;
   for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if ((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] >= 1 && B[DG_BI_N_LINKS] <= 6) has_reg = true; }
   const bool sliceable = dense && nt >= 1 && !has_reg;
-  const int min_lanes = (sliceable && !getenv("DG_NO_NARROW_MODES")) ? 4 : 16;
+  int min_lanes = (sliceable && !getenv("DG_NO_NARROW_MODES")) ? 4 : 16;
+  // One env per wavefront: a scene whose rows do not fit the register budget of the 4-envs-per-wavefront sweeps (more than
+  // 16 links, or a contact budget above 12) at a batch that gives every SIMD at most one such wavefront -- every row of the
+  // scene then sits in registers (pgs_wave_env) and four times as many SIMDs work.  (from_the_readme at 1 024 envs: 5.6 -> 3.8 ms.)
+  if (sliceable && lanes > 1 && !getenv("DG_MAX_LANES") && !getenv("DG_NO_NARROW_MODES") && !getenv("DG_NO_WAVE_ENV") && nt <= 32 && nl <= 32 && maxc <= 32 && (nl > 16 || maxc > 12) && total * 4 <= LDS_MAX) {
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (num_envs <= 4 * prop.multiProcessorCount) lanes = 1;
+  }
+  if (lanes == 1 && !(sliceable && nt <= 32 && nl <= 32 && maxc <= 32)) lanes = 4;  // (DG_MAX_LANES=1 on a scene the mode does not hold)
+  if (sliceable && lanes == 1) min_lanes = 1;  // (asked for with DG_MAX_LANES=1, or picked above)
   while (lanes >= min_lanes && total * lanes * 4 > LDS_MAX) lanes >>= 1;
   // Latency: a big batch of a sliceable scene that still leaves most SIMDs without a wavefront (fewer than two
   // workgroups per CU) is cut into smaller workgroups -- the sweeps get more lanes per env, the rest loses nothing.

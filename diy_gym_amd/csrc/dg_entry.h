@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void step_kernel(DevScene sc, MotorTable mt, fl
   extern __shared__ float smem[];
   constexpr int ACTIVE = envs_per_wave(LANES);
   // 16 / 32 envs per wavefront: the spare lanes stay alive and join the dense Gauss-Seidel sweeps (pgs_dense_sliced)
-  constexpr bool SLICED = LANES == 32 || LANES == 16 || LANES == 8 || LANES == 4 || LANES == -16;
+  constexpr bool SLICED = LANES == 32 || LANES == 16 || LANES == 8 || LANES == 4 || LANES == 1 || LANES == -16;
   const int lane = threadIdx.x; if (!SLICED && lane >= ACTIVE) return;
   const bool primary = lane < ACTIVE;
   const int env = blockIdx.x * ACTIVE + lane; const bool valid = primary && env < sc.num_envs; const int e = env < sc.num_envs ? env : sc.num_envs - 1;

@@ -1,5 +1,5 @@
 // dg_inst.hip -- instantiates the kernels of one envs-per-wavefront mode.  Compiled several times:
-//   -DDG_LANES={64,32,16,8,4,0}  -DDG_PART=0  step kernels (+ stamped build for 64, 16 and 8)
+//   -DDG_LANES={64,32,16,8,4,1,0}  -DDG_PART=0  step kernels (+ stamped build for 64, 16 and 8)
 //                            -DDG_PART=1  reset / observe / frame / pose kernels and the mode's launch table
 //   -DDG_LANES=64            -DDG_PART=2  helper-wave step kernels
 //   -DDG_LANES=-16 -DDG_TAG=g16           the global-workspace mode with 16 envs per wavefront
@@ -17,7 +17,7 @@
 namespace dg {
 
 constexpr int L = DG_LANES;
-constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 32 || DG_LANES == 16 || DG_LANES == 8 || DG_LANES == 4 || DG_LANES == -16);
+constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 32 || DG_LANES == 16 || DG_LANES == 8 || DG_LANES == 4 || DG_LANES == 1 || DG_LANES == -16);
 
 void DGL(l_step)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, float* gws);
 hipError_t DGL(l_prepare_step)(int lds);

@@ -285,13 +285,16 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
         else { n = v3(planes[4 * k], planes[4 * k + 1], planes[4 * k + 2]); d0 = planes[4 * k + 3]; }
         dist = dot(n, ol) + d0;
       };
-      // stable partition: the faces that have the eye on their outer side (dist > 0) first, the others behind them
+      // stable partition: the faces that have the eye on their outer side first, the others behind them.  "Outer side" with
+      // the margin of the eye-inside test below: a camera mounted ON a face of its own link (from_the_readme's gripper
+      // camera) has a signed distance of +-1 ulp there, and which sign comes out must not decide whether that link hides
+      // the whole picture -- within a micrometre of a face the eye counts as behind it (fp64, the oracle, gets -0).
       int nout = 0;
-      for (int k0 = 0; k0 < np; k0 += 64) { V3 n; float dist = -1.f; if (k0 + lane < np) face(k0 + lane, n, dist); nout += __popcll(__ballot(dist > 0.f)); }
+      for (int k0 = 0; k0 < np; k0 += 64) { V3 n; float dist = -1.f; if (k0 + lane < np) face(k0 + lane, n, dist); nout += __popcll(__ballot(dist > 1e-6f)); }
       int at_out = 0, at_in = nout;
       for (int k0 = 0; k0 < np; k0 += 64) {
         const bool have = k0 + lane < np; V3 n = v3(0.f, 0.f, 1.f); float dist = -1.f; if (have) face(k0 + lane, n, dist);
-        const bool out = have && dist > 0.f, in = have && !out;
+        const bool out = have && dist > 1e-6f, in = have && !out;
         const unsigned long long mo = __ballot(out), mi = __ballot(in), below = (1ull << lane) - 1ull;
         if (have) {
           const int at = out ? at_out + __popcll(mo & below) : at_in + __popcll(mi & below); const V3 nw = mul(Rl, n);
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
     for (int u = 0; u < 2; u++) {
       if (!px[u].inside) continue;
       const RayHit& h = px[u].h;
-      const bool hit = h.shape >= 0 && h.t >= zn; const size_t o = (size_t)env * W * H + (size_t)px[u].row * W + px[u].col;
+      const bool hit = h.shape >= 0 && (h.t >= zn || (diag & 32)); const size_t o = (size_t)env * W * H + (size_t)px[u].row * W + px[u].col;
       if (depth) depth[o] = hit ? -h.t : -zf;
       if (seg) {
         int vseg = -1;

@@ -939,6 +939,138 @@ DGD bool pgs_sliced_regs_dispatch(const Lane<LANES>& ln, int ncont, int wave_max
 // solves, which requires the loop to be free of global stores (vmcnt orders loads behind them) -- so the accumulated
 // impulses, the only thing a sweep writes, live in LDS: acc[row id][env of the group].  Row ids: contact (c, d) ->
 // 3 c + d, motor of link gl -> 3 maxc + gl, limit (gl, side) -> 3 maxc + nl + 2 gl + side.
+// ---- one env per wavefront (LANES == 1): every row of the scene in registers, however many contacts ------------
+// Big scenes at a modest batch (from_the_readme: 24 DoF, 18 links, up to 32 contacts, 1 024 envs) leave most SIMDs
+// without a wavefront in the 4-envs-per-wavefront mode, and their rows do not fit that mode's register budget (every
+// lane of an env's 16-lane group carries the row scalars).  With the whole wavefront on ONE env the row scalars are
+// wave-uniform: lane k holds DoF k of every vector (two registers per contact row: J / diag and R), row r's scalars
+// (right-hand side, impulse, diagonal) live in lane r % 32 of three registers, a link's in lane gl; a row update does
+// its arithmetic in the owner lane's registers and v_readlane hands the impulse change to the other lanes.  No masks:
+// `live`, the contact count and the active joint limits are uniform, so converged envs leave the loop, absent
+// contacts are skipped by scalar branches.  Same row order and the same pre-scaled arithmetic as pgs_dense_sliced_regs.
+DGD float row_pair_sum(float x) {  // x[l] + x[l ^ 16] in every lane (v_permlane16_swap: odd rows of a <-> even rows of b; see half_swap_sum)
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+DGD float rdl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// v_writelane_b32 with a compile-time lane (this compiler has no builtin for it): lane L of v becomes the uniform value s
+template <int L> DGD float wrl(float v, float s) {
+  int si = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s));  // (already uniform: pins it in an SGPR)
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(si), "n"(L));
+  return v;
+}
+template <int I, int N, class F> DGD void static_for(F&& f) { if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); } }
+
+template <bool PROF>
+DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PROF>& prof) {
+  constexpr int NLM = 32, CM = 32;  // links / contacts with register rows (dense scenes: <= 32 DoF; max_contacts <= 32)
+  const DevScene& sc = lq.sc; const int nt = sc.nt, rs = sc.crow_tail + 3, nl = sc.nl;
+  const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
+  const int lane = threadIdx.x & 63;
+  auto sum32 = [&](float x) { return row_pair_sum(group_sum16(x)); };  // total over lanes 0..31, in each of them
+  float dv = 0.f;
+  const LinkRows<1, true> rows(lq);  // lane gl: column offset, motor row, DoF, body base / size of link gl
+  // ---- links: M^-1 column (lane k: entry of DoF k) and, in lane gl, the link's scalars
+  float lR[NLM];
+#pragma unroll
+  for (int gl = 0; gl < NLM; gl++) {
+    lR[gl] = 0.f;
+    if (gl < nl) { int col, mo, j, base, nv; float lim; rows.get(gl, col, mo, j, base, nv, lim); const float v = lq.L(col - base + min(lane, nt - 1)); lR[gl] = (lane >= base && lane < base + nv) ? v : 0.f; }
+  }
+  float ldg = 1.f, lrd = 0.f, mb = 0.f, mlim = 0.f, macc = 0.f, lb0 = 0.f, la0 = -1.f, lb1 = 0.f, la1 = -1.f;
+  if (lane < nl) {
+    ldg = lq.L(rows.col + rows.j - rows.base); lrd = frcp(ldg); mb = lq.L(rows.mo + MR_B); mlim = ((rows.motors >> lane) & 1ull) ? rows.lim : 0.f;
+    lb0 = lq.L(rows.mo + MR_LO_B); la0 = lq.L(rows.mo + MR_LO_ACC); lb1 = lq.L(rows.mo + MR_HI_B); la1 = lq.L(rows.mo + MR_HI_ACC);
+  }
+  int lj[NLM];  // DoF of link gl (uniform)
+#pragma unroll
+  for (int gl = 0; gl < NLM; gl++) lj[gl] = gl < nl ? __builtin_amdgcn_readlane(rows.j, gl) : 0;
+  // ---- contact rows: J / diag and R by DoF; scalars of row r = 3 c + d in lane r & 31 of slot r >> 5
+  float cJ[3 * CM], cR[3 * CM], cbv[3], caccv[3], cdgv[3], cmuv[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const int r = lane + 32 * s; const bool has = lane < 32 && r < 3 * ncont; const int rr = has ? r : 0, ro = sc.tr_off + rr * rs;
+    const float dg = lq.L(ro + 2 * nt + 2), rd = (has && dg > 1e-18f) ? frcp(dg) : 0.f;
+    cbv[s] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdgv[s] = has ? dg : 0.f; caccv[s] = 0.f;
+    cmuv[s] = (has && rr % 3 == 0) ? lq.L(sc.cont_off + 1 + (rr / 3) * CL_STRIDE + CL_MU) : 0.f;  // friction coefficient: with the contact's normal row
+  }
+#pragma unroll
+  for (int c = 0; c < CM; c++) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int r = 3 * c + d; cJ[r] = 0.f; cR[r] = 0.f;
+      if (c < ncont) {
+        const int ro = sc.tr_off + r * rs; const float dg = lq.L(ro + 2 * nt + 2), rd = dg > 1e-18f ? frcp(dg) : 0.f;
+        const bool in = lane < nt; const int k = min(lane, nt - 1);
+        const float jj = lq.L(ro + k), rv = lq.L(ro + nt + k);
+        cJ[r] = in ? jj * rd : 0.f; cR[r] = in ? rv : 0.f;
+      }
+    }
+  }
+  float maxres = 0.f; int iters_done = 0;
+  // the owner lane's registers hold the row's scalars; v_readlane broadcasts what the other lanes need
+  auto contact_row = [&](auto rc, float lim, bool friction) {  // row R (compile time: its registers, its owner lane); lim: friction bound
+    constexpr int R = decltype(rc)::value, o = R & 31, s = R >> 5;
+    const float jv = sum32(cJ[R] * dv);
+    const float want = caccv[s] + (cbv[s] - jv);
+    const float nacc = friction ? __builtin_amdgcn_fmed3f(want, -lim, lim) : fmaxf(want, 0.f);
+    const float dl = nacc - caccv[s];
+    const float delta = rdl(dl, o), res = rdl(dl * cdgv[s], o);
+    caccv[s] = wrl<o>(caccv[s], rdl(nacc, o));
+    dv += cR[R] * delta;
+    maxres = fmaxf(maxres, res * res);
+  };
+  for (int it = 0; it < sc.iters; it++) {
+    maxres = 0.f;
+    static_for<0, NLM>([&](auto gc) {  // motor rows, link by link (oracle order)
+      constexpr int gl = decltype(gc)::value;
+      if (gl < nl && ((rows.motors >> gl) & 1ull)) {
+        const float nacc = __builtin_amdgcn_fmed3f(macc + (mb - rdl(dv, lj[gl])) * lrd, -mlim, mlim);
+        const float dl = nacc - macc;
+        const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
+        macc = wrl<gl>(macc, rdl(nacc, gl));
+        dv += lR[gl] * delta;
+        maxres = fmaxf(maxres, res * res);
+      }
+    });
+    prof.stamp(PS_PGS_MOTOR);
+    // joint-limit rows this env has active (the flags cannot change during the sweeps): few, so a loop over the set bits
+    // with the link's M^-1 column read from LDS instead of 64 unrolled tests
+    for (uint64_t m = limit_rows; m; m &= m - 1) {
+      const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1;
+      const float sg = side == 0 ? 1.f : -1.f; float& la = side == 0 ? la0 : la1; const float lbv = side == 0 ? lb0 : lb1;
+      if (!(rdl(la, gl) >= 0.f)) continue;
+      int col, mo, j, base, nv; float lim_unused; rows.get(gl, col, mo, j, base, nv, lim_unused);
+      const float cv = lq.L(col - base + min(lane, nt - 1)), Rk = (lane >= base && lane < base + nv) ? cv : 0.f;
+      const float nacc = fmaxf(la + (lbv - sg * rdl(dv, j)) * lrd, 0.f);
+      const float dl = nacc - la;
+      const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
+      la = lane == gl ? rdl(nacc, gl) : la;
+      dv += Rk * (sg * delta);
+      maxres = fmaxf(maxres, res * res);
+    }
+    prof.stamp(PS_PGS_LIMIT);
+    // contact normals, then the friction pairs (compile-time rows: they are registers)
+    static_for<0, CM>([&](auto cc) { constexpr int C = decltype(cc)::value; if (C < ncont) contact_row(std::integral_constant<int, 3 * C>{}, 0.f, false); });
+    static_for<0, CM>([&](auto cc) {
+      constexpr int C = decltype(cc)::value, on = (3 * C) & 31, sn = (3 * C) >> 5;
+      if (C < ncont) {
+        const float lim = rdl(cmuv[sn] * caccv[sn], on);  // mu x the normal impulse just solved
+        contact_row(std::integral_constant<int, 3 * C + 1>{}, lim, true); contact_row(std::integral_constant<int, 3 * C + 2>{}, lim, true);
+      }
+    });
+    prof.stamp(PS_PGS_CONTACT);
+    iters_done = it + 1;
+    if (maxres <= thr) break;
+  }
+  if (lane < nt) lq.L(sc.dv_base + lane) = dv;
+  if (lane < nl && ((rows.motors >> lane) & 1ull)) lq.L(rows.mo + MR_ACC) = macc;  // motor impulses for the applied-torque readout
+#pragma unroll
+  for (int s = 0; s < 3; s++) { const int r = lane + 32 * s; if (lane < 32 && r < 3 * ncont) lq.L(sc.tr_off + r * rs + 2 * nt + 1) = caccv[s]; }  // contact impulses (force/torque sensor)
+  return iters_done;
+}
+
 template <int LANES, int NTB, bool PROF>
 DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, int ncont_primary, int wave_max_cont, uint64_t limit_rows, Prof<PROF>& prof) {
   static_assert(LANES == -16, "global-workspace sliced sweeps run 16 envs per wavefront");
@@ -1374,7 +1506,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   // ops; positions have not changed since the poses of the step's start were computed
   const bool early = PAR && sc.early_dyn && index == 0;
   // lane-sliced modes: this lane's env in the grouping of the sweeps (lane = env * SL + slice), see pgs_dense_sliced
-  constexpr int EPW = envs_per_wave(LANES), SLN = SLICED ? 64 / EPW : 1, SLOG = SLN == 16 ? 4 : SLN == 8 ? 3 : SLN == 4 ? 2 : SLN == 2 ? 1 : 0;
+  constexpr int EPW = envs_per_wave(LANES), SLN = SLICED ? 64 / EPW : 1, SLOG = SLN == 64 ? 6 : SLN == 16 ? 4 : SLN == 8 ? 3 : SLN == 4 ? 2 : SLN == 2 ? 1 : 0;
   const int qlane = threadIdx.x & 63, qsl = qlane & (SLN - 1), qe = qlane >> SLOG;
   const int qenv = blockIdx.x * EPW + qe; const bool qvalid = qenv < sc.num_envs; const int qec = qvalid ? qenv : sc.num_envs - 1;
   const Lane<LANES> lq(sc, ln.mt, SLICED ? ln.lds - qlane + qe : ln.lds, SLICED ? ln.st - ln.env + qec : ln.st, SLICED ? qec : ln.env, SLICED ? qvalid : ln.valid);
@@ -1477,7 +1609,9 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   }
   if (SLICED && all_dense) {
     const bool try_regs = sc.split_pgs != -1;  // (dg_world_create: DG_NO_REG_ROWS sets -1 for ablation / tests)
-    if constexpr (SLICED && LANES == 4) {  // 16 lanes per env: the padded DoF count is 16 or 32
+    if constexpr (SLICED && LANES == 1) {
+      iters_done = pgs_wave_env<PROF>(lq, __builtin_amdgcn_readfirstlane(ncont), limit_rows, prof);
+    } else if constexpr (SLICED && LANES == 4) {  // 16 lanes per env: the padded DoF count is 16 or 32
       if (sc.nt <= 16) { if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 16, PROF>(ln, ncont, wave_max_cont, limit_rows, prof); }
       else if (!(try_regs && pgs_sliced_regs_dispatch<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof, iters_done))) iters_done = pgs_dense_sliced<LANES, 32, PROF>(ln, ncont, wave_max_cont, limit_rows, prof);
     } else if constexpr (SLICED && LANES > 0) {

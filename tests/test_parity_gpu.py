@@ -258,7 +258,7 @@ def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
     # too big for 16 envs per wavefront in LDS
     gpu, cpu = make_pair('readme', 3)
-    assert gpu.sim.lanes == 4   # 4 envs per wavefront in LDS, 16 lanes share each env's rows
+    assert gpu.sim.lanes == 1   # one env per wavefront: every row of the scene in registers (a batch of at most one wavefront per SIMD)
     w = rollout(gpu, cpu, 6)
     assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
     gpu._tick += 1; cpu._tick += 1
@@ -292,6 +292,11 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3),
     ('marbles', {'DG_MAX_LANES': '8'}, 8, 100, 2e-3),
     ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
+    ('maze', {'DG_MAX_LANES': '1'}, 1, 25, 5e-3),           # one env per wavefront: every row in registers, scalars in owner lanes
+    ('readme', {'DG_MAX_LANES': '1'}, 1, 30, 2e-3),
+    ('readme', {'DG_NO_WAVE_ENV': '1'}, 4, 30, 2e-3),        # 16 lanes per env, rows streamed from LDS (the mode of batches above one wavefront per SIMD)
+    ('cart_tree', {'DG_MAX_LANES': '1'}, 1, 20, 2e-2),
+    ('marbles', {'DG_MAX_LANES': '1'}, 1, 100, 2e-3),
     ('readme', {'DG_NO_NARROW_MODES': '1'}, -16, 30, 2e-3),                              # global workspace, sliced
     ('readme', {'DG_NO_NARROW_MODES': '1', 'DG_NO_SLICED_GLOBAL': '1'}, 0, 30, 2e-3),    # global workspace, 64 envs per wavefront
     ('ur_ik', {'DG_NO_HELPER_WAVE': '1'}, 64, 30, 5e-4),    # single-wavefront step kernel

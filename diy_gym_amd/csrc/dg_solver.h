@@ -1035,21 +1035,23 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
       }
     });
     prof.stamp(PS_PGS_MOTOR);
-    // joint-limit rows this env has active (the flags cannot change during the sweeps): few, so a loop over the set bits
-    // with the link's M^-1 column read from LDS instead of 64 unrolled tests
-    for (uint64_t m = limit_rows; m; m &= m - 1) {
-      const int bit = __ffsll((long long)m) - 1, gl = bit >> 1, side = bit & 1;
-      const float sg = side == 0 ? 1.f : -1.f; float& la = side == 0 ? la0 : la1; const float lbv = side == 0 ? lb0 : lb1;
-      if (!(rdl(la, gl) >= 0.f)) continue;
-      int col, mo, j, base, nv; float lim_unused; rows.get(gl, col, mo, j, base, nv, lim_unused);
-      const float cv = lq.L(col - base + min(lane, nt - 1)), Rk = (lane >= base && lane < base + nv) ? cv : 0.f;
-      const float nacc = fmaxf(la + (lbv - sg * rdl(dv, j)) * lrd, 0.f);
-      const float dl = nacc - la;
-      const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
-      la = lane == gl ? rdl(nacc, gl) : la;
-      dv += Rk * (sg * delta);
-      maxres = fmaxf(maxres, res * res);
-    }
+    // joint-limit rows this env has active (the flags cannot change during the sweeps): one scalar test per link, the
+    // link's column and owner lane at compile time
+    if (limit_rows) static_for<0, NLM>([&](auto gc) {
+      constexpr int gl = decltype(gc)::value;
+      if (gl < nl && ((limit_rows >> (2 * gl)) & 3ull)) {
+        if (((limit_rows >> (2 * gl)) & 1ull) && rdl(la0, gl) >= 0.f) {
+          const float nacc = fmaxf(la0 + (lb0 - rdl(dv, lj[gl])) * lrd, 0.f), dl = nacc - la0;
+          const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
+          la0 = wrl<gl>(la0, rdl(nacc, gl)); dv += lR[gl] * delta; maxres = fmaxf(maxres, res * res);
+        }
+        if (((limit_rows >> (2 * gl + 1)) & 1ull) && rdl(la1, gl) >= 0.f) {
+          const float nacc = fmaxf(la1 + (lb1 + rdl(dv, lj[gl])) * lrd, 0.f), dl = nacc - la1;
+          const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
+          la1 = wrl<gl>(la1, rdl(nacc, gl)); dv -= lR[gl] * delta; maxres = fmaxf(maxres, res * res);
+        }
+      }
+    });
     prof.stamp(PS_PGS_LIMIT);
     // contact normals, then the friction pairs (compile-time rows: they are registers)
     static_for<0, CM>([&](auto cc) { constexpr int C = decltype(cc)::value; if (C < ncont) contact_row(std::integral_constant<int, 3 * C>{}, 0.f, false); });

@@ -209,7 +209,7 @@ def pmc_traffic(args, argv):
     out = {}
     base = [a for a in argv if a != '--pmc']
     inner = ['--steps', '40', '--warmup', '10', '--inner']
-    for counters in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES']):
+    for counters in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM']):
         d = tempfile.mkdtemp(prefix='dg_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
         cmd = ['rocprofv3', '--pmc'] + counters + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + inner
         try:
@@ -430,7 +430,7 @@ def run_rank(args, argv):
         else:
             kname, kms, kbytes = ('step_kernel_par' if getattr(sim, 'par', False) else 'step_kernel'), step_ms, state_bytes
         achieved = kbytes * B / (kms * 1e-3) / 1e9
-        traffic = valu_frac = wait_frac = None
+        traffic = valu_frac = wait_frac = issue = None
         if pmc:
             if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
                 traffic = (2.0 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024.0
@@ -438,6 +438,16 @@ def run_rank(args, argv):
                 valu_frac = pmc['SQ_INSTS_VALU'] * 2.0 / (SIMDS * kms * 1e-3 * CLOCK_HZ)
             if pmc.get('SQ_WAVE_CYCLES'):
                 wait_frac = pmc.get('SQ_WAIT_ANY', 0.0) / pmc['SQ_WAVE_CYCLES']
+            if pmc.get('SQ_WAVES') and 'SQ_INSTS_VALU' in pmc:
+                # the bound that applies to these kernels: one wavefront per SIMD issues one instruction per ~4.5 cycles
+                # whatever its ILP (tools/micro/valu_issue*.hip, profiles/r2_micro_valu_issue_*.txt); the kernel's time is
+                # its longest wavefront's instruction stream at that rate.  Mean over ALL wavefronts of the launch here
+                # (helper wavefronts that wait at barriers included), so 1.0 would mean every wavefront issues flat out.
+                insts = sum(pmc.get(k, 0.0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM')) / pmc['SQ_WAVES']
+                cycles = kms * 1e-3 * CLOCK_HZ
+                issue = {'bound': 'lone-wavefront instruction issue', 'instructions_per_wavefront_mean': insts, 'kernel_cycles': cycles,
+                         'cycles_per_instruction_mean': cycles / insts if insts else None, 'lone_wavefront_limit_cycles_per_instruction': 4.5,
+                         'frac': 4.5 * insts / cycles if cycles else None, 'wavefronts': pmc['SQ_WAVES']}
         out = {
             'metric': 'env steps/sec (whole node)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -453,9 +463,9 @@ def run_rank(args, argv):
                          'traffic': traffic, 'kernel': kname, 'kernel_ms': kms, 'bytes_per_env_step': kbytes,
                          'step_kernel_ms': step_ms, 'render_kernel_ms': render_ms if cameras else None,
                          'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
-                         'limiter': ('HBM image writes' if args.workload == 'from_the_readme' else
+                         'limiter': ('NOT HBM either: VALU issue of the culling and intersection tests around 655 MB of image writes per launch (DESIGN.md 6)' if args.workload == 'from_the_readme' else
                                      'NOT HBM: instruction issue and latency of one wavefront per SIMD; the hbm fraction is reported because the contract asks for it'),
-                         'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac,
+                         'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac, 'issue': issue,
                          'pmc_source': 'rocprofv3 child runs of this command, this invocation' if pmc else None},
             'solver': solver, 'aged': aged, 'api_eager': api,
         }

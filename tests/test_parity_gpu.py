@@ -254,6 +254,36 @@ def test_r2d2_maze_40_steps():
     assert np.abs(a[:, q] - b[:, q]).max() < MAZE_Q_TOL and np.abs(a[:, qd] - b[:, qd]).max() < MAZE_QD_TOL
 
 
+@pytest.mark.parametrize('env_vars,lanes', [({}, None), ({'DG_MAX_LANES': '1'}, 1), ({'DG_MAX_LANES': '16'}, 16), ({'DG_MAX_LANES': '4'}, 4)])
+def test_contact_budget_cuts_the_list_in_pair_order(env_vars, lanes):
+    """A contact budget smaller than what the scene produces (from_the_readme: 25 resting contacts, budget 7): contacts
+    beyond it are dropped IN PAIR ORDER by the oracle and by every narrow-phase variant -- the lane-sliced one tests
+    several pairs at a time and appends afterwards, so the cut must fall at the same contact.  Asserted: the contact
+    counts (all at the budget), the state and the observations over 20 steps of resting contact."""
+    import copy
+    import yaml
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
+    from oracle_backend import OracleBackend
+    import diy_gym_amd.examples  # noqa: F401
+    tree = yaml.safe_load(open(CONFIGS['readme']))
+    tree['max_contacts'] = 7
+    os.environ.update(env_vars)
+    try:
+        gpu = DIYGym(Configuration.from_dict('from_the_readme', copy.deepcopy(tree)), num_envs=5, device='cuda:0', seed=5)
+    finally:
+        for k in env_vars:
+            del os.environ[k]
+    cpu = DIYGym(Configuration.from_dict('from_the_readme', copy.deepcopy(tree)), num_envs=5, seed=5, backend_factory=OracleBackend)
+    if lanes is not None:
+        assert gpu.sim.lanes == lanes
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, 20, scale=0.2)
+    assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(5)] and int(d[:, 0].max()) == 7
+    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+
+
 def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
     # too big for 16 envs per wavefront in LDS

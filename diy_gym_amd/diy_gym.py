@@ -102,6 +102,7 @@ class DIYGym(Receptor):
         self.sim = backend_factory(self.layout, self.num_envs, device=device, seed=seed, env_index_base=env_index_base)
         self.device = self.sim.device
         self._mask = 0
+        self._staged = None   # list of (column offset, width, tensors) while step() collects the addons' actions
         self._tick = 0  # bumps whenever the simulation state changes (cameras render lazily per tick)
         self._all_slots = (1 << self.layout.n_slots) - 1 if self.layout.n_slots else 0
         self._has_hook_rewards = any(type(a).reward is not Addon.reward for a in self._hook_addons)
@@ -157,15 +158,37 @@ class DIYGym(Receptor):
         return t.reshape(1, width).expand(self.num_envs, width) if t.numel() == width else t.reshape(self.num_envs, width)
 
     def _stage_action(self, addon, action):
-        """Copy one controller addon's action into its columns of the action buffer."""
+        """One controller addon's action for its columns of the action buffer.  Inside ``step()`` the pieces are
+        collected and written by ONE concatenation into the buffer when they cover all of it (``_flush_actions``: the
+        reference's dict API then costs one small kernel per step instead of two per addon); otherwise, and outside
+        ``step()`` (an addon's ``update`` called by hand), each addon's columns are written on the spot."""
         op = addon.op
         if isinstance(action, dict):
             parts = [self._as_batch(action[k], int(np.prod(sp.shape))) for k, sp in addon.action_space.spaces.items()]
-            value = torch.cat(parts, dim=1)
         else:
-            value = self._as_batch(action, op.io_dim)
-        self.sim.act[:, op.io_off:op.io_off + op.io_dim] = value
+            parts = [self._as_batch(action, op.io_dim)]
         self._mask |= 1 << op.slot
+        if self._staged is not None:
+            self._staged.append((op.io_off, op.io_dim, parts))
+        else:
+            self.sim.act[:, op.io_off:op.io_off + op.io_dim] = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+    def _flush_actions(self):
+        staged, self._staged = self._staged, None
+        if not staged:
+            return
+        staged.sort(key=lambda t: t[0])
+        at = 0
+        for off, dim, _ in staged:
+            if off != at:
+                at = -1
+                break
+            at += dim
+        if at == self.layout.act_dim and at > 0:
+            torch.cat([p for _, _, parts in staged for p in parts], dim=1, out=self.sim.act)   # every column, in order: one kernel
+        else:
+            for off, dim, parts in staged:
+                self.sim.act[:, off:off + dim] = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
     # -------------------------------------------------------------- gym API
     def seed(self, seed=None):
@@ -222,9 +245,15 @@ class DIYGym(Receptor):
             action = unflatten(torch.as_tensor(np.asarray(action, dtype=np.float32)) if not isinstance(action, torch.Tensor)
                                else action, self.original_action_space, batch_dims=0 if self.compat else 1)
         self._mask = 0
-        for receptor_name, receptor_action in action.items():
-            for addon_name, addon_action in receptor_action.items():
-                self.receptors[receptor_name].addons[addon_name].update(addon_action)
+        self._staged = []
+        try:
+            for receptor_name, receptor_action in action.items():
+                for addon_name, addon_action in receptor_action.items():
+                    self.receptors[receptor_name].addons[addon_name].update(addon_action)
+        except BaseException:
+            self._staged = None
+            raise
+        self._flush_actions()
         self.sim.step(self._mask)
         self._tick += 1
         return self._finish_step()

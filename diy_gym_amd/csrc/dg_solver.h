@@ -944,7 +944,7 @@ DGD bool pgs_sliced_regs_dispatch(const Lane<LANES>& ln, int ncont, int wave_max
 // without a wavefront in the 4-envs-per-wavefront mode, and their rows do not fit that mode's register budget (every
 // lane of an env's 16-lane group carries the row scalars).  With the whole wavefront on ONE env the row scalars are
 // wave-uniform: lane k holds DoF k of every vector (two registers per contact row: J / diag and R), row r's scalars
-// (right-hand side, impulse, diagonal) live in lane r % 32 of three registers, a link's in lane gl; a row update does
+// (right-hand side, impulse, diagonal) live in lane 16 + r % 16 of six registers, a link's in lane gl; a row update does
 // its arithmetic in the owner lane's registers and v_readlane hands the impulse change to the other lanes.  No masks:
 // `live`, the contact count and the active joint limits are uniform, so converged envs leave the loop, absent
 // contacts are skipped by scalar branches.  Same row order and the same pre-scaled arithmetic as pgs_dense_sliced_regs.
@@ -968,7 +968,12 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   const DevScene& sc = lq.sc; const int nt = sc.nt, rs = sc.crow_tail + 3, nl = sc.nl;
   const float thr = sc.HF[DG_HF_RESIDUAL_THRESHOLD];
   const int lane = threadIdx.x & 63;
-  auto sum32 = [&](float x) { return row_pair_sum(group_sum16(x)); };  // total over lanes 0..31, in each of them
+  // total over lanes 0..31, delivered to lanes 16..31 only (where the contact rows' owner lanes are): four DPP steps within
+  // each row of 16, then row 1 adds lane 15 of row 0 (row_bcast:15, rows 1 and 3 written) -- no cross-row swap needed
+  auto sum32 = [&](float x) {
+    const float y = group_sum16(x);
+    return y + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x142, 0xA, 0xF, false));
+  };
   float dv = 0.f;
   const LinkRows<1, true> rows(lq);  // lane gl: column offset, motor row, DoF, body base / size of link gl
   // ---- links: M^-1 column (lane k: entry of DoF k) and, in lane gl, the link's scalars
@@ -987,10 +992,11 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
 #pragma unroll
   for (int gl = 0; gl < NLM; gl++) lj[gl] = gl < nl ? __builtin_amdgcn_readlane(rows.j, gl) : 0;
   // ---- contact rows: J / diag and R by DoF; scalars of row r = 3 c + d in lane r & 31 of slot r >> 5
-  float cJ[3 * CM], cR[3 * CM], cbv[3], caccv[3], cdgv[3], cmuv[3];
+  constexpr int NSL = (3 * CM + 15) / 16;  // scalar slots: row r lives in lane 16 + (r & 15) of slot r >> 4
+  float cJ[3 * CM], cR[3 * CM], cbv[NSL], caccv[NSL], cdgv[NSL], cmuv[NSL];
 #pragma unroll
-  for (int s = 0; s < 3; s++) {
-    const int r = lane + 32 * s; const bool has = lane < 32 && r < 3 * ncont; const int rr = has ? r : 0, ro = sc.tr_off + rr * rs;
+  for (int s = 0; s < NSL; s++) {
+    const int r = (lane - 16) + 16 * s; const bool has = lane >= 16 && lane < 32 && r < 3 * ncont; const int rr = has ? r : 0, ro = sc.tr_off + rr * rs;
     const float dg = lq.L(ro + 2 * nt + 2), rd = (has && dg > 1e-18f) ? frcp(dg) : 0.f;
     cbv[s] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdgv[s] = has ? dg : 0.f; caccv[s] = 0.f;
     cmuv[s] = (has && rr % 3 == 0) ? lq.L(sc.cont_off + 1 + (rr / 3) * CL_STRIDE + CL_MU) : 0.f;  // friction coefficient: with the contact's normal row
@@ -1011,7 +1017,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   float maxres = 0.f; int iters_done = 0;
   // the owner lane's registers hold the row's scalars; v_readlane broadcasts what the other lanes need
   auto contact_row = [&](auto rc, float lim, bool friction) {  // row R (compile time: its registers, its owner lane); lim: friction bound
-    constexpr int R = decltype(rc)::value, o = R & 31, s = R >> 5;
+    constexpr int R = decltype(rc)::value, o = 16 + (R & 15), s = R >> 4;
     const float jv = sum32(cJ[R] * dv);
     const float want = caccv[s] + (cbv[s] - jv);
     const float nacc = friction ? __builtin_amdgcn_fmed3f(want, -lim, lim) : fmaxf(want, 0.f);
@@ -1056,7 +1062,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
     // contact normals, then the friction pairs (compile-time rows: they are registers)
     static_for<0, CM>([&](auto cc) { constexpr int C = decltype(cc)::value; if (C < ncont) contact_row(std::integral_constant<int, 3 * C>{}, 0.f, false); });
     static_for<0, CM>([&](auto cc) {
-      constexpr int C = decltype(cc)::value, on = (3 * C) & 31, sn = (3 * C) >> 5;
+      constexpr int C = decltype(cc)::value, on = 16 + ((3 * C) & 15), sn = (3 * C) >> 4;
       if (C < ncont) {
         const float lim = rdl(cmuv[sn] * caccv[sn], on);  // mu x the normal impulse just solved
         contact_row(std::integral_constant<int, 3 * C + 1>{}, lim, true); contact_row(std::integral_constant<int, 3 * C + 2>{}, lim, true);
@@ -1069,7 +1075,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   if (lane < nt) lq.L(sc.dv_base + lane) = dv;
   if (lane < nl && ((rows.motors >> lane) & 1ull)) lq.L(rows.mo + MR_ACC) = macc;  // motor impulses for the applied-torque readout
 #pragma unroll
-  for (int s = 0; s < 3; s++) { const int r = lane + 32 * s; if (lane < 32 && r < 3 * ncont) lq.L(sc.tr_off + r * rs + 2 * nt + 1) = caccv[s]; }  // contact impulses (force/torque sensor)
+  for (int s = 0; s < NSL; s++) { const int r = (lane - 16) + 16 * s; if (lane >= 16 && lane < 32 && r < 3 * ncont) lq.L(sc.tr_off + r * rs + 2 * nt + 1) = caccv[s]; }  // contact impulses (force/torque sensor)
   return iters_done;
 }
 

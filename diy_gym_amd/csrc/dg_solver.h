@@ -353,6 +353,72 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
   }
 }
 
+// The same rows for the lanes whose contact joins two BASE shapes (no link on either side: marbles, a drone on the
+// ground, a free body on a table) in an all-dense scene, without the pair-by-pair serialisation: every table entry is
+// fetched per lane, so ONE pass serves all lanes whatever pairs they hold.  Returns whether this lane's contact was
+// such a contact (the others go through build_contact_rows, pair by pair).  Same arithmetic per row as point_row.
+template <int LANES>
+DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool vel_in_lds, int d_lo = 0, int d_hi = 3) {
+  const DevScene& sc = ln.sc;
+  if (!sc.dense) return false;
+  const int tl = sc.crow_tail, rs = crow_stride(tl), nt = sc.nt;
+  const int cc = has ? c : 0, co = sc.cont_off + 1 + cc * CL_STRIDE;
+  const int pair = has ? (int)ln.L(co + CL_PAIR) : 0;
+  const int pa = sc.PI[pair * DG_PI_STRIDE + DG_PI_A], pb = sc.PI[pair * DG_PI_STRIDE + DG_PI_B];  // (per-lane indices: vector loads)
+  const int ba = sc.SI[pa * DG_SI_STRIDE + DG_SI_BODY], la = sc.SI[pa * DG_SI_STRIDE + DG_SI_LINK], bb = sc.SI[pb * DG_SI_STRIDE + DG_SI_BODY], lb = sc.SI[pb * DG_SI_STRIDE + DG_SI_LINK];
+  const bool mine = has && la < 0 && lb < 0;
+  if (!__any(mine)) return false;
+  if (mine) {
+    const int fa = sc.BI[ba * DG_BI_STRIDE + DG_BI_FLAGS], fb = sc.BI[bb * DG_BI_STRIDE + DG_BI_FLAGS];
+    const bool a_dyn = !((fa & DG_BODY_FIXED) && sc.BI[ba * DG_BI_STRIDE + DG_BI_N_LINKS] == 0), b_dyn = !((fb & DG_BODY_FIXED) && sc.BI[bb * DG_BI_STRIDE + DG_BI_N_LINKS] == 0);
+    const V3 p = ln.L3(co + CL_P), n = ln.L3(co + CL_N); const float dist = ln.L(co + CL_DIST);
+    V3 t1, t2; tangent_basis(n, t1, t2);
+    const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
+    ln.L(co + CL_MU) = sc.SF[pa * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[pb * DG_SF_STRIDE + DG_SF_FRICTION];
+    // one side: Jacobian of the body's base coordinates, response through the first six rows of its M^-1, J . v
+    auto side = [&](int b, int flags, V3 d, int ro, float& diag, float& jv) {
+      cip P = sc.PLB + b * PLB_STRIDE; const int nv = P[PLB_NV], mo = P[PLB_MINV], dvo = P[PLB_DV], g = dvo - sc.dv_base;
+      if (flags & DG_BODY_FIXED) return;  // a base that does not move: no entries (the row stays zero there)
+      const int so = sc.BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF];
+      const M3 R0 = ln.LR(P[PLB_R0]); const V3 pos = v3(ln.S(so), ln.S(so + 1), ln.S(so + 2));
+      const V3 ja = tmul(R0, cross(p - pos, d)), jl = tmul(R0, d);
+      const float J[6] = {ja.x, ja.y, ja.z, jl.x, jl.y, jl.z};
+      ln.L3set(ro + g, ja); ln.L3set(ro + g + 3, jl);
+      for (int k = 0; k < nv; k++) {
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) r += ln.L(mo + j * nv + k) * J[j];
+        ln.L(ro + nt + g + k) = r;
+        if (k < 6) diag += r * J[k];
+      }
+      if (vel_in_lds) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) jv += J[k] * ln.L(dvo + k);
+      } else {
+        const V3 wb = tmul(R0, v3(ln.S(so + DG_BS_ANGVEL), ln.S(so + DG_BS_ANGVEL + 1), ln.S(so + DG_BS_ANGVEL + 2)));
+        const V3 vb = tmul(R0, v3(ln.S(so + DG_BS_LINVEL), ln.S(so + DG_BS_LINVEL + 1), ln.S(so + DG_BS_LINVEL + 2)));
+        jv += J[0] * wb.x + J[1] * wb.y + J[2] * wb.z + J[3] * vb.x + J[4] * vb.y + J[5] * vb.z;
+      }
+    };
+    const int b1 = a_dyn ? ba : bb, f1 = a_dyn ? fa : fb;
+    for (int d = d_lo; d < d_hi; d++) {
+      const V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
+      const int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
+      for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;
+      side(b1, f1, a_dyn ? dir : -dir, ro, diag, jv);
+      ln.L(co + CL_DVA) = (float)sc.PLB[b1 * PLB_STRIDE + PLB_DV]; ln.L(co + CL_NVA) = (float)sc.PLB[b1 * PLB_STRIDE + PLB_NV];
+      if (a_dyn && b_dyn) {
+        side(bb, fb, -dir, ro, diag, jv);
+        ln.L(co + CL_DVB) = (float)sc.PLB[bb * PLB_STRIDE + PLB_DV]; ln.L(co + CL_NVB) = (float)sc.PLB[bb * PLB_STRIDE + PLB_NV];
+      } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
+      float b = -jv;
+      if (d == 0) { const float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
+      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = 0.f; ln.L(ro + tl + 2) = diag;
+    }
+  }
+  return mine;
+}
+
 // ---- batched LDS vector helpers -------------------------------------------------------------------------
 // A single wave pays a full LDS round trip for every dependent access, so vectors of run-time length n are moved in
 // chunks of 8 independent accesses (reads past n stay inside the padded regions and are masked out).
@@ -1572,7 +1638,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if constexpr (!SLICED) {
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
-    bool todo = has;
+    bool todo = has && !build_contact_rows_base(ln, c, has, vel_dense);  // base-on-base contacts: one pass for every pair
     while (__any(todo)) {
       const int leader = __ffsll((long long)__ballot(todo)) - 1;
       const int pair = __shfl(mypair, leader);
@@ -1596,7 +1662,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     for (int c0 = 0; c0 < wmc; c0 += CPI) {
       const int c = c0 + csub; const bool has = c < ncq && d_lo < d_hi;
       const int mypair = has ? (int)lq.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
-      bool todo = has;
+      bool todo = has && !build_contact_rows_base(lq, c, has, vd, d_lo, d_hi);  // base-on-base contacts: one pass for every pair
       while (__any(todo)) {
         const int leader = __ffsll((long long)__ballot(todo)) - 1;
         const int pair = __shfl(mypair, leader);

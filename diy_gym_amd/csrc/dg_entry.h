@@ -143,11 +143,22 @@ template <int LANES>
 __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws) {
   extern __shared__ float smem[];
   constexpr int ACTIVE = envs_per_wave(LANES);
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
-  const int env = blockIdx.x * ACTIVE + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
-  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, valid);
+  // LDS modes with fewer than 64 envs per wavefront: the hot-start steps run the lane-sliced step (narrow phase, row
+  // construction and sweeps shared by the lanes of an env's group) exactly as step_kernel does -- one lane per env
+  // through the generic solver cost from_the_readme 16 ms per masked reset against 3.4 ms per step.  Envs of the
+  // wavefront that are NOT being reset take part with `valid` off: they compute in their (scratch) workspace and store
+  // nothing.
+  constexpr bool SLICED = LANES == 32 || LANES == 16 || LANES == 8 || LANES == 4 || LANES == 1;
+  const int lane = threadIdx.x; if (!SLICED && lane >= ACTIVE) return;
+  const bool primary = lane < ACTIVE;
+  const int env = blockIdx.x * ACTIVE + lane; const bool valid = primary && env < sc.num_envs; const int e = env < sc.num_envs ? env : sc.num_envs - 1;
   const bool doit = valid && (mask == nullptr || mask[e] != 0);
-  if (doit) {
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, SLICED ? doit : valid);
+  if constexpr (SLICED) {
+    if (doit) { ln.Sset(DG_ST_STEP, 0.0f); run_reset_ops(ln); }
+    if (__any(doit)) { Prof<false> prof; for (int k = 0; k < sc.hot_start; k++) sim_step<LANES, false, false, true, false>(ln, nullptr, prof, smem, gws); }
+    if (!primary) return;
+  } else if (doit) {
     ln.Sset(DG_ST_STEP, 0.0f);
     run_reset_ops(ln);
     Prof<false> prof;

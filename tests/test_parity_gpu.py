@@ -284,6 +284,33 @@ def test_contact_budget_cuts_the_list_in_pair_order(env_vars, lanes):
     assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
 
 
+@pytest.mark.parametrize('name,B,env_vars', [('maze', 19, {}), ('readme', 5, {}), ('readme', 6, {'DG_NO_WAVE_ENV': '1'}), ('marbles', 70, {})])
+def test_masked_reset_in_the_lane_sliced_modes(name, B, env_vars):
+    """reset(mask) in the modes with fewer than 64 envs per wavefront: the hot-start steps run lane-sliced, the envs of a
+    wavefront that are NOT being reset take part with their stores off.  Asserted: those envs' state is bit-identical
+    to what it was, the reset envs match the oracle's masked reset, and the rollout continues in step with the oracle."""
+    os.environ.update(env_vars)
+    try:
+        gpu, cpu = make_pair(name, B)
+    finally:
+        for k in env_vars:
+            del os.environ[k]
+    assert gpu.sim.lanes in (32, 16, 8, 4, 1)
+    scale = 10.0 if name == 'maze' else 0.3
+    rollout(gpu, cpu, 8, scale=scale)
+    mask = torch.zeros(B, dtype=torch.uint8); mask[1::3] = 1
+    before = np.array(gpu.sim.get_state())
+    gpu.sim.reset(mask.to(gpu.device)); cpu.sim.reset(mask)
+    after = np.array(gpu.sim.get_state())
+    keep = (mask == 0).numpy()
+    assert np.array_equal(before[keep], after[keep])           # untouched envs: not a bit changed
+    assert not np.array_equal(before[~keep], after[~keep])
+    assert np.allclose(after, cpu.sim.get_state(), rtol=3e-4, atol=2e-3), np.abs(after - cpu.sim.get_state()).max()
+    assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 2e-3
+    w = rollout(gpu, cpu, 5, scale=scale, seed=3)
+    assert w['term_mismatch'] == 0 and w['obs'] < (2e-2 if name == 'maze' else 5e-3), w
+
+
 def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
     # too big for 16 envs per wavefront in LDS

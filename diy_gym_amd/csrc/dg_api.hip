@@ -259,6 +259,16 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       plan.push_back((world || gl >= 0) ? -1 : BI[b * DG_BI_STRIDE + DG_BI_STATE_OFF]);
       plan.push_back(si[DG_SI_POINT_OFF]); plan.push_back(si[DG_SI_N_POINTS]);
     } }
+  // ancestor masks per link (body-local bits; bodies with more than 32 links get zeros and are never sliced)
+  const size_t am_off = plan.size();
+  for (int b = 0; b < nb; b++) {
+    const int32_t* B = BI + b * DG_BI_STRIDE; const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    for (int i = 0; i < n; i++) {
+      uint32_t m = 0u;
+      if (n <= 32) { m = 1u << i; const int par = LI[(first + i) * DG_LI_STRIDE + DG_LI_PARENT]; if (par >= 0) m |= (uint32_t)plan[am_off + (size_t)par]; }
+      plan.push_back((int32_t)m);
+    }
+  }
   PLB = plan.data(); PLL = plan.data() + (size_t)nb * PLB_STRIDE;  // (the appends above may have moved the vector)
   HIP_TRY(hipMalloc(&w->d_plan, sizeof(int32_t) * std::max<size_t>(plan.size(), 1))); HIP_TRY(hipMemcpy(w->d_plan, plan.data(), sizeof(int32_t) * plan.size(), hipMemcpyHostToDevice));
   // global -> constant address space: a no-op on the hardware, a promise of immutability to the compiler
@@ -268,9 +278,10 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.PI = dI + I[DG_H_OFF_PAIR_I]; sc.GI = dI + I[DG_H_OFF_GROUP_I]; sc.OI = dI + I[DG_H_OFF_OP_I]; sc.IL = dI + I[DG_H_OFF_ILIST];
   sc.BF = dF + I[DG_H_OFF_BODY_F]; sc.LF = dF + I[DG_H_OFF_LINK_F]; sc.FF = dF + I[DG_H_OFF_FRAME_F]; sc.SF = dF + I[DG_H_OFF_SHAPE_F];
   sc.PF = dF + I[DG_H_OFF_POINT_F]; sc.OF = dF + I[DG_H_OFF_OP_F]; sc.FL = dF + I[DG_H_OFF_FLIST]; sc.HF = dF;
-  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off); sc.SD = sc.PLB + sd_off;
+  sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off); sc.SD = sc.PLB + sd_off; sc.AM = sc.PLB + am_off;
   sc.nba = 0; for (int b = 0; b < nb; b++) if (!(BI[b * DG_BI_STRIDE + DG_BI_FLAGS] & DG_BODY_FROZEN)) sc.nba = b + 1;
   sc.nsha = 0; for (int s = 0; s < I[DG_H_N_SHAPES]; s++) if (I[I[DG_H_OFF_SHAPE_I] + s * DG_SI_STRIDE + DG_SI_TYPE] != DG_SHAPE_BOX) sc.nsha = s + 1;
+  sc.no_minv_slices = getenv("DG_NO_MINV_SLICES") ? 1 : 0;
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];

@@ -48,10 +48,12 @@ struct DevScene {
   int coll_split, cont2_off;  // with coll_wave: a fourth wavefront tests the second half of the pair table into its own contact list at cont2_off
   int coll_wave;  // helper-wave step kernel: a third wavefront runs the narrow phase (every moving body has register-resident dynamics)
   cfp GD;   // per pair group, device-only: [x y z reach] of a frozen static partner (reach < 0: none), see dg_world_create
+  cip AM;   // per link, device-only: bit i set = link first + i of the same body is this link or one of its ancestors (minv_sliced)
   cip SD;   // per shape, device-only: [pose slot | base position state offset or -1 | first hull point | hull points], see dg_world_create
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
   int32_t nba;  // 1 + the last body that is not frozen in the world: per-body loops of the step stop here (a maze is one robot + 120 frozen walls)
+  int32_t no_minv_slices;  // DG_NO_MINV_SLICES: the M^-1 columns stay with one lane per env (ablation / tests)
   int32_t nsha; // 1 + the last shape that is not an analytic box (the narrow phase caches a segment per round shape)
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
@@ -272,7 +274,7 @@ struct Lane {
 
   // forward dynamics of body b, velocity update, and M^-1 (packed symmetric) into the MINV region
   template <class PROF_T>
-  DGD void dynamics(int b, PROF_T& prof) const {
+  DGD void dynamics(int b, PROF_T& prof, bool skip_minv = false) const {
     cip B = bi(b); cfp Bf = bf(b);
     const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS], so = B[DG_BI_STATE_OFF];
     const bool fx = fixed(b); const float h = sc.h;
@@ -388,6 +390,7 @@ struct Lane {
       Sset(so + DG_BS_ANGVEL + 2, S(so + DG_BS_ANGVEL + 2) + h * dww.z);
     }
     prof.stamp(3 /* PS_ABA */);
+    if (skip_minv) return;  // (lane-sliced modes: minv_sliced does the columns with every lane of the env's group)
     // ---- M^-1 by unit impulse responses; column col of generalised coordinates (base 6 first when floating).
     // p (bias) reuses AW_PA, link accelerations reuse AW_V.  M^-1 is symmetric, so only its lower triangle is computed:
     // the response to an impulse on joint j is propagated inward along j's ancestors only and outward over the links
@@ -568,6 +571,78 @@ struct Lane {
     for (int i = 0; i < n; i++) r += L(jo + k + i) * S(li(first + i)[DG_LI_STATE_OFF] + DG_LS_QD);
     return r;
   }
+  // Whether minv_sliced can take body b: the free tail of the transient region (behind the body's articulated-body
+  // workspace; the contact rows that live there are built after the dynamics) must hold the private scratch of at
+  // least two lanes -- bias force, joint impulse and acceleration per link, 13 slots.  Returns the number of slices.
+  DGD int minv_slices(int b, int max_slices) const {
+    const int n = bi(b)[DG_BI_N_LINKS]; if (n < 1 || n > 32) return 0;
+    const int ns = min((sc.tr_slots - sc.ab_stride - n * AW_STRIDE) / (13 * n), max_slices);
+    return ns >= 2 ? ns : 0;
+  }
+  // M^-1 of body b by unit impulse responses (the column loop of dynamics()), the columns shared by the `ns` lanes of the
+  // env's group: lane `sl` takes columns sl, sl + ns, ...  The loops over links are wave-uniform (table lookups stay
+  // scalar); what a lane's column needs of them is a predicate -- the ancestor mask of its joint for the inward pass,
+  // i <= joint for the outward pass -- and each lane keeps bias forces, joint impulses and accelerations in its own
+  // scratch.  Same arithmetic per column as the serial loop.  Called by every lane of the wavefront with the Lane of
+  // ITS env (the grouping of the sweeps); the articulated inertias (AW_E, AW_R, AW_U, AW_D, AB_L) are read-only here.
+  DGD void minv_sliced(int b, int sl, int ns, int group) const {
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    const bool fx = fixed(b); const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV], nb6 = fx ? 0 : 6;
+    const int sb = sc.tr_off + sc.ab_stride + n * AW_STRIDE + (sl < ns ? sl : 0) * 13 * n;
+    auto sx = [&](int i) { return sb + 13 * i; };  // [bias force 6][joint impulse][acceleration 6] of link i, this lane's
+    float Lb[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) Lb[k] = fx ? 0.f : L(ab() + AB_L + k);
+    for (int c0 = 0; c0 < nv; c0 += ns) {
+      const int col = c0 + sl; const bool act = sl < ns && col < nv; const int jdof = act ? col - nb6 : -1;
+      const unsigned anc = jdof >= 0 ? (unsigned)sc.AM[first + jdof] : 0u;  // ancestors-or-self of the driven joint, body-local bits
+      S6 p0 = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (act) for (int i = 0; i < n; i++) { S6 z = {v3(0, 0, 0), v3(0, 0, 0)}; L6set(sx(i), z); L(sx(i) + 6) = 0.0f; }
+      for (int i = n - 1; i >= 0; i--) {  // inward along each lane's own path
+        const bool on = (anc >> i) & 1u;
+        if (!__any(on)) continue;
+        const int gl = first + i, par = li(gl)[DG_LI_PARENT], o = aw(i);
+        if (on) {
+          const S6 p = L6(sx(i)); const S6 Sx = subspace(gl);
+          const float u = (i == jdof ? 1.0f : 0.0f) - dot(Sx, p);
+          L(sx(i) + 6) = u;
+          if (par >= 0 || !fx) {
+            const S6 pa = p + L6(o + AW_U) * (u / L(o + AW_D));
+            const S6 pf = xforce_to_parent(LM(o + AW_E), L3(o + AW_R), pa);
+            if (par < 0) p0 = p0 + pf; else L6add(sx(par - first), pf);
+          }
+        }
+      }
+      S6 a0c = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (!fx) {
+        float rhs[6] = {-p0.a.x, -p0.a.y, -p0.a.z, -p0.l.x, -p0.l.y, -p0.l.z}, x[6];
+        if (jdof < 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) rhs[k] = (k == col) ? 1.0f : 0.0f;
+        }
+        chol6_solve(Lb, rhs, x);
+        a0c.a = v3(x[0], x[1], x[2]); a0c.l = v3(x[3], x[4], x[5]);
+        if (act) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) L(mo + col * nv + k) = x[k];
+        }
+      }
+      for (int i = 0; i < n; i++) {  // outward over the links up to each lane's joint (none for a base column)
+        const bool on = act && i <= jdof;
+        if (!__any(on)) break;
+        const int gl = first + i, par = li(gl)[DG_LI_PARENT], o = aw(i);
+        if (on) {
+          const S6 ap = par < 0 ? a0c : L6(sx(par - first) + 7);
+          const S6 a1 = xmotion(LM(o + AW_E), L3(o + AW_R), ap);
+          const float qdd = (L(sx(i) + 6) - dot(L6(o + AW_U), a1)) / L(o + AW_D);
+          L6set(sx(i) + 7, a1 + subspace(gl) * qdd);
+          L(mo + col * nv + nb6 + i) = qdd;
+        }
+      }
+    }
+    for (int r = sl; r < nv; r += group) for (int c = r + 1; c < nv; c++) L(mo + r * nv + c) = L(mo + c * nv + r);  // mirror the lower triangle
+  }
+
   // Jacobian (into jo) and response M^-1 J^T (into ro) of body b for a unit force along world direction
   // dir at world point p on link gl (-1 base).  Returns J M^-1 J^T.
   DGD float point_row(int b, int gl, V3 p, V3 dir, int jo, int ro) const {

@@ -1591,17 +1591,24 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (PAR) __syncthreads();  // B1: every pose is in LDS
   prof.stamp(PS_KIN);
   if constexpr (SLICED) collide<LANES, 64, SLN>(lq, 0, 0x7fffffff, -1, qsl);  // every lane: the env's group shares the pairs
-  if (primary) {
   const bool own_collide = !(PAR && sc.coll_wave);  // else the third wavefront is doing it right now
+  if (primary) {
   if constexpr (SLICED) ncont = (int)ln.L(sc.cont_off);
   else if (own_collide) ncont = collide<LANES, FULLWAVE ? 64 : (PAR ? 64 : 0)>(ln);
   prof.stamp(PS_COLLIDE);
+  }  // primary
   if (!early) for (int b = 0; b < sc.nba; b++) {
     if (b == hb || (ln.fixed(b) && ln.bi(b)[DG_BI_N_LINKS] == 0)) continue;
-    if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof);
-    const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
-    for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+    // lane-sliced modes: the M^-1 columns of a tree body are shared by the lanes of the env's group (minv_sliced)
+    const int mslices = (SLICED && !ln.plb(b)[PLB_CHAIN] && !sc.no_minv_slices) ? ln.minv_slices(b, SLN) : 0;
+    if (primary) { if (ln.plb(b)[PLB_CHAIN]) ln.template dynamics_chain<6>(b, prof); else ln.dynamics(b, prof, mslices > 0); }
+    if constexpr (SLICED) { if (mslices > 0) { lq.minv_sliced(b, qsl, mslices, SLN); prof.stamp(4 /* PS_MINV */); } }
+    if (primary) {
+      const int dvo = ln.plb(b)[PLB_DV], nv = ln.plb(b)[PLB_NV];
+      for (int k = 0; k < nv; k++) ln.L(dvo + k) = 0.f;
+    }
   }
+  if (primary) {
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
   if (!own_collide) {
     ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront(s) before B2

@@ -349,6 +349,7 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3),
     ('marbles', {'DG_MAX_LANES': '8'}, 8, 100, 2e-3),
     ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
+    ('maze', {'DG_MAX_LANES': '4', 'DG_NO_MINV_SLICES': '1'}, 4, 25, 5e-3),   # M^-1 columns by one lane per env (they are shared by the group's lanes otherwise)
     ('maze', {'DG_MAX_LANES': '1'}, 1, 25, 5e-3),           # one env per wavefront: every row in registers, scalars in owner lanes
     ('readme', {'DG_MAX_LANES': '1'}, 1, 30, 2e-3),
     ('readme', {'DG_NO_WAVE_ENV': '1'}, 4, 30, 2e-3),        # 16 lanes per env, rows streamed from LDS (the mode of batches above one wavefront per SIMD)

@@ -1042,21 +1042,30 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   };
   float dv = 0.f;
   const LinkRows<1, true> rows(lq);  // lane gl: column offset, motor row, DoF, body base / size of link gl
-  // ---- links: M^-1 column (lane k: entry of DoF k) and, in lane gl, the link's scalars
-  float lR[NLM];
-#pragma unroll
-  for (int gl = 0; gl < NLM; gl++) {
-    lR[gl] = 0.f;
-    if (gl < nl) { int col, mo, j, base, nv; float lim; rows.get(gl, col, mo, j, base, nv, lim); const float v = lq.L(col - base + min(lane, nt - 1)); lR[gl] = (lane >= base && lane < base + nv) ? v : 0.f; }
-  }
+  // ---- links, keyed by their DoF: the scalars of the joint that owns DoF j live in lane j -- the lane that holds
+  // dv[j], so the motor / limit residual needs no broadcast of dv -- and its M^-1 column (lane k: entry of DoF k) is
+  // register j of lRd.  DoFs ascend with the links (bodies and their links are laid out in order), so sweeping the DoFs in
+  // order is sweeping the links in order.
+  int mylink = -1;
+  for (int gl = 0; gl < nl; gl++) { if (lane == __builtin_amdgcn_readlane(rows.j, gl)) mylink = gl; }
+  const bool isj = mylink >= 0; const int ml = isj ? mylink : 0;
+  const int mcol = __shfl(rows.col, ml), mmo = __shfl(rows.mo, ml), mbase = __shfl(rows.base, ml); const float mlimv = __shfl(rows.lim, ml);
+  const bool has_motor = isj && ((rows.motors >> ml) & 1ull);
   float ldg = 1.f, lrd = 0.f, mb = 0.f, mlim = 0.f, macc = 0.f, lb0 = 0.f, la0 = -1.f, lb1 = 0.f, la1 = -1.f;
-  if (lane < nl) {
-    ldg = lq.L(rows.col + rows.j - rows.base); lrd = frcp(ldg); mb = lq.L(rows.mo + MR_B); mlim = ((rows.motors >> lane) & 1ull) ? rows.lim : 0.f;
-    lb0 = lq.L(rows.mo + MR_LO_B); la0 = lq.L(rows.mo + MR_LO_ACC); lb1 = lq.L(rows.mo + MR_HI_B); la1 = lq.L(rows.mo + MR_HI_ACC);
+  if (isj) {
+    ldg = lq.L(mcol + lane - mbase); lrd = frcp(ldg); mb = lq.L(mmo + MR_B); mlim = has_motor ? mlimv : 0.f;
+    lb0 = lq.L(mmo + MR_LO_B); la0 = lq.L(mmo + MR_LO_ACC); lb1 = lq.L(mmo + MR_HI_B); la1 = lq.L(mmo + MR_HI_ACC);
   }
-  int lj[NLM];  // DoF of link gl (uniform)
-#pragma unroll
-  for (int gl = 0; gl < NLM; gl++) lj[gl] = gl < nl ? __builtin_amdgcn_readlane(rows.j, gl) : 0;
+  const uint64_t jmask = __ballot(isj), jmotor = __ballot(has_motor);
+  const uint64_t jlo = __ballot(isj && ((limit_rows >> (2 * ml)) & 1ull) && la0 >= 0.f), jhi = __ballot(isj && ((limit_rows >> (2 * ml + 1)) & 1ull) && la1 >= 0.f);
+  float lRd[NLM];
+  static_for<0, NLM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value; lRd[j] = 0.f;
+    if ((jmask >> j) & 1ull) {
+      const int g = __builtin_amdgcn_readlane(mylink, j); int col, mo, jj, base, nv; float lim; rows.get(g, col, mo, jj, base, nv, lim);
+      const float v = lq.L(col - base + min(lane, nt - 1)); lRd[j] = (lane >= base && lane < base + nv) ? v : 0.f;
+    }
+  });
   // ---- contact rows: J / diag and R by DoF; scalars of row r = 3 c + d in lane r & 31 of slot r >> 5
   constexpr int NSL = (3 * CM + 15) / 16;  // scalar slots: row r lives in lane 16 + (r & 15) of slot r >> 4
   float cJ[3 * CM], cR[3 * CM], cbv[NSL], caccv[NSL], cdgv[NSL], cmuv[NSL];
@@ -1095,32 +1104,30 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   };
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
-    static_for<0, NLM>([&](auto gc) {  // motor rows, link by link (oracle order)
-      constexpr int gl = decltype(gc)::value;
-      if (gl < nl && ((rows.motors >> gl) & 1ull)) {
-        const float nacc = __builtin_amdgcn_fmed3f(macc + (mb - rdl(dv, lj[gl])) * lrd, -mlim, mlim);
-        const float dl = nacc - macc;
-        const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
-        macc = wrl<gl>(macc, rdl(nacc, gl));
-        dv += lR[gl] * delta;
+    static_for<0, NLM>([&](auto jc) {  // motor rows, DoF by DoF = link by link (oracle order); lane j does the arithmetic
+      constexpr int j = decltype(jc)::value;
+      if ((jmotor >> j) & 1ull) {
+        const float nacc = __builtin_amdgcn_fmed3f(macc + (mb - dv) * lrd, -mlim, mlim), dl = nacc - macc;
+        const float delta = rdl(dl, j), res = rdl(dl * ldg, j);
+        macc = wrl<j>(macc, rdl(nacc, j));
+        dv += lRd[j] * delta;
         maxres = fmaxf(maxres, res * res);
       }
     });
     prof.stamp(PS_PGS_MOTOR);
-    // joint-limit rows this env has active (the flags cannot change during the sweeps): one scalar test per link, the
-    // link's column and owner lane at compile time
-    if (limit_rows) static_for<0, NLM>([&](auto gc) {
-      constexpr int gl = decltype(gc)::value;
-      if (gl < nl && ((limit_rows >> (2 * gl)) & 3ull)) {
-        if (((limit_rows >> (2 * gl)) & 1ull) && rdl(la0, gl) >= 0.f) {
-          const float nacc = fmaxf(la0 + (lb0 - rdl(dv, lj[gl])) * lrd, 0.f), dl = nacc - la0;
-          const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
-          la0 = wrl<gl>(la0, rdl(nacc, gl)); dv += lR[gl] * delta; maxres = fmaxf(maxres, res * res);
+    // joint-limit rows this env has active (the flags cannot change during the sweeps): lower, then upper, joint by joint
+    if (jlo | jhi) static_for<0, NLM>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (((jlo | jhi) >> j) & 1ull) {
+        if ((jlo >> j) & 1ull) {
+          const float nacc = fmaxf(la0 + (lb0 - dv) * lrd, 0.f), dl = nacc - la0;
+          const float delta = rdl(dl, j), res = rdl(dl * ldg, j);
+          la0 = wrl<j>(la0, rdl(nacc, j)); dv += lRd[j] * delta; maxres = fmaxf(maxres, res * res);
         }
-        if (((limit_rows >> (2 * gl + 1)) & 1ull) && rdl(la1, gl) >= 0.f) {
-          const float nacc = fmaxf(la1 + (lb1 + rdl(dv, lj[gl])) * lrd, 0.f), dl = nacc - la1;
-          const float delta = rdl(dl, gl), res = rdl(dl * ldg, gl);
-          la1 = wrl<gl>(la1, rdl(nacc, gl)); dv -= lR[gl] * delta; maxres = fmaxf(maxres, res * res);
+        if ((jhi >> j) & 1ull) {
+          const float nacc = fmaxf(la1 + (lb1 + dv) * lrd, 0.f), dl = nacc - la1;
+          const float delta = rdl(dl, j), res = rdl(dl * ldg, j);
+          la1 = wrl<j>(la1, rdl(nacc, j)); dv -= lRd[j] * delta; maxres = fmaxf(maxres, res * res);
         }
       }
     });
@@ -1139,7 +1146,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
     if (maxres <= thr) break;
   }
   if (lane < nt) lq.L(sc.dv_base + lane) = dv;
-  if (lane < nl && ((rows.motors >> lane) & 1ull)) lq.L(rows.mo + MR_ACC) = macc;  // motor impulses for the applied-torque readout
+  if (has_motor) lq.L(mmo + MR_ACC) = macc;  // motor impulses for the applied-torque readout
 #pragma unroll
   for (int s = 0; s < NSL; s++) { const int r = (lane - 16) + 16 * s; if (lane >= 16 && lane < 32 && r < 3 * ncont) lq.L(sc.tr_off + r * rs + 2 * nt + 1) = caccv[s]; }  // contact impulses (force/torque sensor)
   return iters_done;

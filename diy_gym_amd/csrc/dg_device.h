@@ -34,7 +34,10 @@ DGD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.
 // of the 10-12 of the IEEE-rounded library expansions; <= 1 ulp on the normal-range operands of this code.
 DGD float frcp(float b) { float r = __builtin_amdgcn_rcpf(b); return fmaf(r, fmaf(-b, r, 1.0f), r); }
 DGD float frsq(float x) { float r = __builtin_amdgcn_rsqf(x); return r * fmaf(-0.5f * x * r, r, 1.5f); }
-DGD float fsqrt(float x) { return x > 0.f ? x * frsq(x) : 0.f; }
+// (v_rsq_f32 answers +inf for a DENORMAL argument and the Newton step then turns that into -inf: a squared length
+// between 1e-45 and 1e-38 -- a joint creeping at 1e-20 rad/s after a reset -- made norm() return -inf and the damping
+// term NaN.  Below 1e-30 the root is < 1e-15 and is reported as 0.)
+DGD float fsqrt(float x) { return x > 1e-30f ? x * frsq(x) : 0.f; }
 DGD float norm(V3 a) { return fsqrt(dot(a, a)); }
 
 DGD V3 mul(const M3& A, V3 b) {

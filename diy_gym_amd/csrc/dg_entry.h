@@ -155,9 +155,14 @@ __global__ __launch_bounds__(64) void reset_kernel(DevScene sc, MotorTable mt, f
   const bool doit = valid && (mask == nullptr || mask[e] != 0);
   Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + e, e, SLICED ? doit : valid);
   if constexpr (SLICED) {
+    if (sc.no_sliced_reset) {  // DG_NO_SLICED_RESET: one lane per env through the generic solver (ablation / tests)
+      if (!primary) return;
+      if (doit) { ln.Sset(DG_ST_STEP, 0.0f); run_reset_ops(ln); Prof<false> prof; for (int k = 0; k < sc.hot_start; k++) sim_step(ln, nullptr, prof); }
+    } else {
     if (doit) { ln.Sset(DG_ST_STEP, 0.0f); run_reset_ops(ln); }
     if (__any(doit)) { Prof<false> prof; for (int k = 0; k < sc.hot_start; k++) sim_step<LANES, false, false, true, false>(ln, nullptr, prof, smem, gws); }
     if (!primary) return;
+    }
   } else if (doit) {
     ln.Sset(DG_ST_STEP, 0.0f);
     run_reset_ops(ln);

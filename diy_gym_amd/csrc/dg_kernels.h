@@ -53,6 +53,7 @@ struct DevScene {
   cip PD;   // per candidate pair, device-only: first shape | second << 12 | types << 24 | swapped << 28 (canonical order)
   cip PLL;  // per link: [pose_off, mrow_off, iaacc_off]
   int32_t nba;  // 1 + the last body that is not frozen in the world: per-body loops of the step stop here (a maze is one robot + 120 frozen walls)
+  int32_t no_sliced_reset;  // DG_NO_SLICED_RESET
   int32_t no_minv_slices;  // DG_NO_MINV_SLICES: the M^-1 columns stay with one lane per env (ablation / tests)
   int32_t nsha; // 1 + the last shape that is not an analytic box (the narrow phase caches a segment per round shape)
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;

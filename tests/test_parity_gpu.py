@@ -311,6 +311,28 @@ def test_masked_reset_in_the_lane_sliced_modes(name, B, env_vars):
     assert w['term_mismatch'] == 0 and w['obs'] < (2e-2 if name == 'maze' else 5e-3), w
 
 
+def test_creeping_velocities_in_the_denormal_range_of_their_squares():
+    """A joint or base velocity of 1e-23 .. 1e-19 has a squared length that is a DENORMAL float; v_rsq_f32 answers +inf
+    for a denormal argument, and the norm() of the damping term once turned that into -inf and the step into NaN (found
+    by tools/gpu_soak_resets.py: a masked reset leaves the uncontrolled joints of R2D2 creeping at 2e-19 rad/s).
+    Asserted: such states step to finite values that match the oracle."""
+    gpu, cpu = make_pair('maze', 6)
+    st = np.array(cpu.sim.get_state())
+    L = gpu.layout
+    qd = [o + 1 for o in L.link_state_off]
+    so = L.body_state_off[[i for i in range(L.n_bodies) if L.body_n_links[i] > 0][0]]
+    for e, v in enumerate((2.168e-19, 1e-20, 3e-21, -5e-22, 1e-23, 7e-20)):
+        st[e, qd[7]] = v; st[e, qd[5]] = -0.3 * v
+        st[e, so + 7:so + 13] = 0.0
+        if e % 2:
+            st[e, so + 7] = 0.5 * v   # a creeping base as well
+    gpu.sim.set_state(st); cpu.sim.set_state(st)
+    w = rollout(gpu, cpu, 6, scale=10.0)
+    a, b = np.array(gpu.sim.get_state()), np.array(cpu.sim.get_state())
+    assert np.isfinite(a).all() and w['term_mismatch'] == 0
+    assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
+
+
 def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
     # too big for 16 envs per wavefront in LDS

@@ -56,6 +56,7 @@ struct dg_world {
   int32_t* diag = nullptr;
   unsigned long long* profile_cycles = nullptr;
   bool par = false;  // step runs as two wavefronts per workgroup (helper wave)
+  bool no_par_reset = false;  // DG_NO_PAR_RESET: masked resets through reset_kernel<64> (one wavefront, generic solver)
   float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
   ~dg_world() {  // also the clean-up of a dg_world_create that failed half way
@@ -309,7 +310,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       if (ok) { sc.helper_body = b; break; }
     }
   }
-  w->par = sc.helper_body >= 0;
+  w->par = sc.helper_body >= 0; w->no_par_reset = getenv("DG_NO_PAR_RESET") != nullptr;
   // third wavefront for the narrow phase: it uses the transient region as its shape cache while the other two run
   // dynamics, so every moving body must have the register-resident (transient-free) dynamics
   sc.coll_wave = 0;
@@ -429,7 +430,12 @@ static dim3 grid_of(const dg_world* w) { const int per = envs_per_wave(w->lanes)
 int32_t dg_world_reset(dg_world* w, float* state, const uint8_t* mask, float* obs, void* stream) {
   if (!w || !state) return fail(DG_ERR_ARG, "null argument");
   DG_ON_DEVICE(w->device);
-  launch_table(w->lanes).reset(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, state, mask, obs, w->d_gws);
+  // four-wavefront scenes with the usual single hot-start step: the reset ops and that step run in the step kernel itself
+  // (reset mode), the envs the mask does not name computing in their scratch workspace with stores off
+  if (w->par && w->sc.hot_start == 1 && !w->no_par_reset)
+    launch_table(w->lanes).step_par(grid_of(w), w->lds_bytes, (hipStream_t)stream, false, w->sc, w->mt, state, nullptr, 0ull, obs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mask, 1);
+  else
+    launch_table(w->lanes).reset(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, state, mask, obs, w->d_gws);
   HIP_TRY(hipGetLastError());
   return DG_OK;
 }
@@ -459,7 +465,7 @@ int32_t dg_world_step(dg_world* w, float* state, const float* actions, uint64_t 
   {
     const LaunchTable& lt = launch_table(w->lanes); const bool prof = w->profile_cycles != nullptr;
     if (prof && !lt.has_prof) return fail(DG_ERR_UNSUPPORTED, "in-kernel stamps are not built for this workspace mode");
-    if (w->par) lt.step_par(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles);
+    if (w->par) lt.step_par(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles, nullptr, 0);
     else lt.step(grid_of(w), w->lds_bytes, (hipStream_t)stream, prof, w->sc, w->mt, state, actions, update_mask, obs, rew, term, rew_sum, term_flag, w->diag, w->profile_cycles, w->d_gws);
     HIP_TRY(hipGetLastError());
   }

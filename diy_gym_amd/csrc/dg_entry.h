@@ -61,14 +61,22 @@ DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
 template <bool PROF>
 __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
                                                         float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
-                                                        unsigned long long* cycles) {
+                                                        unsigned long long* cycles, const uint8_t* reset_mask, int reset_mode) {
   extern __shared__ float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * 64 + lane; const bool valid = env < sc.num_envs; const int e = valid ? env : sc.num_envs - 1;
+  const int env = blockIdx.x * 64 + lane; const bool exists = env < sc.num_envs; const int e = exists ? env : sc.num_envs - 1;
+  // reset_mode (dg_world_reset of a scene with one hot-start step): the main wave runs the reset ops of the envs named by the
+  // mask, then the four wavefronts run ONE step without update ops -- the hot-start step -- in which only those envs
+  // store anything (`valid`); a workgroup without such an env leaves at once.  Every wavefront sees the same 64 envs, so
+  // the exit and the extra barrier Br below are taken by all four or by none.
+  const bool doit = exists && (!reset_mode || reset_mask == nullptr || reset_mask[e] != 0);
+  if (reset_mode && !__any(doit)) return;
+  const bool valid = reset_mode ? doit : exists;
   const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
   const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0ull; (void)t_start;
   if (wave == 3) {  // ---------------- second half of the narrow phase; in the early first substep, the dynamics of every second moving body
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    if (reset_mode) __syncthreads();  // Br: the reset ops have written the state
     DG_WAVE_STAMP(0); __syncthreads();  // B0
     if (sc.early_dyn) early_dynamics(ln, 1);
     DG_WAVE_STAMP(1); __syncthreads();  // B0'
@@ -87,6 +95,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   }
   if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    if (reset_mode) __syncthreads();  // Br
     DG_WAVE_STAMP(0); __syncthreads();  // B0
     if (sc.early_dyn) {  // first substep: narrow phase and the arms' dynamics while the first two waves run the update ops
       collide<64, 64>(ln);  // (the fourth wavefront takes every second moving body's dynamics)
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   }
   if (wave == 1) {  // ---------------- helper
     Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
+    if (reset_mode) __syncthreads();  // Br
     ln.kinematics(sc.helper_body);
     DG_WAVE_STAMP(0); __syncthreads();  // B0: every pose is in LDS
     if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1, diag);
@@ -121,11 +131,12 @@ __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable m
   }
   Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
   Prof<PROF> prof; prof.start();
+  if (reset_mode) { if (doit) { ln.Sset(DG_ST_STEP, 0.0f); run_reset_ops(ln); } __syncthreads(); }  // Br
   for (int b = 0; b < sc.nba; b++) if (b != sc.helper_body) ln.kinematics(b);
   __syncthreads();  // B0
   prof.stamp(PS_KIN);
   if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body, diag);
-  ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
+  if (!reset_mode) ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
   __syncthreads();  // B0': the helper's motor targets are in the state
   prof.stamp(PS_UPDATE);
   sim_step<64, PROF, true>(ln, diag, prof);

@@ -22,7 +22,7 @@ constexpr bool HAS_PROF = (DG_LANES == 64 || DG_LANES == 32 || DG_LANES == 16 ||
 void DGL(l_step)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, float* gws);
 hipError_t DGL(l_prepare_step)(int lds);
 #if DG_LANES == 64
-void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS);
+void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, const uint8_t* reset_mask, int reset_mode);
 hipError_t l_prepare_par_64(int lds);
 #endif
 
@@ -37,9 +37,9 @@ hipError_t DGL(l_prepare_step)(int lds) {
   return e;
 }
 #elif DG_PART == 2
-void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS) {
-  if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles);
-  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr);
+void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, const uint8_t* reset_mask, int reset_mode) {
+  if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles, reset_mask, reset_mode);
+  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr, reset_mask, reset_mode);
 }
 hipError_t l_prepare_par_64(int lds) {
   hipError_t e = hipFuncSetAttribute((const void*)step_kernel_par<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -11,7 +11,7 @@ struct LaunchTable {
   bool has_prof;
   hipError_t (*prepare)(int lds_bytes);
   void (*step)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, float* gws);
-  void (*step_par)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS);
+  void (*step_par)(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, const uint8_t* reset_mask, int reset_mode);  // reset_mode 1: masked reset + one hot-start step (mask NULL = every env)
   void (*reset)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws);
   void (*observe)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, float* gws);
   void (*frame)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws);

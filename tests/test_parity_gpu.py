@@ -284,7 +284,10 @@ def test_contact_budget_cuts_the_list_in_pair_order(env_vars, lanes):
     assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
 
 
-@pytest.mark.parametrize('name,B,env_vars', [('maze', 19, {}), ('readme', 5, {}), ('readme', 6, {'DG_NO_WAVE_ENV': '1'}), ('marbles', 70, {})])
+@pytest.mark.parametrize('name,B,env_vars', [('maze', 19, {}), ('readme', 5, {}), ('readme', 6, {'DG_NO_WAVE_ENV': '1'}), ('marbles', 70, {}),
+                                              ('maze', 19, {'DG_NO_SLICED_RESET': '1'}),
+                                              # four-wavefront scenes: reset ops + the hot-start step inside the step kernel (reset mode), and the one-wavefront reset kernel
+                                              ('ur_ik', 70, {}), ('touching', 70, {}), ('ur_ik', 70, {'DG_NO_PAR_RESET': '1'})])
 def test_masked_reset_in_the_lane_sliced_modes(name, B, env_vars):
     """reset(mask) in the modes with fewer than 64 envs per wavefront: the hot-start steps run lane-sliced, the envs of a
     wavefront that are NOT being reset take part with their stores off.  Asserted: those envs' state is bit-identical
@@ -295,7 +298,7 @@ def test_masked_reset_in_the_lane_sliced_modes(name, B, env_vars):
     finally:
         for k in env_vars:
             del os.environ[k]
-    assert gpu.sim.lanes in (32, 16, 8, 4, 1)
+    assert gpu.sim.lanes in (32, 16, 8, 4, 1) or name in ('ur_ik', 'touching')
     scale = 10.0 if name == 'maze' else 0.3
     rollout(gpu, cpu, 8, scale=scale)
     mask = torch.zeros(B, dtype=torch.uint8); mask[1::3] = 1

@@ -61,93 +61,22 @@ DGD void early_dynamics(const Lane<LANES>& ln, int parity) {
 template <bool PROF>
 __global__ __launch_bounds__(256) void step_kernel_par(DevScene sc, MotorTable mt, float* state, const float* actions, uint64_t mask,
                                                         float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, int32_t* diag,
-                                                        unsigned long long* cycles, const uint8_t* reset_mask, int reset_mode) {
-  extern __shared__ float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * 64 + lane; const bool exists = env < sc.num_envs; const int e = exists ? env : sc.num_envs - 1;
-  // reset_mode (dg_world_reset of a scene with one hot-start step): the main wave runs the reset ops of the envs named by the
-  // mask, then the four wavefronts run ONE step without update ops -- the hot-start step -- in which only those envs
-  // store anything (`valid`); a workgroup without such an env leaves at once.  Every wavefront sees the same 64 envs, so
-  // the exit and the extra barrier Br below are taken by all four or by none.
-  const bool doit = exists && (!reset_mode || reset_mask == nullptr || reset_mask[e] != 0);
-  if (reset_mode && !__any(doit)) return;
-  const bool valid = reset_mode ? doit : exists;
-  const float* act_row = actions ? actions + (size_t)e * sc.act_dim : nullptr;
-  const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0ull; (void)t_start;
-  if (wave == 3) {  // ---------------- second half of the narrow phase; in the early first substep, the dynamics of every second moving body
-    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    if (reset_mode) __syncthreads();  // Br: the reset ops have written the state
-    DG_WAVE_STAMP(0); __syncthreads();  // B0
-    if (sc.early_dyn) early_dynamics(ln, 1);
-    DG_WAVE_STAMP(1); __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) {
-      __syncthreads();  // B1
-      if (sc.coll_split && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, sc.npairs / 2, 0x7fffffff, sc.cont2_off);
-      __syncthreads();  // B2
-      if (split_decide_follow(ln, 0u, false)) __syncthreads();  // Bs: the sweeps run on the first two wavefronts
-      __syncthreads();  // B3
-    }
-    DG_WAVE_STAMP(2); __syncthreads();  // B4: every final pose is in LDS, every state row written
-    run_output_ops(ln, nullptr, (valid && rew) ? rew + (size_t)e * sc.rew_dim : nullptr, (valid && term) ? term + (size_t)e * sc.term_dim : nullptr,
-                   (valid && rew_sum) ? rew_sum + e : nullptr, (valid && term_flag) ? term_flag + e : nullptr, OUT_REW_TERM);
-    DG_WAVE_STAMP(3);
-    return;
-  }
-  if (wave == 2) {  // ---------------- narrow phase, concurrently with the two arms' dynamics (between B1 and B2)
-    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    if (reset_mode) __syncthreads();  // Br
-    DG_WAVE_STAMP(0); __syncthreads();  // B0
-    if (sc.early_dyn) {  // first substep: narrow phase and the arms' dynamics while the first two waves run the update ops
-      collide<64, 64>(ln);  // (the fourth wavefront takes every second moving body's dynamics)
-      early_dynamics(ln, 0);
-    }
-    DG_WAVE_STAMP(1); __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) {
-      __syncthreads();  // B1: every pose is in LDS
-      if (sc.coll_wave && !(sc.early_dyn && k == 0)) collide<64, 64>(ln, 0, sc.coll_split ? sc.npairs / 2 : 0x7fffffff);  // contact list + count go to LDS; the main wave reads them after B2
-      __syncthreads();  // B2
-      if (split_decide_follow(ln, false, false)) __syncthreads();  // Bs
-      __syncthreads();  // B3
-    }
-    DG_WAVE_STAMP(2); __syncthreads();  // B4
-    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_OBS_REST);
-    DG_WAVE_STAMP(3);
-    return;
-  }
-  if (wave == 1) {  // ---------------- helper
-    Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-    if (reset_mode) __syncthreads();  // Br
-    ln.kinematics(sc.helper_body);
-    DG_WAVE_STAMP(0); __syncthreads();  // B0: every pose is in LDS
-    if (act_row) run_update_ops(ln, act_row, mask, sc.helper_body, -1, diag);
-    DG_WAVE_STAMP(1); __syncthreads();  // B0'
-    for (int k = 0; k < sc.substeps; k++) helper_substep(ln, sc.early_dyn && k == 0, k == sc.substeps - 1);
-    ln.kinematics(sc.helper_body);  // final pose of its body for the outputs
-    DG_WAVE_STAMP(2); __syncthreads();  // B4
-    // its arm's joint-state observations (state reads only; the main wave skips them)
-    run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_OF, sc.helper_body);
-    DG_WAVE_STAMP(3);
-    return;
-  }
-  Lane<64> ln(sc, mt, smem + lane, state + e, e, valid);
-  Prof<PROF> prof; prof.start();
-  if (reset_mode) { if (doit) { ln.Sset(DG_ST_STEP, 0.0f); run_reset_ops(ln); } __syncthreads(); }  // Br
-  for (int b = 0; b < sc.nba; b++) if (b != sc.helper_body) ln.kinematics(b);
-  __syncthreads();  // B0
-  prof.stamp(PS_KIN);
-  if (act_row) run_update_ops(ln, act_row, mask, -1, sc.helper_body, diag);
-  if (!reset_mode) ln.Sset(DG_ST_STEP, ln.S(DG_ST_STEP) + 1.0f);
-  __syncthreads();  // B0': the helper's motor targets are in the state
-  prof.stamp(PS_UPDATE);
-  sim_step<64, PROF, true>(ln, diag, prof);
-  for (int b = 0; b < sc.nba; b++) if (b != sc.helper_body) ln.kinematics(b);
-  __syncthreads();  // B4: the helper's body too
-  prof.stamp(PS_KIN);
-  // the output phase is shared: this wave emits the joint states of its bodies, the helper its arm's, the third
-  // wavefront the other observe ops, the fourth the reward / terminal ops and the collapsed outputs
-  run_output_ops(ln, (valid && obs) ? obs + (size_t)e * sc.obs_dim : nullptr, nullptr, nullptr, nullptr, nullptr, OUT_JOINT_NOT_OF, sc.helper_body);
-  prof.stamp(PS_OUTPUT);
-  if constexpr (PROF) { if (lane == 0) for (int k = 0; k < PS_COUNT; k++) cycles[(size_t)blockIdx.x * PS_ROW + k] = prof.acc[k]; }
+                                                        unsigned long long* cycles) {
+  constexpr const uint8_t* reset_mask = nullptr;
+#define DG_PAR_RESET 0
+#include "dg_step_par_body.inc"
+#undef DG_PAR_RESET
+}
+// dg_world_reset of a four-wavefront scene with one hot-start step: the same body in reset mode, under its own name so that
+// profiles keep the step's launches and the (mostly empty) reset launches apart
+template <int HOT_START_STEPS>  // (a template so that the header can be included by every translation unit; only <1> exists)
+__global__ __launch_bounds__(256) void reset_kernel_par(DevScene sc, MotorTable mt, float* state, const uint8_t* reset_mask, float* obs) {
+  constexpr bool PROF = HOT_START_STEPS < 0;  // false (dependent on the template parameter so that the stamped branches are discarded)
+  const float* actions = nullptr; const uint64_t mask = 0ull; float* rew = nullptr; uint8_t* term = nullptr; float* rew_sum = nullptr; uint8_t* term_flag = nullptr;
+  int32_t* diag = nullptr; unsigned long long* cycles = nullptr;
+#define DG_PAR_RESET 1
+#include "dg_step_par_body.inc"
+#undef DG_PAR_RESET
 }
 
 template <int LANES>

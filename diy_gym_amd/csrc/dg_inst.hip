@@ -38,12 +38,14 @@ hipError_t DGL(l_prepare_step)(int lds) {
 }
 #elif DG_PART == 2
 void l_step_par_64(dim3 grid, int lds, hipStream_t st, bool prof, DG_STEP_PARAMS, const uint8_t* reset_mask, int reset_mode) {
-  if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles, reset_mask, reset_mode);
-  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr, reset_mask, reset_mode);
+  if (reset_mode) hipLaunchKernelGGL(reset_kernel_par<1>, grid, dim3(256), lds, st, sc, mt, state, reset_mask, obs);
+  else if (prof) hipLaunchKernelGGL(step_kernel_par<true>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, cycles);
+  else hipLaunchKernelGGL(step_kernel_par<false>, grid, dim3(256), lds, st, sc, mt, state, actions, mask, obs, rew, term, rew_sum, term_flag, diag, (unsigned long long*)nullptr);
 }
 hipError_t l_prepare_par_64(int lds) {
   hipError_t e = hipFuncSetAttribute((const void*)step_kernel_par<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)step_kernel_par<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)reset_kernel_par<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   return e;
 }
 #else  // DG_PART == 1

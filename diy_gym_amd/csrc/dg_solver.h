@@ -68,7 +68,8 @@ DGD void seg_ends(const WShape& c, V3& e0, V3& e1) {
 }
 DGD float clamp01(float t) { return fminf(fmaxf(t, 0.f), 1.f); }
 DGD V3 closest_on_seg(V3 a, V3 b, V3 p) {
-  V3 ab = b - a; float den = dot(ab, ab); float t = den > 1e-30f ? clamp01(fdiv(dot(p - a, ab), den)) : 0.f;  // (not > 0: v_rcp_f32 of a denormal is +inf) return a + ab * t;
+  // (den > 1e-30, not > 0: v_rcp_f32 of a denormal is +inf)
+  V3 ab = b - a; float den = dot(ab, ab); float t = den > 1e-30f ? clamp01(fdiv(dot(p - a, ab), den)) : 0.f; return a + ab * t;
 }
 DGD void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
   V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2; float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), sN, tN; const float eps = 1e-12f;

@@ -336,6 +336,39 @@ def test_creeping_velocities_in_the_denormal_range_of_their_squares():
     assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
 
 
+def test_marbles_against_the_wheels_of_r2d2():
+    """Sphere against capsule (closest point on a segment, then sphere-sphere): marbles dropped onto and pushed into
+    R2D2's wheels.  No other scene holds that pair of round shapes, which is how a missing `return` in closest_on_seg
+    once passed every test.  Asserted: contacts appear, counts, state and observations follow the oracle."""
+    import copy
+    import yaml
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
+    from oracle_backend import OracleBackend
+    import diy_gym_amd.examples  # noqa: F401
+    tree = yaml.safe_load(open(CONFIGS['marbles']))
+    tree['r2d2'] = {'model': 'r2d2.urdf', 'xyz': [0.0, 0.0, 0.5]}
+    tree['red_marble']['xyz'] = [0.28, 0.12, 0.25]      # beside the right front wheel
+    tree['green_marble']['xyz'] = [-0.28, 0.12, 0.25]    # beside the left front wheel
+    tree['blue_marble']['xyz'] = [0.27, -0.12, 1.2]      # falls onto the right back wheel
+    gpu = DIYGym(Configuration.from_dict('marbles_r2d2', copy.deepcopy(tree)), num_envs=7, device='cuda:0', seed=5)
+    cpu = DIYGym(Configuration.from_dict('marbles_r2d2', copy.deepcopy(tree)), num_envs=7, seed=5, backend_factory=OracleBackend)
+    d = gpu.sim.enable_diagnostics()
+    lo, hi = action_bounds(gpu)
+    gen = torch.Generator().manual_seed(2)
+    most = 0
+    for i in range(150):
+        act = lo + (hi - lo) * torch.rand((7, lo.numel()), generator=gen)
+        act[:, 0] = -abs(act[:, 0]) * 20.0   # external forces push the marbles towards the robot (x of the first force addon)
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(7)], i
+        most = max(most, int(d[:, 0].max()))
+    assert most >= 6   # wheels + body on the plane, marbles on the plane and against the robot
+    assert np.isfinite(np.array(gpu.sim.get_state())).all()
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-2
+    assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 5e-3
+
+
 def test_from_the_readme_scene_and_gripper_camera():
     # Jaco (10 DoF, joint-space DLS IK), table, 1:10 R2D2 with a 200x200 camera on its gripper tip: does not fit LDS,
     # too big for 16 envs per wavefront in LDS

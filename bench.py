@@ -364,20 +364,7 @@ def run_rank(args, argv):
 
     solver = solver_stats() if rank == 0 and not args.inner else None
 
-    # aged segment: the same loop after --age-steps more (untimed) steps of the same random-action rollout
-    aged = None
-    if args.age_steps > 0 and not args.inner:
-        for i in range(args.age_steps // R if graph is not None else 0):
-            graph.replay()
-        for i in range((args.age_steps // R) * R if graph is not None else 0, args.age_steps):
-            one_step(i)
-        el = timed(args.steps)
-        a_step_ms, a_render_ms = kernel_times(min(32, args.steps))
-        aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps, 'ms_per_step_aged': el / args.steps * 1e3,
-                'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
-                'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B,
-                'solver': solver_stats() if rank == 0 else None}
-
+    # (measured BEFORE the aged segment, so that the rates are those of the API on the same young rollout as `value`)
     # eager public-API rates: env.step() with the reference's dict actions, and with flatten_actions /
     # flatten_observations + collapsed reward / terminal (the trainer-facing fast path); auto-reset as above
     api = None
@@ -417,6 +404,20 @@ def run_rank(args, argv):
             env2.close()
         except Exception as exc:  # pragma: no cover
             api['flat_api_error'] = repr(exc)
+
+    # aged segment: the same loop after --age-steps more (untimed) steps of the same random-action rollout
+    aged = None
+    if args.age_steps > 0 and not args.inner:
+        for i in range(args.age_steps // R if graph is not None else 0):
+            graph.replay()
+        for i in range((args.age_steps // R) * R if graph is not None else 0, args.age_steps):
+            one_step(i)
+        el = timed(args.steps)
+        a_step_ms, a_render_ms = kernel_times(min(32, args.steps))
+        aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps + (105 if api else 0), 'ms_per_step_aged': el / args.steps * 1e3,
+                'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
+                'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B,
+                'solver': solver_stats() if rank == 0 else None}
 
     if rank == 0:
         total_envs = B * world

@@ -81,6 +81,8 @@ class HipBackend:
         if self.device.type != 'cuda':
             raise RuntimeError('diy_gym_amd runs on ROCm devices only, got %s' % self.device)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        # always indexed: tensors allocated on 'cuda' report 'cuda:<n>', and device('cuda') != device('cuda:0')
+        self.device = torch.device('cuda', dev_index)
         self.stride = ((self.num_envs + 63) // 64) * 64
         I, F = layout.I, layout.F
         handle = _vp()

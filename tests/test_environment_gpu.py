@@ -240,3 +240,26 @@ def test_flat_env_step_rejects_a_wrong_width():
     with pytest.raises(ValueError):
         env.sim.step(env._all_slots, torch.zeros((8, 12)))   # CPU tensor
     env.step(torch.zeros((8, 12), device='cuda:0'))
+
+
+def test_unindexed_device_string_is_accepted():
+    """DIYGym(..., device='cuda') -- no index: tensors allocated there report 'cuda:0', and device('cuda') != device('cuda:0'),
+    so the backend keeps the INDEXED device.  The flat step path, reset(mask) without a copy and render() all take
+    caller tensors through the device check."""
+    import yaml
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
+    tree = yaml.safe_load(open(os.path.join(ROOT, 'tests', 'golden', 'basic_env.yaml')))
+    tree.update(flatten_actions=True, flatten_observations=True, sum_rewards=True, terminal_if_any=True)
+    env = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=4, device='cuda')
+    assert env.device == torch.device('cuda', torch.cuda.current_device()) and env.sim.obs.device == env.device
+    act = torch.zeros((4, env.layout.act_dim), device='cuda')
+    obs, rew, term, _ = env.step(act)
+    assert obs.device == env.device
+    mask = torch.tensor([1, 0, 1, 0], dtype=torch.uint8, device='cuda')
+    before = mask.data_ptr()
+    env.reset(mask)
+    assert mask.data_ptr() == before
+    cam = [a for r in env.receptors.values() for a in r.addons.values() if hasattr(a, 'camera_index')][0]
+    out = cam.observe()
+    assert out['depth'].shape[0] == 4 and bool(torch.isfinite(out['depth']).all())

@@ -67,7 +67,7 @@ def rollout(gpu, cpu, steps, scale=1.0, seed=0):
     gen = torch.Generator().manual_seed(seed)
     lo, hi = action_bounds(gpu)
     B = gpu.num_envs
-    worst = dict(obs=0.0, rew=0.0, effort_rel=0.0, term_mismatch=0)
+    worst = dict(obs=0.0, rew=0.0, effort_rel=0.0, rew_effort_rel=0.0, rew_effort_max=0.0, term_mismatch=0)
     eo, er = effort_columns(gpu)
     ko = torch.ones(gpu.sim.obs.shape[1], dtype=torch.bool); ko[eo] = False
     kr = torch.ones(gpu.sim.rew.shape[1], dtype=torch.bool); kr[er] = False
@@ -81,6 +81,9 @@ def rollout(gpu, cpu, steps, scale=1.0, seed=0):
             worst['rew'] = max(worst['rew'], float(dr[:, kr].max()))
         if eo:
             worst['effort_rel'] = max(worst['effort_rel'], float((do[:, eo] / (1.0 + cpu.sim.obs[:, eo].abs())).max()))
+        if er:  # electricity_cost columns (reference electricity_cost.py:15-18): -sum |tau qd| k, relative like the efforts they are built from
+            worst['rew_effort_rel'] = max(worst['rew_effort_rel'], float((dr[:, er] / (1.0 + cpu.sim.rew[:, er].abs())).max()))
+            worst['rew_effort_max'] = max(worst['rew_effort_max'], float(cpu.sim.rew[:, er].abs().max()))
         worst['term_mismatch'] += int((gpu.sim.term.cpu() != cpu.sim.term).sum())
     return worst
 
@@ -221,6 +224,7 @@ def test_cart_tree_every_feature_at_pybullet_residual_threshold_30_steps():
     gpu, cpu = make_pair('cart_tree', 37)
     w = rollout(gpu, cpu, 30)
     assert w['obs'] < 2e-2 and w['rew'] < 2e-2 and w['term_mismatch'] == 0, w
+    assert w['rew_effort_rel'] < 5e-2, w   # electricity cost at the 1e-7 early-out: as loose as the efforts themselves
     assert torch.equal(gpu.sim.term_flag.cpu(), cpu.sim.term_flag)
 
 
@@ -231,6 +235,9 @@ def test_cart_tree_every_feature_converged_solver():
     gpu, cpu = make_pair('cart_tree', 37, residual_threshold=1e-13)
     w = rollout(gpu, cpu, 12)
     assert w['obs'] < 1e-3 and w['rew'] < 1e-3 and w['effort_rel'] < 2e-3 and w['term_mismatch'] == 0, w   # measured 2.8e-4, 7e-6, 1.9e-4
+    # electricity_cost (reference electricity_cost.py:15-18) on the GPU against the oracle: the column exists, is not
+    # trivially zero, and agrees as tightly as the efforts it is computed from
+    assert effort_columns(gpu)[1] and w['rew_effort_max'] > 1e-3 and w['rew_effort_rel'] < 2e-3, w
     assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < CART_STATE_TOL
 
 
@@ -376,6 +383,8 @@ def test_from_the_readme_scene_and_gripper_camera():
     assert gpu.sim.lanes == 1   # one env per wavefront: every row of the scene in registers (a batch of at most one wavefront per SIMD)
     w = rollout(gpu, cpu, 6)
     assert w['obs'] < 5e-3 and w['term_mismatch'] == 0, w
+    # lazy_robot (electricity_cost, from_the_readme.yaml:21): -sum |tau qd| over the Jaco's joints, relative like the efforts
+    assert effort_columns(gpu)[1] and w['rew_effort_max'] > 1e-4 and w['rew_effort_rel'] < 2e-2 and w['rew'] < 5e-3, w
     gpu._tick += 1; cpu._tick += 1
     g = gpu.models['r2d2'].addons['arm_camera'].observe(); c = cpu.models['r2d2'].addons['arm_camera'].observe()
     assert g['rgb'].shape == (3, 200, 200, 3) and g['depth'].shape == (3, 200, 200)
@@ -391,9 +400,13 @@ def test_from_the_readme_resting_contacts_60_steps():
     d = gpu.sim.enable_diagnostics()
     lo, hi = action_bounds(gpu)
     gen = torch.Generator().manual_seed(0)
+    _, er = effort_columns(gpu)
+    worst_power = 0.0
     for i in range(60):
         act = (lo + (hi - lo) * torch.rand((3, lo.numel()), generator=gen)) * 0.2
         gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        worst_power = max(worst_power, float(((gpu.sim.rew.cpu() - cpu.sim.rew).abs()[:, er] / (1.0 + cpu.sim.rew[:, er].abs())).max()))
+    assert er and worst_power < 2e-2, worst_power   # electricity_cost column over the whole resting rollout
     assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(3)] and int(d[:, 0].min()) >= 20
     assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-3
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 1e-4
@@ -406,6 +419,8 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('cart_tree', {'DG_MAX_LANES': '4'}, 4, 20, 2e-2),     # 16 lanes per env (row_mirror reduction)
     ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3),
     ('marbles', {'DG_MAX_LANES': '8'}, 8, 100, 2e-3),
+    ('maze', {'DG_MAX_LANES': '8'}, 8, 25, 5e-3),           # the mode dg_world_create picks for r2d2_maze at BASELINE's 4 096 envs
+    ('drone', {'DG_MAX_LANES': '32'}, 32, 40, 2e-3),        # ... and for drone_pilot at 16 384 envs
     ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
     ('maze', {'DG_MAX_LANES': '4', 'DG_NO_MINV_SLICES': '1'}, 4, 25, 5e-3),   # M^-1 columns by one lane per env (they are shared by the group's lanes otherwise)
     ('maze', {'DG_MAX_LANES': '1'}, 1, 25, 5e-3),           # one env per wavefront: every row in registers, scalars in owner lanes
@@ -588,3 +603,101 @@ def test_masked_reset_only_touches_masked_envs():
     keep = mask.numpy() == 0
     assert np.array_equal(before[keep], after[keep])
     assert np.abs(after - cpu.sim.get_state()).max() < 2e-3
+
+
+# ---- converged-solver twins of the loosely-conditioned contact scenes ---------------------------------------------------
+def _from_tree(name, tree, B, seed=5, **engine):
+    import copy
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.config import Configuration
+    from oracle_backend import OracleBackend
+    import diy_gym_amd.examples  # noqa: F401
+    gpu = DIYGym(Configuration.from_dict(name, copy.deepcopy(tree)), num_envs=B, device='cuda:0', seed=seed, engine=engine)
+    cpu = DIYGym(Configuration.from_dict(name, copy.deepcopy(tree)), num_envs=B, seed=seed, backend_factory=OracleBackend, engine=engine)
+    return gpu, cpu
+
+
+def test_r2d2_maze_converged_solver():
+    """test_r2d2_maze_40_steps with the sweeps run to convergence (residual threshold 1e-13, iteration cap 4 000 instead of
+    pybullet's 1e-7 / 150): fp32 kernel and fp64 oracle then solve the same well-posed contact problem, and a 10 % error in
+    one wheel's contact row could not hide in the tolerance: 2e-3 on the whole state (pose, twist, joint angles AND rates).
+    Wheels driven at the +-10 rad/s of the reference's example (r2d2_maze.py:14, generate_maze.py:26-35 for the scene).
+    Blind to: the choice of threshold / cap itself, hull thinning, Bullet constants from recollection."""
+    import yaml
+    tree = yaml.safe_load(open(CONFIGS['maze']))
+    tree['solver_iterations'] = 4000
+    gpu, cpu = _from_tree('r2d2_maze', tree, 19, residual_threshold=1e-13)
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, 40, scale=10.0)   # (R2D2 lands on its wheels around step 18)
+    assert w['term_mismatch'] == 0
+    assert int(d[:, 0].min()) >= 4                                   # the wheels are on the ground
+    assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(19)]
+    a, b = gpu.sim.get_state(), cpu.sim.get_state()
+    assert np.abs(a - b).max() < 2e-3, np.abs(a - b).max()
+
+
+def test_marbles_against_the_wheels_converged_solver():
+    """test_marbles_against_the_wheels_of_r2d2 with the sweeps run to convergence: 2e-3 on the whole state over the first 60
+    steps (marbles pushed into the wheels, one dropped onto a wheel), contact counts equal at every step."""
+    import yaml
+    tree = yaml.safe_load(open(CONFIGS['marbles']))
+    tree['solver_iterations'] = 2000
+    tree['r2d2'] = {'model': 'r2d2.urdf', 'xyz': [0.0, 0.0, 0.5]}
+    tree['red_marble']['xyz'] = [0.28, 0.12, 0.25]
+    tree['green_marble']['xyz'] = [-0.28, 0.12, 0.25]
+    tree['blue_marble']['xyz'] = [0.27, -0.12, 1.2]
+    gpu, cpu = _from_tree('marbles_r2d2', tree, 7, residual_threshold=1e-13)
+    d = gpu.sim.enable_diagnostics()
+    lo, hi = action_bounds(gpu)
+    gen = torch.Generator().manual_seed(2)
+    most = 0
+    for i in range(60):
+        act = lo + (hi - lo) * torch.rand((7, lo.numel()), generator=gen)
+        act[:, 0] = -abs(act[:, 0]) * 20.0
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(7)], i
+        most = max(most, int(d[:, 0].max()))
+    assert most >= 6
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-3
+    assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 2e-3
+
+
+# ---- assets and addons that only had host-side tests -------------------------------------------------------------------
+def test_ur5_with_three_finger_gripper_asset_30_steps():
+    """ur5_3f.urdf of the reference's data tree (diy_gym/data/ur5/ur5_3f.urdf): a 17-DoF fixed-base tree (arm + the robotiq
+    three-finger hand), position-controlled, no ground.  Generic articulated-body path.
+    Blind to: <mimic> joints are independent joints here as in pybullet's loader [R]."""
+    tree = {'render': False,
+            'arm': {'model': 'ur5/ur5_3f.urdf', 'use_fixed_base': True,
+                    'controller': {'addon': 'joint_controller', 'control_mode': 'position',
+                                   'joints': ['shoulder_pan_joint', 'shoulder_lift_joint', 'elbow_joint', 'wrist_1_joint', 'wrist_2_joint', 'wrist_3_joint'],
+                                   'rest_position': [0.0, -1.2, 1.5, -0.3, 1.0, 0.0]},
+                    'joints': {'addon': 'joint_state_sensor', 'include_effort': True},
+                    'tip': {'addon': 'object_state_sensor', 'target_frame': 'ee_fixed_joint'}}}
+    gpu, cpu = _from_tree('ur5_3f', tree, 5)
+    assert gpu.layout.n_links == 17
+    w = rollout(gpu, cpu, 30, scale=0.5)
+    assert w['obs'] < 2e-3 and w['effort_rel'] < 2e-2 and w['term_mismatch'] == 0, w
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+
+
+def test_spawn_multiple_scene_100_steps():
+    """spawn_multiple (reference diy_gym/addons/misc/spawn_multiple.py:6-12): three clones of a marble, each with its own
+    respawn jitter, object_state_sensor and external_force, dropped onto the plane next to each other.  Asserted against
+    the oracle: observations (per-clone columns), state, contact counts."""
+    tree = {'plane': {'model': 'grass/plane.urdf'},
+            'crowd': {'addon': 'spawn_multiple', 'num_models': 3,
+                      'ball': {'model': 'sphere2.urdf', 'scale': 0.2, 'xyz': [0, 0, 0.4], 'mass': 0.5,
+                               'jitter': {'addon': 'respawn', 'position_range': [1.5, 1.5, 0.2]},
+                               'pose': {'addon': 'object_state_sensor'},
+                               'push': {'addon': 'external_force'}}}}
+    gpu, cpu = _from_tree('crowd_env', tree, 33)
+    assert [k for k in gpu.models] == ['plane', 'ball_0', 'ball_1', 'ball_2'] and gpu.layout.act_dim == 9
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, 100)
+    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+    assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(33)] and int(d[:, 0].max()) >= 3
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    # the clones got different respawn draws
+    o = cpu.sim.obs
+    assert float((o[:, 0:2] - o[:, 3:5]).abs().max()) > 1e-2 and float((o[:, 3:5] - o[:, 6:8]).abs().max()) > 1e-2

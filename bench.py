@@ -22,7 +22,8 @@ spawns the N ranks itself (the parent never touches a GPU); under
 ``python -m torch.distributed.run`` it is a rank.
 
 Rank 0 prints ONE JSON line (schema in the task statement) with extra objects:
-``roofline`` (dominant kernel timed live with HIP events on the launch stream),
+``roofline`` (dominant kernel timed live with HIP events on the launch stream and, at N=1, by rocprofv3 child runs of
+this command that also collect the HBM / SQ counters -- ``--no-pmc`` opts out),
 ``solver`` (live Gauss-Seidel / IK iteration statistics from the kernel's
 diagnostics buffer), ``aged`` (the same timed loop after --age-steps more
 steps), ``api_eager`` and ``cpu_baseline`` (the C oracle -- a port, NOT pybullet
@@ -90,8 +91,17 @@ def launch(args, argv):
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 print('bench.py: rank %d exited with status %d; stopping the other ranks' % (r, code), file=sys.stderr)
+                deadline = time.time() + 10.0  # a rank blocked in a collective after its peer died may ignore SIGTERM
                 for o in pending:
                     procs[o].terminate()
+                for o in sorted(pending):
+                    try:
+                        procs[o].wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[o].kill()
+                        procs[o].wait()
+                pending = set()
+                break
         time.sleep(0.05)
     if args.selftest_launcher:
         import torch
@@ -162,33 +172,40 @@ def pybullet_status():
         return 'unavailable on this box'
 
 
-def cpu_baseline(cfg, act_dim, lo, hi, seconds=12.0):
-    """Times the C oracle (same algorithm, fp64) on the host cores with the same workload."""
+def cpu_baseline(cfg, act_dim, lo, hi, seconds=4.0):
+    """Times the C oracle (a port of the same algorithm, NOT pybullet) on the host cores with the same workload, as
+    SURVEY.md 8d specifies: the fp32 build on 1 core and on all cores, and the fp64 build (the parity checker) on all cores."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import oracle_backend
     from diy_gym_amd import DIYGym
-    omp = os.path.join(ROOT, 'oracle', 'libdgsim_oracle_omp.so')
     cores = usable_cores()
     os.environ['OMP_NUM_THREADS'] = str(cores)
-    if os.path.isfile(omp):
-        oracle_backend._LIB = None
-        oracle_backend.ORACLE_LIB = omp
-    else:
-        cores = 1
-    envs = 64 * cores
-    env = DIYGym(cfg, num_envs=envs, seed=1234, backend_factory=oracle_backend.OracleBackend)
-    gen = torch.Generator().manual_seed(99)
-    act = lo + (hi - lo) * torch.rand((envs, act_dim), generator=gen)
-    env.sim.step(env._all_slots, act)  # warm
-    steps, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        env.sim.step(env._all_slots, act)
-        steps += 1
-    dt = time.time() - t0
-    return {'value': envs * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d envs x %d steps of the same config in %.1f s, C oracle (fp64, OpenMP over envs); pybullet itself is %s' %
-                      (envs, steps, dt, pybullet_status())}
+
+    def rate(flavour, envs, secs):
+        factory = oracle_backend.flavour(flavour)
+        if factory is None:
+            return None
+        env = DIYGym(cfg, num_envs=envs, seed=1234, backend_factory=factory)
+        gen = torch.Generator().manual_seed(99)
+        act = lo + (hi - lo) * torch.rand((envs, act_dim), generator=gen)
+        env.sim.step(env._all_slots, act)  # warm
+        steps, t0 = 0, time.time()
+        while time.time() - t0 < secs:
+            env.sim.step(env._all_slots, act)
+            steps += 1
+        dt = time.time() - t0
+        env.close()
+        return {'value': envs * steps / dt, 'envs': envs, 'steps': steps, 'seconds': round(dt, 2)}
+
+    f32_1 = rate('f32', 64, seconds)
+    f32_n = rate('f32_omp', 64 * cores, seconds)
+    f64_n = rate('f64_omp', 64 * cores, seconds)
+    head = f32_n or f32_1 or f64_n
+    return {'value': head['value'], 'unit': 'env-steps/s', 'cores': cores if head is not f32_1 else 1, 'kind': 'port', 'nproc': os.cpu_count(),
+            'fp32_1_core': f32_1, 'fp32_all_cores': f32_n, 'fp64_all_cores': f64_n,
+            'sample': 'same config, random actions, ~%.0f s each: C oracle built as fp32 on 1 core (64 envs), fp32 with OpenMP over envs on %d cores (%d envs) '
+                      '[= value], fp64 on %d cores; pybullet itself is %s' % (seconds, cores, 64 * cores, cores, pybullet_status())}
 
 
 def quantiles(t):
@@ -198,32 +215,56 @@ def quantiles(t):
             'max': float(f.max())}
 
 
-def pmc_traffic(args, argv):
-    """--pmc: HBM bytes and VALU instructions per launch of the dominant kernel, measured NOW by running this very
-    command (fewer steps, no extra segments) under rocprofv3 in child processes, one counter pass each, before this
-    process touches the GPU.  Corrections per MI355X_MICROARCH.md (FETCH_SIZE / WRITE_SIZE in KiB; gfx950 FETCH_SIZE
-    counts half of a coalesced read)."""
+def profile_children(args, argv):
+    """N = 1, default on (``--no-pmc`` opts out): per-launch figures of the dominant kernel measured NOW by running this very
+    command (fewer steps, timed loop only) under rocprofv3 in fresh child processes -- started before this process touches
+    the GPU, ``python bench.py ...`` directly after ``--`` -- one pass each: a kernel trace (average duration), then the
+    HBM counters and the SQ counters in their own passes (never a trace and counters together).  Corrections per
+    MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950's FETCH_SIZE counts half of a coalesced read.
+    Bounded: a pass that fails or runs out of time leaves its fields null."""
     import csv
     import glob
+    import shutil
     import tempfile
-    out = {}
-    base = [a for a in argv if a != '--pmc']
+    if shutil.which('rocprofv3') is None:
+        return None
+    out, t_begin = {}, time.time()
+    skip = ('--pmc', '--no-pmc')
+    base = [a for a in argv if a not in skip]
     inner = ['--steps', '40', '--warmup', '10', '--inner']
-    for counters in (['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM']):
-        d = tempfile.mkdtemp(prefix='dg_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
-        cmd = ['rocprofv3', '--pmc'] + counters + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + inner
+    env = dict(os.environ, TMPDIR=os.environ.get('TMPDIR', '/tmp'))
+    passes = [('trace', ['--kernel-trace', '--stats']), ('fetch', ['--pmc', 'FETCH_SIZE']), ('write', ['--pmc', 'WRITE_SIZE']),
+              ('sq', ['--pmc', 'SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM'])]
+    for name, flags in passes:
+        left = args.pmc_budget - (time.time() - t_begin)
+        if left < 20:
+            print('bench.py: profiling budget (%d s) spent before the %s pass; its fields stay null' % (args.pmc_budget, name), file=sys.stderr)
+            break
+        d = tempfile.mkdtemp(prefix='dg_prof_', dir=env['TMPDIR'])
+        cmd = ['rocprofv3'] + flags + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + inner
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True, cwd='/tmp')
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left, check=True, cwd=env['TMPDIR'], env=env)
         except Exception as exc:
-            print('bench.py: rocprofv3 pass %s failed (%s); traffic stays null' % (counters, exc), file=sys.stderr)
-            return None
-        agg = {}
-        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-            for r in csv.DictReader(open(f)):
-                if args.kernel_filter in r['Kernel_Name']:
-                    agg.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-        for k, v in agg.items():
-            out[k] = sum(v) / len(v)
+            print('bench.py: rocprofv3 %s pass failed (%s); its fields stay null' % (name, type(exc).__name__), file=sys.stderr)
+            shutil.rmtree(d, ignore_errors=True)
+            continue
+        if name == 'trace':
+            for f in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if args.kernel_filter in r['Name'] and 'reset' not in r['Name']:
+                        out['trace'] = {'kernel': r['Name'].split('(')[0].replace('void ', ''), 'calls': int(r['Calls']), 'average_ns': float(r['AverageNs']),
+                                        'min_ns': float(r['MinNs']), 'max_ns': float(r['MaxNs'])}
+                        break
+        else:
+            agg = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if args.kernel_filter in r['Kernel_Name'] and 'reset' not in r['Kernel_Name']:
+                        agg.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+            for k, v in agg.items():
+                out[k] = sum(v) / len(v)
+        shutil.rmtree(d, ignore_errors=True)
+    out['seconds'] = round(time.time() - t_begin, 1)
     return out
 
 
@@ -237,9 +278,9 @@ def run_rank(args, argv):
     distributed = world > 1
 
     pmc = None
-    if args.pmc and not distributed and not args.inner:
+    if not args.no_pmc and not distributed and not args.inner:
         args.kernel_filter = 'render_kernel' if args.workload == 'from_the_readme' else 'step_kernel'
-        pmc = pmc_traffic(args, argv)  # child processes; this process has not touched the GPU yet
+        pmc = profile_children(args, argv)  # child processes; this process has not touched the GPU yet
 
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -275,23 +316,33 @@ def run_rank(args, argv):
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    # The timed region replays a hipGraph of len(ring) consecutive steps (step [+ render] + masked auto-reset each): the
-    # work is identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.2 ms kernels.
-    graph, R = None, len(ring)
+    # The timed region replays hipGraphs of consecutive steps (step [+ render] + masked auto-reset each): the work is
+    # identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.1 ms kernels.  EXACTLY --steps
+    # steps, all of them replayed: whole segments of len(ring) steps plus one shorter segment for the remainder.
+    R = len(ring)
+
+    def capture(n_steps, body):
+        cap = torch.cuda.Stream(device=device)
+        cap.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(cap):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                for i in range(n_steps):
+                    body(i)
+        torch.cuda.current_stream(device).wait_stream(cap)
+        torch.cuda.synchronize()
+        return g
+
+    graph = graph_rest = graph_kernel = None
     if not args.eager:
         try:
-            cap = torch.cuda.Stream(device=device)
-            cap.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(cap):
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=cap):
-                    for i in range(R):
-                        one_step(i)
-            torch.cuda.current_stream(device).wait_stream(cap)
-            torch.cuda.synchronize()
+            graph = capture(R, one_step)
+            if args.steps % R:
+                graph_rest = capture(args.steps % R, one_step)
+            graph_kernel = capture(R, lambda i: sim.step(slots, ring[i % R]))  # the step kernel alone, for kernel_times()
         except Exception as exc:  # pragma: no cover
             print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
-            graph = None
+            graph = graph_rest = graph_kernel = None
 
     def timed(steps):
         torch.cuda.synchronize()
@@ -299,13 +350,14 @@ def run_rank(args, argv):
             dist.barrier()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        done = 0
         if graph is not None:
             for _ in range(steps // R):
                 graph.replay()
-            done = (steps // R) * R
-        for i in range(done, steps):
-            one_step(i)
+            if steps % R:
+                graph_rest.replay()
+        else:
+            for i in range(steps):
+                one_step(i)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -321,9 +373,10 @@ def run_rank(args, argv):
     episodes_main = float(sim.state[1, :B].sum().item()) - B  # DG_ST_EPISODE summed over envs
 
     def kernel_times(n):
-        """Average duration of the dominant kernel(s): HIP events around the launches, on the launch stream (torch's
-        current stream IS the stream the C-ABI launches on), same inputs; events cannot be recorded per launch inside
-        a replayed graph, so this runs right after the timed region."""
+        """Average duration of the dominant kernel(s) by HIP events on the launch stream (torch's current stream IS the
+        stream the C-ABI launches on), same inputs, right after the timed region.  The step kernel: events around
+        replays of a graph of len(ring) back-to-back step launches (no host launch gaps inside); eager launches
+        bracketed one by one -- launch overhead included -- are reported next to it.  The render kernel: eager."""
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
         for i in range(n):
             ev[i][0].record()
@@ -335,9 +388,23 @@ def run_rank(args, argv):
             if auto_reset:
                 sim.reset(sim.term_flag)
         torch.cuda.synchronize()
-        return (float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])))
+        eager = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        render = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        replayed = None
+        if graph_kernel is not None:
+            reps = max(1, n // R)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(reps):
+                graph_kernel.replay()
+            g1.record()
+            torch.cuda.synchronize()
+            replayed = g0.elapsed_time(g1) / (reps * R)
+            if auto_reset:
+                sim.reset(sim.term_flag)
+        return (replayed if replayed is not None else eager), render, eager
 
-    step_ms, render_ms = kernel_times(min(64, args.steps))
+    step_ms, render_ms, step_eager_ms = kernel_times(max(R, min(64, args.steps)))
 
     # live solver statistics from the kernel's diagnostics buffer (a separate, untimed segment: the production
     # launches above carry no diagnostics)
@@ -413,7 +480,7 @@ def run_rank(args, argv):
         for i in range((args.age_steps // R) * R if graph is not None else 0, args.age_steps):
             one_step(i)
         el = timed(args.steps)
-        a_step_ms, a_render_ms = kernel_times(min(32, args.steps))
+        a_step_ms, a_render_ms, _ = kernel_times(max(R, min(32, args.steps)))
         aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps + (105 if api else 0), 'ms_per_step_aged': el / args.steps * 1e3,
                 'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
                 'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B,
@@ -430,6 +497,12 @@ def run_rank(args, argv):
             kname, kms, kbytes = 'render_kernel', render_ms, image_bytes
         else:
             kname, kms, kbytes = ('step_kernel_par' if getattr(sim, 'par', False) else 'step_kernel'), step_ms, state_bytes
+        # kernel_ms: this kernel's average launch duration -- from the rocprofv3 kernel trace of a child run of this very
+        # command when there is one (it cannot include launch gaps), else from the HIP events above
+        kms_events, ksource = kms, 'HIP events around %s' % ('graph replays of back-to-back launches' if (graph_kernel is not None and kname != 'render_kernel') else 'eager launches')
+        trace = pmc.get('trace') if pmc else None
+        if trace:
+            kms, ksource = trace['average_ns'] * 1e-6, 'rocprofv3 --kernel-trace --stats of a child run of this command (%d launches)' % trace['calls']
         achieved = kbytes * B / (kms * 1e-3) / 1e9
         traffic = valu_frac = wait_frac = issue = None
         if pmc:
@@ -461,13 +534,14 @@ def run_rank(args, argv):
                        'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes,
                        'parity': 'vs the C oracle only; parity with pybullet itself is UNPINNED (DESIGN.md 4)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': kname, 'kernel_ms': kms, 'bytes_per_env_step': kbytes,
-                         'step_kernel_ms': step_ms, 'render_kernel_ms': render_ms if cameras else None,
+                         'traffic': traffic, 'kernel': kname, 'kernel_ms': kms, 'kernel_ms_source': ksource, 'kernel_ms_hip_events': kms_events,
+                         'bytes_per_env_step': kbytes,
+                         'step_kernel_ms': step_ms, 'step_kernel_ms_event_bracketed_eager_launch': step_eager_ms, 'render_kernel_ms': render_ms if cameras else None,
                          'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
                          'limiter': ('NOT HBM either: VALU issue of the culling and intersection tests around 655 MB of image writes per launch (DESIGN.md 6)' if args.workload == 'from_the_readme' else
                                      'NOT HBM: instruction issue and latency of one wavefront per SIMD; the hbm fraction is reported because the contract asks for it'),
                          'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac, 'issue': issue,
-                         'pmc_source': 'rocprofv3 child runs of this command, this invocation' if pmc else None},
+                         'pmc_source': ('rocprofv3 child runs of this command, this invocation (%.0f s)' % pmc['seconds']) if pmc else None},
             'solver': solver, 'aged': aged, 'api_eager': api,
         }
         if render_bound and args.workload != 'from_the_readme':
@@ -492,7 +566,9 @@ def main():
     ap.add_argument('--no-auto-reset', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the eager env.step() API measurements')
     ap.add_argument('--eager', action='store_true', help='time the eager launch loop instead of a replayed hipGraph')
-    ap.add_argument('--pmc', action='store_true', help='N=1: measure roofline.traffic / VALU share now, with rocprofv3 child runs of this command')
+    ap.add_argument('--pmc', action='store_true', help='(default at N=1; kept for old command lines)')
+    ap.add_argument('--no-pmc', action='store_true', help='N=1: skip the rocprofv3 child runs (kernel trace + HBM / SQ counter passes) that fill roofline.traffic / kernel_ms')
+    ap.add_argument('--pmc-budget', type=int, default=360, help='seconds the rocprofv3 child runs may take in total')
     ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)  # the profiled child of --pmc: timed loop only
     ap.add_argument('--master-port', type=int, default=0)
     ap.add_argument('--selftest-launcher', action='store_true', help='CPU-only rendezvous test of the N-rank launcher (gloo)')

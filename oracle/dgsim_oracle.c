@@ -1,4 +1,4 @@
-/* dgsim_oracle.c -- CPU oracle for the DIYGym batched step path (fp64, plain C).
+/* dgsim_oracle.c -- CPU oracle for the DIYGym batched step path (plain C; fp64 unless -DDGO_REAL=float).
  *
  * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg as the checker for the HIP path.  The product
@@ -16,7 +16,7 @@
  * There are no golden vectors in the reference, so what pins
  * this oracle is tests/test_oracle_kat.py: analytic known-answer tests
  * (free fall, resting contact, pendulum period and energy, mass-matrix
- * symmetry, ABA vs. Lagrangian double pendulum, FK of the UR5 at the
+ * symmetry, ABA vs. Lagrangian real pendulum, FK of the UR5 at the
  * reference's rest pose computed independently in numpy, IK fixed point) and
  * the reference's one behavioural test (tests/test_environment.py:23-40).
  *
@@ -26,6 +26,8 @@
 #include "dgsim_oracle.h"
 
 #include <math.h>
+#include <tgmath.h> /* sqrt / sin / atan2 ... of a `real` pick the float versions in the fp32 build */
+#undef I /* (complex.h's imaginary unit, pulled in by tgmath.h) */
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +40,10 @@
 #define MAXC 32     /* contacts per env */
 #define MAXROWS (3 * MAXL * 8 + 3 * MAXC)
 
+#define HUGE_R ((real)(sizeof(real) == 8 ? 1e300 : 3.0e38))   /* "no bound" */
+#define TINY_R ((real)(sizeof(real) == 8 ? 1e-300 : 1.0e-37)) /* "parallel" */
+int32_t dgo_real_bytes(void) { return (int32_t)sizeof(real); }
+
 static char g_err[512];
 static void set_err(const char* fmt, ...) {
   va_list ap;
@@ -48,17 +54,17 @@ static void set_err(const char* fmt, ...) {
 const char* dgo_last_error(void) { return g_err; }
 
 /* ------------------------------------------------------------------ math */
-typedef struct { double x, y, z; } v3;
-typedef struct { double m[3][3]; } m3;
-typedef struct { double x, y, z, w; } qt;
+typedef struct { real x, y, z; } v3;
+typedef struct { real m[3][3]; } m3;
+typedef struct { real x, y, z, w; } qt;
 
-static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 V(real x, real y, real z) { v3 r = {x, y, z}; return r; }
 static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
-static v3 vscale(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
-static double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vscale(v3 a, real s) { return V(a.x * s, a.y * s, a.z * s); }
+static real vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-static double vnorm(v3 a) { return sqrt(vdot(a, a)); }
+static real vnorm(v3 a) { return sqrt(vdot(a, a)); }
 static v3 mv(const m3* A, v3 b) {
   return V(A->m[0][0] * b.x + A->m[0][1] * b.y + A->m[0][2] * b.z, A->m[1][0] * b.x + A->m[1][1] * b.y + A->m[1][2] * b.z,
            A->m[2][0] * b.x + A->m[2][1] * b.y + A->m[2][2] * b.z);
@@ -74,13 +80,13 @@ static m3 mmul(const m3* A, const m3* B) {
   return C;
 }
 static m3 mident(void) { m3 I = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}}; return I; }
-static m3 mfrom9(const double* p) {
+static m3 mfrom9(const real* p) {
   m3 A;
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) A.m[i][j] = p[3 * i + j];
   return A;
 }
-static m3 msym6(const double* p) { /* xx xy xz yy yz zz */
+static m3 msym6(const real* p) { /* xx xy xz yy yz zz */
   m3 A = {{{p[0], p[1], p[2]}, {p[1], p[3], p[4]}, {p[2], p[4], p[5]}}};
   return A;
 }
@@ -91,53 +97,53 @@ static qt qmul(qt a, qt b) {
 }
 static qt qconj(qt a) { qt r = {-a.x, -a.y, -a.z, a.w}; return r; }
 static qt qnormalize(qt a) {
-  double n = sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  real n = sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
   qt r = {a.x / n, a.y / n, a.z / n, a.w / n};
   return r;
 }
 static m3 qmat(qt q) {
-  double n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0 ? 2.0 / n : 0.0;
-  double xs = q.x * s, ys = q.y * s, zs = q.z * s;
-  double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys,
+  real n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0 ? 2.0 / n : 0.0;
+  real xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  real wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys,
          yz = q.y * zs, zz = q.z * zs;
   m3 R = {{{1 - (yy + zz), xy - wz, xz + wy}, {xy + wz, 1 - (xx + zz), yz - wx}, {xz - wy, yz + wx, 1 - (xx + yy)}}};
   return R;
 }
 static qt qfrom_mat(const m3* R) {
-  double tr = R->m[0][0] + R->m[1][1] + R->m[2][2];
+  real tr = R->m[0][0] + R->m[1][1] + R->m[2][2];
   qt q;
   if (tr > 0) {
-    double s = sqrt(tr + 1.0) * 2.0;
+    real s = sqrt(tr + 1.0) * 2.0;
     q.x = (R->m[2][1] - R->m[1][2]) / s; q.y = (R->m[0][2] - R->m[2][0]) / s; q.z = (R->m[1][0] - R->m[0][1]) / s; q.w = 0.25 * s;
   } else if (R->m[0][0] > R->m[1][1] && R->m[0][0] > R->m[2][2]) {
-    double s = sqrt(1.0 + R->m[0][0] - R->m[1][1] - R->m[2][2]) * 2.0;
+    real s = sqrt(1.0 + R->m[0][0] - R->m[1][1] - R->m[2][2]) * 2.0;
     q.x = 0.25 * s; q.y = (R->m[0][1] + R->m[1][0]) / s; q.z = (R->m[0][2] + R->m[2][0]) / s; q.w = (R->m[2][1] - R->m[1][2]) / s;
   } else if (R->m[1][1] > R->m[2][2]) {
-    double s = sqrt(1.0 + R->m[1][1] - R->m[0][0] - R->m[2][2]) * 2.0;
+    real s = sqrt(1.0 + R->m[1][1] - R->m[0][0] - R->m[2][2]) * 2.0;
     q.x = (R->m[0][1] + R->m[1][0]) / s; q.y = 0.25 * s; q.z = (R->m[1][2] + R->m[2][1]) / s; q.w = (R->m[0][2] - R->m[2][0]) / s;
   } else {
-    double s = sqrt(1.0 + R->m[2][2] - R->m[0][0] - R->m[1][1]) * 2.0;
+    real s = sqrt(1.0 + R->m[2][2] - R->m[0][0] - R->m[1][1]) * 2.0;
     q.x = (R->m[0][2] + R->m[2][0]) / s; q.y = (R->m[1][2] + R->m[2][1]) / s; q.z = 0.25 * s; q.w = (R->m[1][0] - R->m[0][1]) / s;
   }
   return qnormalize(q);
 }
 /* pybullet getQuaternionFromEuler: fixed-axis XYZ = Rz(yaw) Ry(pitch) Rx(roll) [R] */
-static qt qfrom_euler(double r, double p, double y) {
-  double cr = cos(r * 0.5), sr = sin(r * 0.5), cp = cos(p * 0.5), sp = sin(p * 0.5), cy = cos(y * 0.5), sy = sin(y * 0.5);
+static qt qfrom_euler(real r, real p, real y) {
+  real cr = cos(r * 0.5), sr = sin(r * 0.5), cp = cos(p * 0.5), sp = sin(p * 0.5), cy = cos(y * 0.5), sy = sin(y * 0.5);
   qt q = {sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
   return q;
 }
 /* pybullet getEulerFromQuaternion (btQuaternion::getEulerZYX branches) [R] */
 static v3 euler_from_q(qt q) {
-  double sarg = -2.0 * (q.x * q.z - q.w * q.y);
+  real sarg = -2.0 * (q.x * q.z - q.w * q.y);
   if (sarg <= -0.99999) return V(0.0, -0.5 * M_PI, 2.0 * atan2(q.x, -q.y));
   if (sarg >= 0.99999) return V(0.0, 0.5 * M_PI, 2.0 * atan2(-q.x, q.y));
-  double sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
+  real sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, sqw = q.w * q.w;
   return V(atan2(2.0 * (q.y * q.z + q.w * q.x), sqw - sqx - sqy + sqz), asin(sarg),
            atan2(2.0 * (q.x * q.y + q.w * q.z), sqw + sqx - sqy - sqz));
 }
-static m3 rot_axis(v3 a, double th) { /* Rodrigues, |a| = 1 */
-  double c = cos(th), s = sin(th), t = 1 - c;
+static m3 rot_axis(v3 a, real th) { /* Rodrigues, |a| = 1 */
+  real c = cos(th), s = sin(th), t = 1 - c;
   m3 R = {{{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
            {t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x},
            {t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}}};
@@ -145,17 +151,17 @@ static m3 rot_axis(v3 a, double th) { /* Rodrigues, |a| = 1 */
 }
 
 /* spatial vectors: [angular(3); linear(3)] */
-typedef struct { double v[6]; } s6;
-typedef struct { double m[6][6]; } m6;
+typedef struct { real v[6]; } s6;
+typedef struct { real m[6][6]; } m6;
 static v3 ang(const s6* a) { return V(a->v[0], a->v[1], a->v[2]); }
 static v3 lin(const s6* a) { return V(a->v[3], a->v[4], a->v[5]); }
 static s6 mk6(v3 a, v3 l) { s6 r = {{a.x, a.y, a.z, l.x, l.y, l.z}}; return r; }
 static s6 s6add(s6 a, s6 b) { for (int i = 0; i < 6; i++) a.v[i] += b.v[i]; return a; }
-static s6 s6scale(s6 a, double s) { for (int i = 0; i < 6; i++) a.v[i] *= s; return a; }
-static double s6dot(const s6* a, const s6* b) { double s = 0; for (int i = 0; i < 6; i++) s += a->v[i] * b->v[i]; return s; }
+static s6 s6scale(s6 a, real s) { for (int i = 0; i < 6; i++) a.v[i] *= s; return a; }
+static real s6dot(const s6* a, const s6* b) { real s = 0; for (int i = 0; i < 6; i++) s += a->v[i] * b->v[i]; return s; }
 static s6 m6v(const m6* A, const s6* x) {
   s6 r;
-  for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += A->m[i][j] * x->v[j]; r.v[i] = s; }
+  for (int i = 0; i < 6; i++) { real s = 0; for (int j = 0; j < 6; j++) s += A->m[i][j] * x->v[j]; r.v[i] = s; }
   return r;
 }
 /* motion transform parent -> child:  E = rotation parent->child coords, r = child origin in parent coords */
@@ -184,11 +190,11 @@ static s6 crf(const s6* v, const s6* f) { /* v x* f (force) */
   v3 w = ang(v), l = lin(v), n = ang(f), fl = lin(f);
   return mk6(vadd(vcross(w, n), vcross(l, fl)), vcross(w, fl));
 }
-static m6 rigid_inertia(double m, v3 c, const m3* Ic) {
+static m6 rigid_inertia(real m, v3 c, const m3* Ic) {
   m6 I; memset(&I, 0, sizeof I);
   m3 cx = {{{0, -c.z, c.y}, {c.z, 0, -c.x}, {-c.y, c.x, 0}}};
-  double cc = vdot(c, c);
-  double cv[3] = {c.x, c.y, c.z};
+  real cc = vdot(c, c);
+  real cv[3] = {c.x, c.y, c.z};
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       I.m[i][j] = Ic->m[i][j] + m * ((i == j ? cc : 0.0) - cv[i] * cv[j]);
@@ -199,19 +205,19 @@ static m6 rigid_inertia(double m, v3 c, const m3* Ic) {
   return I;
 }
 /* solve A x = b for SPD 6x6 (Cholesky); returns 0 on failure */
-static int spd_solve(int n, const double* A, const double* b, double* x) {
-  double L[12 * 12];
+static int spd_solve(int n, const real* A, const real* b, real* x) {
+  real L[12 * 12];
   if (n > 12) return 0;
   memset(L, 0, sizeof L);
   for (int i = 0; i < n; i++)
     for (int j = 0; j <= i; j++) {
-      double s = A[i * n + j];
+      real s = A[i * n + j];
       for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
       if (i == j) { if (s <= 0) return 0; L[i * n + i] = sqrt(s); } else L[i * n + j] = s / L[j * n + j];
     }
-  double y[12];
-  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
-  for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+  real y[12];
+  for (int i = 0; i < n; i++) { real s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { real s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
   return 1;
 }
 
@@ -221,39 +227,39 @@ static uint64_t mix64(uint64_t z) {
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
   return z;
 }
-static double rng_uniform(uint64_t seed, uint64_t env, uint64_t episode, uint64_t op, uint64_t comp) {
+static real rng_uniform(uint64_t seed, uint64_t env, uint64_t episode, uint64_t op, uint64_t comp) {
   uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1));
   z = mix64(z ^ (episode * 0xD1342543DE82EF95ULL + op * 0x2545F4914F6CDD1DULL + comp + 1));
-  return (double)(z >> 40) * (1.0 / 16777216.0);
+  return (real)(z >> 40) * (1.0 / 16777216.0);
 }
 
 /* ------------------------------------------------------------- the world */
 typedef struct {
-  int32_t* I; double* F; int64_t ni, nf;
+  int32_t* I; real* F; int64_t ni, nf;
   int nb, nl, nfr, nsh, npairs, nops;
   int act_dim, obs_dim, rew_dim, term_dim, substeps, iters, max_steps, hot_start, ik_iters, state_dim;
   int addon_off, max_contacts, rew_mode, term_mode, n_term_groups;
   const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
-  const double *BF, *LF, *FF, *SF, *PF, *OF, *FL;
-  double h; v3 g;
+  const real *BF, *LF, *FF, *SF, *PF, *OF, *FL;
+  real h; v3 g;
 } Scene;
 
 typedef struct {
   int body_a, link_a, body_b, link_b; /* link = global link index or -1 (base) */
   v3 p; /* world contact point (midway) */
   v3 n; /* world normal, from B towards A */
-  double dist; /* signed distance (negative = penetration) */
-  double mu;
+  real dist; /* signed distance (negative = penetration) */
+  real mu;
   int shape_a, shape_b;      /* global shape indices */
-  v3 t1, t2; double imp[3];  /* friction directions and the solved impulses (normal, t1, t2), filled in after the sweeps */
+  v3 t1, t2; real imp[3];  /* friction directions and the solved impulses (normal, t1, t2), filled in after the sweeps */
 } Contact;
 
 struct dgo_world {
   Scene sc;
   int B;
   uint64_t seed; int64_t env_base;
-  double* state; /* [B][state_dim] */
-  double* mcfg;  /* [nl][DG_MC_STRIDE] */
+  real* state; /* [B][state_dim] */
+  real* mcfg;  /* [nl][DG_MC_STRIDE] */
   int* last_contacts; int* last_iters;
   Contact* last_cs; /* [B][MAXC]: contacts and impulses of each env's most recent substep (force_torque_sensor) */
 };
@@ -266,28 +272,28 @@ typedef struct {
   m3 E[MAXL]; v3 r[MAXL];         /* parent->child motion transform */
   m3 Rw[MAXL]; v3 pw[MAXL];       /* link frame in world */
   s6 S[MAXL], v[MAXL], c[MAXL], pA[MAXL], U[MAXL], a[MAXL];
-  m6 IA[MAXL]; double d[MAXL], u[MAXL], qdd[MAXL];
+  m6 IA[MAXL]; real d[MAXL], u[MAXL], qdd[MAXL];
   s6 v0, pA0, a0; m6 IA0;
   int parent[MAXL]; /* local index, -1 base */
-  double dv[MAXV]; /* solver velocity change: base(6, base coords) + joints */
+  real dv[MAXV]; /* solver velocity change: base(6, base coords) + joints */
 } BodyWS;
 
-static double* env_state(dgo_world* w, int e) { return w->state + (size_t)e * w->sc.state_dim; }
+static real* env_state(dgo_world* w, int e) { return w->state + (size_t)e * w->sc.state_dim; }
 static const int32_t* body_i(const Scene* s, int b) { return s->BI + b * DG_BI_STRIDE; }
-static const double* body_f(const Scene* s, int b) { return s->BF + b * DG_BF_STRIDE; }
+static const real* body_f(const Scene* s, int b) { return s->BF + b * DG_BF_STRIDE; }
 static const int32_t* link_i(const Scene* s, int l) { return s->LI + l * DG_LI_STRIDE; }
-static const double* link_f(const Scene* s, int l) { return s->LF + l * DG_LF_STRIDE; }
+static const real* link_f(const Scene* s, int l) { return s->LF + l * DG_LF_STRIDE; }
 static int body_fixed(const Scene* s, int b) { return body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FIXED; }
-static double* body_ext(const Scene* s, double* st, int b) {
+static real* body_ext(const Scene* s, real* st, int b) {
   return st + body_i(s, b)[DG_BI_STATE_OFF] + (body_fixed(s, b) ? DG_BS_FIXED_END : DG_BS_FLOAT_END);
 }
 
-static int parse_scene(Scene* s, const int32_t* I, int64_t ni, const double* F, int64_t nf) {
+static int parse_scene(Scene* s, const int32_t* I, int64_t ni, const double* F64, int64_t nf) {
   if (ni < DG_H_INT_COUNT || I[DG_H_MAGIC] != DG_MAGIC) { set_err("bad scene magic"); return 0; }
   if (I[DG_H_VERSION] != DG_VERSION) { set_err("scene version %d, expected %d", I[DG_H_VERSION], DG_VERSION); return 0; }
   s->I = (int32_t*)malloc(sizeof(int32_t) * (size_t)ni); memcpy(s->I, I, sizeof(int32_t) * (size_t)ni);
-  s->F = (double*)malloc(sizeof(double) * (size_t)nf); memcpy(s->F, F, sizeof(double) * (size_t)nf);
-  s->ni = ni; s->nf = nf; I = s->I; F = s->F;
+  s->F = (real*)malloc(sizeof(real) * (size_t)nf); for (int64_t k = 0; k < nf; k++) s->F[k] = (real)F64[k];
+  s->ni = ni; s->nf = nf; I = s->I; const real* F = s->F;
   s->nb = I[DG_H_N_BODIES]; s->nl = I[DG_H_N_LINKS]; s->nfr = I[DG_H_N_FRAMES]; s->nsh = I[DG_H_N_SHAPES];
   s->npairs = I[DG_H_N_PAIRS]; s->nops = I[DG_H_N_OPS];
   s->act_dim = I[DG_H_ACT_DIM]; s->obs_dim = I[DG_H_OBS_DIM]; s->rew_dim = I[DG_H_REW_DIM]; s->term_dim = I[DG_H_TERM_DIM];
@@ -311,8 +317,8 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
   dgo_world* w = (dgo_world*)calloc(1, sizeof *w);
   if (!parse_scene(&w->sc, idata, n_i, fdata, n_f)) { free(w); return NULL; }
   w->B = num_envs; w->seed = seed; w->env_base = env_index_base;
-  w->state = (double*)calloc((size_t)num_envs * w->sc.state_dim, sizeof(double));
-  w->mcfg = (double*)calloc((size_t)(w->sc.nl > 0 ? w->sc.nl : 1) * DG_MC_STRIDE, sizeof(double));
+  w->state = (real*)calloc((size_t)num_envs * w->sc.state_dim, sizeof(real));
+  w->mcfg = (real*)calloc((size_t)(w->sc.nl > 0 ? w->sc.nl : 1) * DG_MC_STRIDE, sizeof(real));
   w->last_contacts = (int*)calloc(num_envs, sizeof(int));
   w->last_iters = (int*)calloc(num_envs, sizeof(int));
   w->last_cs = (Contact*)calloc((size_t)num_envs * MAXC, sizeof(Contact));
@@ -329,11 +335,11 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
   }
   /* initial state = load pose (reference model.py:68), joints at zero */
   for (int e = 0; e < num_envs; e++) {
-    double* st = env_state(w, e);
+    real* st = env_state(w, e);
     for (int b = 0; b < w->sc.nb; b++) {
       if (body_i(&w->sc, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue;
-      double* bs = st + body_i(&w->sc, b)[DG_BI_STATE_OFF];
-      const double* bf = body_f(&w->sc, b);
+      real* bs = st + body_i(&w->sc, b)[DG_BI_STATE_OFF];
+      const real* bf = body_f(&w->sc, b);
       for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] = bf[DG_BF_INIT_POS + k];
       for (int k = 0; k < 4; k++) bs[DG_BS_QUAT + k] = bf[DG_BF_INIT_QUAT + k];
     }
@@ -344,7 +350,7 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
         continue;
       }
       if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;
-      double* ps = st + w->sc.addon_off + oi[DG_OI_STATE_OFF];
+      real* ps = st + w->sc.addon_off + oi[DG_OI_STATE_OFF];
       for (int k = 0; k < oi[DG_OI_N]; k++) ps[k] = 1.0;
       ps[oi[DG_OI_N]] = w->sc.F[DG_HF_ANG_DAMPING];
     }
@@ -356,23 +362,23 @@ void dgo_destroy(dgo_world* w) {
   free(w->sc.I); free(w->sc.F); free(w->state); free(w->mcfg); free(w->last_contacts); free(w->last_iters); free(w->last_cs); free(w);
 }
 int32_t dgo_state_dim(const dgo_world* w) { return w->sc.state_dim; }
-double* dgo_state(dgo_world* w) { return w->state; }
-double* dgo_motor_cfg(dgo_world* w) { return w->mcfg; }
+real* dgo_state(dgo_world* w) { return w->state; }
+real* dgo_motor_cfg(dgo_world* w) { return w->mcfg; }
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env) { return w->last_contacts[env]; }
 int32_t dgo_last_iterations(const dgo_world* w, int32_t env) { return w->last_iters[env]; }
 
 /* --------------------------------------------------------- kinematics */
-static void body_kinematics(const Scene* s, const double* st, int b, BodyWS* ws, const double* q_override) {
+static void body_kinematics(const Scene* s, const real* st, int b, BodyWS* ws, const real* q_override) {
   const int32_t* bi = body_i(s, b);
-  const double* bs = (bi[DG_BI_FLAGS] & DG_BODY_FROZEN) ? body_f(s, b) + DG_BF_INIT_POS : st + bi[DG_BI_STATE_OFF]; /* pos3 quat4 either way */
+  const real* bs = (bi[DG_BI_FLAGS] & DG_BODY_FROZEN) ? body_f(s, b) + DG_BF_INIT_POS : st + bi[DG_BI_STATE_OFF]; /* pos3 quat4 either way */
   ws->n = bi[DG_BI_N_LINKS]; ws->first = bi[DG_BI_FIRST_LINK]; ws->fixed = bi[DG_BI_FLAGS] & DG_BODY_FIXED;
   ws->p0 = V(bs[0], bs[1], bs[2]);
   qt q0 = {bs[3], bs[4], bs[5], bs[6]}; ws->q0 = q0; ws->R0 = qmat(q0);
   for (int i = 0; i < ws->n; i++) {
     int gl = ws->first + i;
-    const int32_t* li = link_i(s, gl); const double* lf = link_f(s, gl);
+    const int32_t* li = link_i(s, gl); const real* lf = link_f(s, gl);
     int par = li[DG_LI_PARENT]; ws->parent[i] = par < 0 ? -1 : par - ws->first;
-    double q = q_override ? q_override[i] : st[li[DG_LI_STATE_OFF] + DG_LS_Q];
+    real q = q_override ? q_override[i] : st[li[DG_LI_STATE_OFF] + DG_LS_Q];
     m3 RT = mfrom9(lf + DG_LF_ROT); v3 pT = V(lf[DG_LF_POS], lf[DG_LF_POS + 1], lf[DG_LF_POS + 2]);
     v3 ax = V(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]);
     m3 Rpc; v3 r;
@@ -393,8 +399,8 @@ static void link_world(const BodyWS* ws, int local_link, m3* R, v3* p) {
 }
 
 /* velocities (spatial, link coords) from state */
-static void body_velocities(const Scene* s, const double* st, int b, BodyWS* ws) {
-  const double* bs = st + (ws->fixed ? 0 : body_i(s, b)[DG_BI_STATE_OFF]);
+static void body_velocities(const Scene* s, const real* st, int b, BodyWS* ws) {
+  const real* bs = st + (ws->fixed ? 0 : body_i(s, b)[DG_BI_STATE_OFF]);
   if (ws->fixed) memset(&ws->v0, 0, sizeof ws->v0);
   else {
     v3 vw = V(bs[DG_BS_LINVEL], bs[DG_BS_LINVEL + 1], bs[DG_BS_LINVEL + 2]);
@@ -402,7 +408,7 @@ static void body_velocities(const Scene* s, const double* st, int b, BodyWS* ws)
     ws->v0 = mk6(mtv(&ws->R0, ww), mtv(&ws->R0, vw));
   }
   for (int i = 0; i < ws->n; i++) {
-    double qd = st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD];
+    real qd = st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD];
     const s6* vp = ws->parent[i] < 0 ? &ws->v0 : &ws->v[ws->parent[i]];
     s6 vJ = s6scale(ws->S[i], qd);
     ws->v[i] = s6add(xmotion(&ws->E[i], ws->r[i], vp), vJ);
@@ -412,7 +418,7 @@ static void body_velocities(const Scene* s, const double* st, int b, BodyWS* ws)
 
 /* Bullet's per-link "global" damping [R]: force -m v_com (k + k|v_com|), torque
  * -I_c w (k + k|w|), returned as a spatial force about the link origin */
-static s6 damping_force(double m, v3 c, const m3* Ic, const s6* v, double kl, double ka) {
+static s6 damping_force(real m, v3 c, const m3* Ic, const s6* v, real kl, real ka) {
   v3 w = ang(v), vo = lin(v);
   v3 vc = vadd(vo, vcross(w, c));
   v3 f = vscale(vc, -m * (kl + kl * vnorm(vc)));
@@ -424,16 +430,16 @@ static s6 damping_force(double m, v3 c, const m3* Ic, const s6* v, double kl, do
  * torques (damping, torque-control).  Leaves IA, U, d in ws for impulse responses. */
 /* per-env link mass: the URDF mass times the dynamics_randomizer's scale for this link, if it has one (the inertia
  * tensor is scaled with the mass) */
-static double link_mass_scale(const Scene* s, const double* st, int gl) {
+static real link_mass_scale(const Scene* s, const real* st, int gl) {
   int o = link_i(s, gl)[DG_LI_MASS_SCALE]; return o >= 0 ? st[o] : 1.0;
 }
-static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
-  const double* bf = body_f(s, b);
-  double kl = s->F[DG_HF_LIN_DAMPING], ka = s->F[DG_HF_ANG_DAMPING];
+static void body_aba(const Scene* s, const real* st, int b, BodyWS* ws) {
+  const real* bf = body_f(s, b);
+  real kl = s->F[DG_HF_LIN_DAMPING], ka = s->F[DG_HF_ANG_DAMPING];
   if (body_i(s, b)[DG_BI_DYN_OFF] >= 0) ka = st[body_i(s, b)[DG_BI_DYN_OFF]]; /* changeDynamics(angularDamping=) per env */
   /* pass 1: inertias and bias forces */
   for (int i = 0; i < ws->n; i++) {
-    const double* lf = link_f(s, ws->first + i); const double ms = link_mass_scale(s, st, ws->first + i);
+    const real* lf = link_f(s, ws->first + i); const real ms = link_mass_scale(s, st, ws->first + i);
     v3 c = V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]); m3 Ic = msym6(lf + DG_LF_INERTIA);
     for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Ic.m[r][cc] *= ms;
     ws->IA[i] = rigid_inertia(lf[DG_LF_MASS] * ms, c, &Ic);
@@ -449,16 +455,16 @@ static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
     ws->pA0 = crf(&ws->v0, &Iv);
     s6 fd = damping_force(bf[DG_BF_MASS], c, &Ic, &ws->v0, kl, ka);
     /* external wrench (world, about the base origin) -> base coords */
-    const double* ex = body_ext(s, (double*)st, b);
+    const real* ex = body_ext(s, (real*)st, b);
     v3 fe = mtv(&ws->R0, V(ex[0], ex[1], ex[2])), ne = mtv(&ws->R0, V(ex[3], ex[4], ex[5]));
     s6 fx = mk6(ne, fe);
     for (int k = 0; k < 6; k++) ws->pA0.v[k] -= fd.v[k] + fx.v[k];
   }
   /* pass 2: articulated inertias, leaves to root */
   for (int i = ws->n - 1; i >= 0; i--) {
-    const int32_t* li = link_i(s, ws->first + i); const double* lf = link_f(s, ws->first + i);
-    double qd = st[li[DG_LI_STATE_OFF] + DG_LS_QD];
-    double tau = st[li[DG_LI_STATE_OFF] + DG_LS_TORQUE] - lf[DG_LF_DAMPING] * qd; /* Bullet joint damping [R] */
+    const int32_t* li = link_i(s, ws->first + i); const real* lf = link_f(s, ws->first + i);
+    real qd = st[li[DG_LI_STATE_OFF] + DG_LS_QD];
+    real tau = st[li[DG_LI_STATE_OFF] + DG_LS_TORQUE] - lf[DG_LF_DAMPING] * qd; /* Bullet joint damping [R] */
     ws->U[i] = m6v(&ws->IA[i], &ws->S[i]);
     ws->d[i] = s6dot(&ws->S[i], &ws->U[i]);
     ws->u[i] = tau - s6dot(&ws->S[i], &ws->pA[i]);
@@ -469,11 +475,11 @@ static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
     for (int k = 0; k < 6; k++) pa.v[k] = ws->pA[i].v[k] + Iac.v[k] + ws->U[i].v[k] * ws->u[i] / ws->d[i];
     m6 X = xmat(&ws->E[i], ws->r[i]);
     /* parent += X^T Ia X ; X^T pa */
-    m6 T; for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 6; k++) t += Ia.m[a][k] * X.m[k][c]; T.m[a][c] = t; }
+    m6 T; for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { real t = 0; for (int k = 0; k < 6; k++) t += Ia.m[a][k] * X.m[k][c]; T.m[a][c] = t; }
     m6* Ip = ws->parent[i] < 0 ? &ws->IA0 : &ws->IA[ws->parent[i]];
     s6* pp = ws->parent[i] < 0 ? &ws->pA0 : &ws->pA[ws->parent[i]];
     if (ws->parent[i] >= 0 || !ws->fixed) {
-      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 6; k++) t += X.m[k][a] * T.m[k][c]; Ip->m[a][c] += t; }
+      for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { real t = 0; for (int k = 0; k < 6; k++) t += X.m[k][a] * T.m[k][c]; Ip->m[a][c] += t; }
       s6 pf = xforce_to_parent(&ws->E[i], ws->r[i], &pa);
       for (int k = 0; k < 6; k++) pp->v[k] += pf.v[k];
     }
@@ -483,7 +489,7 @@ static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
   v3 gb = mtv(&ws->R0, s->g);
   if (ws->fixed) ws->a0 = mk6(V(0, 0, 0), vscale(gb, -1.0));
   else {
-    double rhs[6], x[6];
+    real rhs[6], x[6];
     for (int k = 0; k < 6; k++) rhs[k] = -ws->pA0.v[k];
     if (!spd_solve(6, &ws->IA0.m[0][0], rhs, x)) memset(x, 0, sizeof x);
     for (int k = 0; k < 6; k++) ws->a0.v[k] = x[k];
@@ -503,8 +509,8 @@ static void body_aba(const Scene* s, const double* st, int b, BodyWS* ws) {
  * velocity and zero gravity (Featherstone RBDA 7.3 / Bullet's
  * calcAccelerationDeltasMultiDof).  Also returns the row Jacobian J with
  * J . gen_velocity == f . v_link  (+ qd[dof]). */
-static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, double* J, double* dv) {
-  s6 p[MAXL], p0; double u[MAXL];
+static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, real* J, real* dv) {
+  s6 p[MAXL], p0; real u[MAXL];
   memset(p, 0, sizeof(s6) * (size_t)(ws->n > 0 ? ws->n : 1)); memset(&p0, 0, sizeof p0);
   for (int k = 0; k < 6 + ws->n; k++) { J[k] = 0; dv[k] = 0; }
   s6 fj[MAXL], fj0; memset(fj, 0, sizeof(s6) * (size_t)(ws->n > 0 ? ws->n : 1)); memset(&fj0, 0, sizeof fj0);
@@ -523,24 +529,24 @@ static void body_response(const BodyWS* ws, int lk, const s6* f, int dof, double
   s6 a[MAXL], a0; memset(&a0, 0, sizeof a0);
   if (!ws->fixed) {
     for (int k = 0; k < 6; k++) J[k] = fj0.v[k];
-    double rhs[6], x[6]; for (int k = 0; k < 6; k++) rhs[k] = -p0.v[k];
+    real rhs[6], x[6]; for (int k = 0; k < 6; k++) rhs[k] = -p0.v[k];
     if (!spd_solve(6, &ws->IA0.m[0][0], rhs, x)) memset(x, 0, sizeof x);
     for (int k = 0; k < 6; k++) { a0.v[k] = x[k]; dv[k] = x[k]; }
   }
   for (int i = 0; i < ws->n; i++) {
     const s6* ap = ws->parent[i] < 0 ? &a0 : &a[ws->parent[i]];
     s6 a1 = xmotion(&ws->E[i], ws->r[i], ap);
-    double qdd = (u[i] - s6dot(&ws->U[i], &a1)) / ws->d[i];
+    real qdd = (u[i] - s6dot(&ws->U[i], &a1)) / ws->d[i];
     a[i] = s6add(a1, s6scale(ws->S[i], qdd));
     dv[6 + i] = qdd;
   }
 }
 
 /* ----------------------------------------------------------- collision */
-typedef struct { int id, type, body, llink /* local */, glink; m3 R; v3 p; m3 Rl; v3 pl; /* frame the hull points live in */ const double* prm; double mu; int poff, npts; } WShape;
+typedef struct { int id, type, body, llink /* local */, glink; m3 R; v3 p; m3 Rl; v3 pl; /* frame the hull points live in */ const real* prm; real mu; int poff, npts; } WShape;
 
 static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
-  const int32_t* si = s->SI + sh * DG_SI_STRIDE; const double* sf = s->SF + sh * DG_SF_STRIDE;
+  const int32_t* si = s->SI + sh * DG_SI_STRIDE; const real* sf = s->SF + sh * DG_SF_STRIDE;
   o->id = sh; o->type = si[DG_SI_TYPE]; o->body = si[DG_SI_BODY]; o->glink = si[DG_SI_LINK];
   const BodyWS* ws = &wsb[o->body];
   o->llink = o->glink < 0 ? -1 : o->glink - ws->first;
@@ -551,7 +557,7 @@ static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
   o->R = mmul(&Rl, &Rs); o->p = vadd(pl, mv(&Rl, V(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2])));
   o->prm = sf + DG_SF_PARAMS; o->mu = sf[DG_SF_FRICTION]; o->poff = si[DG_SI_POINT_OFF]; o->npts = si[DG_SI_N_POINTS];
 }
-static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, double dist) {
+static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, real dist) {
   if (*nc >= maxc) return;
   Contact* c = &cs[(*nc)++];
   c->body_a = a->body; c->link_a = a->llink; c->body_b = b->body; c->link_b = b->llink; c->shape_a = a->id; c->shape_b = b->id;
@@ -559,18 +565,18 @@ static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const W
   c->p = vscale(vadd(pa, pb), 0.5); c->n = n; c->dist = dist; c->mu = a->mu * b->mu; /* Bullet combines friction by product [R] */
 }
 /* sphere (centre c, radius r) against box shape bx: returns 1 and contact data when dist < margin */
-static int sphere_box(v3 c, double r, const WShape* bx, double margin, v3* pa, v3* pb, v3* n, double* dist) {
+static int sphere_box(v3 c, real r, const WShape* bx, real margin, v3* pa, v3* pb, v3* n, real* dist) {
   v3 lc = mtv(&bx->R, vsub(c, bx->p));
-  double h[3] = {bx->prm[0], bx->prm[1], bx->prm[2]}, l[3] = {lc.x, lc.y, lc.z}, cl[3];
+  real h[3] = {bx->prm[0], bx->prm[1], bx->prm[2]}, l[3] = {lc.x, lc.y, lc.z}, cl[3];
   int inside = 1;
   for (int k = 0; k < 3; k++) { cl[k] = l[k] < -h[k] ? -h[k] : (l[k] > h[k] ? h[k] : l[k]); if (cl[k] != l[k]) inside = 0; }
-  v3 nl; double d;
+  v3 nl; real d;
   if (!inside) {
     v3 df = V(l[0] - cl[0], l[1] - cl[1], l[2] - cl[2]); d = vnorm(df); nl = vscale(df, 1.0 / d);
   } else { /* centre inside: leave through the nearest face */
-    int best = 0; double bd = 1e300; double sg = 1;
-    for (int k = 0; k < 3; k++) { double dp = h[k] - l[k], dm = l[k] + h[k]; if (dp < bd) { bd = dp; best = k; sg = 1; } if (dm < bd) { bd = dm; best = k; sg = -1; } }
-    double nn[3] = {0, 0, 0}; nn[best] = sg; nl = V(nn[0], nn[1], nn[2]); d = -bd; cl[best] = sg * h[best];
+    int best = 0; real bd = HUGE_R; real sg = 1;
+    for (int k = 0; k < 3; k++) { real dp = h[k] - l[k], dm = l[k] + h[k]; if (dp < bd) { bd = dp; best = k; sg = 1; } if (dm < bd) { bd = dm; best = k; sg = -1; } }
+    real nn[3] = {0, 0, 0}; nn[best] = sg; nl = V(nn[0], nn[1], nn[2]); d = -bd; cl[best] = sg * h[best];
   }
   if (d - r >= margin) return 0;
   *n = mv(&bx->R, nl);
@@ -584,21 +590,21 @@ static void seg_ends(const WShape* c, v3* e0, v3* e1) {
   *e0 = vsub(c->p, vscale(ax, c->prm[1])); *e1 = vadd(c->p, vscale(ax, c->prm[1]));
 }
 static v3 closest_on_seg(v3 a, v3 b, v3 p) {
-  v3 ab = vsub(b, a); double den = vdot(ab, ab);
-  double t = den > 0 ? vdot(vsub(p, a), ab) / den : 0.0; t = t < 0 ? 0 : (t > 1 ? 1 : t);
+  v3 ab = vsub(b, a); real den = vdot(ab, ab);
+  real t = den > 0 ? vdot(vsub(p, a), ab) / den : 0.0; t = t < 0 ? 0 : (t > 1 ? 1 : t);
   return vadd(a, vscale(ab, t));
 }
 /* closest points between segments p1-q1, p2-q2 (Ericson, Real-Time Collision Detection 5.1.9) */
 static void seg_seg(v3 p1, v3 q1, v3 p2, v3 q2, v3* c1, v3* c2) {
   v3 d1 = vsub(q1, p1), d2 = vsub(q2, p2), r = vsub(p1, p2);
-  double a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r), sN, tN; const double eps = 1e-12;
+  real a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r), sN, tN; const real eps = 1e-12;
   if (a <= eps && e <= eps) { *c1 = p1; *c2 = p2; return; }
   if (a <= eps) { sN = 0; tN = f / e; tN = tN < 0 ? 0 : (tN > 1 ? 1 : tN); }
   else {
-    double c = vdot(d1, r);
+    real c = vdot(d1, r);
     if (e <= eps) { tN = 0; sN = -c / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
     else {
-      double b = vdot(d1, d2), den = a * e - b * b;
+      real b = vdot(d1, d2), den = a * e - b * b;
       sN = den > eps ? (b * f - c * e) / den : 0.0; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN);
       tN = (b * sN + f) / e;
       if (tN < 0) { tN = 0; sN = -c / a; sN = sN < 0 ? 0 : (sN > 1 ? 1 : sN); }
@@ -607,8 +613,8 @@ static void seg_seg(v3 p1, v3 q1, v3 p2, v3 q2, v3* c1, v3* c2) {
   }
   *c1 = vadd(p1, vscale(d1, sN)); *c2 = vadd(p2, vscale(d2, tN));
 }
-static int sphere_sphere(v3 ca, double ra, v3 cb, double rb, double margin, v3* pa, v3* pb, v3* n, double* dist) {
-  v3 d = vsub(ca, cb); double len = vnorm(d);
+static int sphere_sphere(v3 ca, real ra, v3 cb, real rb, real margin, v3* pa, v3* pb, v3* n, real* dist) {
+  v3 d = vsub(ca, cb); real len = vnorm(d);
   if (len - ra - rb >= margin) return 0;
   *n = len > 1e-12 ? vscale(d, 1.0 / len) : V(0, 0, 1);
   *pa = vsub(ca, vscale(*n, ra)); *pb = vadd(cb, vscale(*n, rb)); *dist = len - ra - rb;
@@ -616,13 +622,13 @@ static int sphere_sphere(v3 ca, double ra, v3 cb, double rb, double margin, v3* 
 }
 
 static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
-  int nc = 0; double margin = s->F[DG_HF_CONTACT_MARGIN];
+  int nc = 0; real margin = s->F[DG_HF_CONTACT_MARGIN];
   for (int pi = 0; pi < s->npairs; pi++) {
     WShape A, Bs; shape_world(s, wsb, s->PI[pi * DG_PI_STRIDE + DG_PI_A], &A); shape_world(s, wsb, s->PI[pi * DG_PI_STRIDE + DG_PI_B], &Bs);
-    const WShape *a = &A, *b = &Bs; double flip = 1.0;
+    const WShape *a = &A, *b = &Bs; real flip = 1.0;
     /* canonical order: lower type id first, except that a box is always `b` */
     if (a->type == DG_SHAPE_BOX || (b->type != DG_SHAPE_BOX && a->type > b->type)) { const WShape* t = a; a = b; b = t; flip = -1.0; }
-    v3 pa, pb, n; double dist;
+    v3 pa, pb, n; real dist;
     #define EMIT() do { if (flip > 0) add_contact(cs, &nc, s->max_contacts, a, b, pa, pb, n, dist); \
                         else add_contact(cs, &nc, s->max_contacts, b, a, pb, pa, vscale(n, -1.0), dist); } while (0)
     if (a->type == DG_SHAPE_SPHERE && b->type == DG_SHAPE_SPHERE) {
@@ -642,17 +648,17 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
       if (a->prm[1] > 0 && sphere_box(e1, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
     } else if (a->type == DG_SHAPE_POINTS && b->type == DG_SHAPE_BOX) {
       /* hull vertices against the box: keep the 4 deepest (ties -> lower index) */
-      int bi[4] = {-1, -1, -1, -1}; double bd[4] = {1e300, 1e300, 1e300, 1e300};
+      int bi[4] = {-1, -1, -1, -1}; real bd[4] = {HUGE_R, HUGE_R, HUGE_R, HUGE_R};
       m3 Rl = a->Rl; v3 pl = a->pl;
       for (int k = 0; k < a->npts; k++) {
-        const double* pp = s->PF + 3 * (a->poff + k);
+        const real* pp = s->PF + 3 * (a->poff + k);
         v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));
-        v3 qa, qb, qn; double qd;
+        v3 qa, qb, qn; real qd;
         if (!sphere_box(pwk, 0.0, b, margin, &qa, &qb, &qn, &qd)) continue;
         for (int j = 0; j < 4; j++) if (qd < bd[j]) { for (int m = 3; m > j; m--) { bd[m] = bd[m - 1]; bi[m] = bi[m - 1]; } bd[j] = qd; bi[j] = k; break; }
       }
       for (int j = 0; j < 4; j++) if (bi[j] >= 0) {
-        const double* pp = s->PF + 3 * (a->poff + bi[j]);
+        const real* pp = s->PF + 3 * (a->poff + bi[j]);
         v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));
         if (sphere_box(pwk, 0.0, b, margin, &pa, &pb, &n, &dist)) EMIT();
       }
@@ -665,20 +671,20 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
 /* ------------------------------------------------------------- solver */
 typedef struct {
   int body_a, body_b; /* body_b = -1: single-body row */
-  double JA[MAXV], RA[MAXV], JB[MAXV], RB[MAXV];
-  double b, lo, hi, acc, diag; /* diag = J M^-1 J^T */
-  int normal_row; double mu;   /* friction rows: index of the normal row */
+  real JA[MAXV], RA[MAXV], JB[MAXV], RB[MAXV];
+  real b, lo, hi, acc, diag; /* diag = J M^-1 J^T */
+  int normal_row; real mu;   /* friction rows: index of the normal row */
   int motor_link;              /* global link index for motor rows else -1 */
 } Row;
 
-static double row_jv(const Row* r, BodyWS* wsb) {
-  double s = 0; const BodyWS* a = &wsb[r->body_a];
+static real row_jv(const Row* r, BodyWS* wsb) {
+  real s = 0; const BodyWS* a = &wsb[r->body_a];
   for (int k = 0; k < 6 + a->n; k++) s += r->JA[k] * a->dv[k];
   if (r->body_b >= 0) { const BodyWS* b = &wsb[r->body_b]; for (int k = 0; k < 6 + b->n; k++) s += r->JB[k] * b->dv[k]; }
   return s;
 }
-static double gen_vel_dot(const Scene* s, const double* st, const BodyWS* ws, const double* J) {
-  double r = 0;
+static real gen_vel_dot(const Scene* s, const real* st, const BodyWS* ws, const real* J) {
+  real r = 0;
   if (!ws->fixed) for (int k = 0; k < 6; k++) r += J[k] * ws->v0.v[k];
   for (int i = 0; i < ws->n; i++) r += J[6 + i] * st[link_i(s, ws->first + i)[DG_LI_STATE_OFF] + DG_LS_QD];
   return r;
@@ -691,19 +697,19 @@ static s6 point_force(const BodyWS* ws, int lk, v3 p, v3 n) {
 }
 static void tangent_basis(v3 n, v3* t1, v3* t2) { /* btPlaneSpace1 [R] */
   if (fabs(n.z) > 0.7071067811865475244) {
-    double a = n.y * n.y + n.z * n.z, k = 1.0 / sqrt(a);
+    real a = n.y * n.y + n.z * n.z, k = 1.0 / sqrt(a);
     *t1 = V(0, -n.z * k, n.y * k); *t2 = V(a * k, -n.x * t1->z, n.x * t1->y);
   } else {
-    double a = n.x * n.x + n.y * n.y, k = 1.0 / sqrt(a);
+    real a = n.x * n.x + n.y * n.y, k = 1.0 / sqrt(a);
     *t1 = V(-n.y * k, n.x * k, 0); *t2 = V(-n.z * t1->y, n.z * t1->x, a * k);
   }
 }
-static int make_contact_row(const Scene* s, const double* st, BodyWS* wsb, const Contact* c, v3 dir, Row* r) {
+static int make_contact_row(const Scene* s, const real* st, BodyWS* wsb, const Contact* c, v3 dir, Row* r) {
   memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1;
   BodyWS *A = &wsb[c->body_a], *Bw = &wsb[c->body_b];
   int a_dyn = !(A->fixed && A->n == 0), b_dyn = !(Bw->fixed && Bw->n == 0);
   if (!a_dyn && !b_dyn) return 0;
-  double diag = 0, jv = 0;
+  real diag = 0, jv = 0;
   if (a_dyn) {
     s6 f = point_force(A, c->link_a, c->p, dir);
     r->body_a = c->body_a; body_response(A, c->link_a, &f, -1, r->JA, r->RA);
@@ -729,7 +735,7 @@ static int make_contact_row(const Scene* s, const double* st, BodyWS* wsb, const
  * internalSingleStepSimulation order [R]: collide at the current poses, forward
  * dynamics, velocity update, constraint solve, position update) */
 static void substep(dgo_world* w, int env, int last) {
-  Scene* s = &w->sc; double* st = env_state(w, env); double h = s->h;
+  Scene* s = &w->sc; real* st = env_state(w, env); real h = s->h;
   if (last) /* force_torque_sensor: generalised velocities at the start of the step's last substep */
     for (int b = 0; b < s->nb; b++) {
       const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; if (po < 0) continue;
@@ -746,7 +752,7 @@ static void substep(dgo_world* w, int env, int last) {
     BodyWS* ws = &wsb[b];
     if (ws->fixed && ws->n == 0) continue;
     body_aba(s, st, b, ws);
-    double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+    real* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
     if (!ws->fixed) {
       v3 al = lin(&ws->a0), aa = ang(&ws->a0), wb = ang(&ws->v0), vb = lin(&ws->v0);
       v3 acl = vadd(al, vcross(wb, vb)); /* classical acceleration of the base origin */
@@ -759,13 +765,13 @@ static void substep(dgo_world* w, int env, int last) {
     memset(ws->dv, 0, sizeof ws->dv);
   }
   /* rows: motors, then joint limits (btMultiBodyJointMotor / JointLimitConstraint [R]) */
-  double erp = s->F[DG_HF_LIMIT_ERP];
+  real erp = s->F[DG_HF_LIMIT_ERP];
   for (int b = 0; b < s->nb; b++) {
     BodyWS* ws = &wsb[b];
     for (int i = 0; i < ws->n; i++) {
-      int gl = ws->first + i; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; const double* mc = w->mcfg + gl * DG_MC_STRIDE;
+      int gl = ws->first + i; real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; const real* mc = w->mcfg + gl * DG_MC_STRIDE;
       ls[DG_LS_APPLIED] = 0.0;
-      double maxf = mc[DG_MC_MAX_IMPULSE_SCALE], maximp = maxf < 0 ? -maxf : maxf * h;
+      real maxf = mc[DG_MC_MAX_IMPULSE_SCALE], maximp = maxf < 0 ? -maxf : maxf * h;
       if (maximp > 0) {
         Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = gl;
         body_response(ws, -1, NULL, i, r->JA, r->RA);
@@ -779,31 +785,31 @@ static void substep(dgo_world* w, int env, int last) {
   for (int b = 0; b < s->nb; b++) {
     BodyWS* ws = &wsb[b];
     for (int i = 0; i < ws->n; i++) {
-      int gl = ws->first + i; const double* lf = link_f(s, gl); double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+      int gl = ws->first + i; const real* lf = link_f(s, gl); real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
       if (lf[DG_LF_LOWER] > lf[DG_LF_UPPER]) continue;
       for (int side = 0; side < 2; side++) {
-        double sg = side == 0 ? 1.0 : -1.0;
-        double dist = side == 0 ? ls[DG_LS_Q] - lf[DG_LF_LOWER] : lf[DG_LF_UPPER] - ls[DG_LS_Q];
+        real sg = side == 0 ? 1.0 : -1.0;
+        real dist = side == 0 ? ls[DG_LS_Q] - lf[DG_LF_LOWER] : lf[DG_LF_UPPER] - ls[DG_LS_Q];
         if (dist >= 0.25) continue; /* rows that cannot become active within one substep are skipped */
         Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = -1;
         body_response(ws, -1, NULL, i, r->JA, r->RA);
         for (int k = 0; k < 6 + ws->n; k++) { r->JA[k] *= sg; r->RA[k] *= sg; }
         r->diag = r->RA[6 + i] * sg;
-        double relv = sg * ls[DG_LS_QD];
+        real relv = sg * ls[DG_LS_QD];
         r->b = -relv + (dist > 0 ? -dist / h : -dist * erp / h);
-        r->lo = 0; r->hi = 1e300;
+        r->lo = 0; r->hi = HUGE_R;
       }
     }
   }
   /* contacts: all normal rows first, then the friction rows (btMultiBodyConstraintSolver order [R]) */
   int first_normal = nr; int crow[MAXC];
-  double cerp = s->F[DG_HF_CONTACT_ERP], slop = s->F[DG_HF_LINEAR_SLOP];
+  real cerp = s->F[DG_HF_CONTACT_ERP], slop = s->F[DG_HF_LINEAR_SLOP];
   for (int k = 0; k < nc; k++) {
     Row* r = &rows[nr]; crow[k] = -1;
     if (!make_contact_row(s, st, wsb, &cs[k], cs[k].n, r)) continue;
-    double pen = cs[k].dist + slop;
+    real pen = cs[k].dist + slop;
     r->b += pen > 0 ? -pen / h : -pen * cerp / h;
-    r->lo = 0; r->hi = 1e300; crow[k] = nr++;
+    r->lo = 0; r->hi = HUGE_R; crow[k] = nr++;
   }
   (void)first_normal;
   int frow[MAXC][2];
@@ -817,19 +823,19 @@ static void substep(dgo_world* w, int env, int last) {
     }
   }
   /* projected Gauss-Seidel with the residual early-out (pybullet solverResidualThreshold [R]) */
-  double thr = s->F[DG_HF_RESIDUAL_THRESHOLD]; int it;
+  real thr = s->F[DG_HF_RESIDUAL_THRESHOLD]; int it;
   for (it = 0; it < s->iters; it++) {
-    double maxres = 0;
+    real maxres = 0;
     for (int k = 0; k < nr; k++) {
       Row* r = &rows[k];
-      double lo = r->lo, hi = r->hi;
+      real lo = r->lo, hi = r->hi;
       if (r->normal_row >= 0) { hi = r->mu * rows[r->normal_row].acc; lo = -hi; }
-      double delta = (r->b - row_jv(r, wsb)) / r->diag;
-      double nacc = r->acc + delta; nacc = nacc < lo ? lo : (nacc > hi ? hi : nacc);
+      real delta = (r->b - row_jv(r, wsb)) / r->diag;
+      real nacc = r->acc + delta; nacc = nacc < lo ? lo : (nacc > hi ? hi : nacc);
       delta = nacc - r->acc; r->acc = nacc;
       BodyWS* A = &wsb[r->body_a]; for (int j = 0; j < 6 + A->n; j++) A->dv[j] += r->RA[j] * delta;
       if (r->body_b >= 0) { BodyWS* Bw = &wsb[r->body_b]; for (int j = 0; j < 6 + Bw->n; j++) Bw->dv[j] += r->RB[j] * delta; }
-      double res = delta * r->diag; if (res * res > maxres) maxres = res * res;
+      real res = delta * r->diag; if (res * res > maxres) maxres = res * res;
     }
     if (maxres <= thr) { it++; break; }
   }
@@ -841,26 +847,26 @@ static void substep(dgo_world* w, int env, int last) {
   }
   for (int k = 0; k < nr; k++) if (rows[k].motor_link >= 0) st[link_i(s, rows[k].motor_link)[DG_LI_STATE_OFF] + DG_LS_APPLIED] = rows[k].acc / h;
   /* apply velocity changes, integrate positions (btMultiBody::stepPositionsMultiDof [R]) */
-  double vmax = s->F[DG_HF_MAX_COORD_VEL];
+  real vmax = s->F[DG_HF_MAX_COORD_VEL];
   for (int b = 0; b < s->nb; b++) {
     BodyWS* ws = &wsb[b];
     if (ws->fixed && ws->n == 0) continue;
-    double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+    real* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
     if (!ws->fixed) {
       v3 dw = mv(&ws->R0, V(ws->dv[0], ws->dv[1], ws->dv[2])), dl = mv(&ws->R0, V(ws->dv[3], ws->dv[4], ws->dv[5]));
       bs[DG_BS_ANGVEL] += dw.x; bs[DG_BS_ANGVEL + 1] += dw.y; bs[DG_BS_ANGVEL + 2] += dw.z;
       bs[DG_BS_LINVEL] += dl.x; bs[DG_BS_LINVEL + 1] += dl.y; bs[DG_BS_LINVEL + 2] += dl.z;
       for (int k = 0; k < 3; k++) bs[DG_BS_POS + k] += h * bs[DG_BS_LINVEL + k];
       v3 wv = V(bs[DG_BS_ANGVEL], bs[DG_BS_ANGVEL + 1], bs[DG_BS_ANGVEL + 2]);
-      double wn = vnorm(wv), th = wn * h; qt dq;
-      if (th > 1e-12) { double sn = sin(0.5 * th) / wn; dq.x = wv.x * sn; dq.y = wv.y * sn; dq.z = wv.z * sn; dq.w = cos(0.5 * th); }
+      real wn = vnorm(wv), th = wn * h; qt dq;
+      if (th > 1e-12) { real sn = sin(0.5 * th) / wn; dq.x = wv.x * sn; dq.y = wv.y * sn; dq.z = wv.z * sn; dq.w = cos(0.5 * th); }
       else { dq.x = 0.5 * h * wv.x; dq.y = 0.5 * h * wv.y; dq.z = 0.5 * h * wv.z; dq.w = 1.0; }
       qt q0 = {bs[3], bs[4], bs[5], bs[6]}; qt qn = qnormalize(qmul(dq, q0));
       bs[3] = qn.x; bs[4] = qn.y; bs[5] = qn.z; bs[6] = qn.w;
     }
     for (int i = 0; i < ws->n; i++) {
-      double* ls = st + link_i(s, ws->first + i)[DG_LI_STATE_OFF];
-      double qd = ls[DG_LS_QD] + ws->dv[6 + i]; qd = qd > vmax ? vmax : (qd < -vmax ? -vmax : qd);
+      real* ls = st + link_i(s, ws->first + i)[DG_LI_STATE_OFF];
+      real qd = ls[DG_LS_QD] + ws->dv[6 + i]; qd = qd > vmax ? vmax : (qd < -vmax ? -vmax : qd);
       ls[DG_LS_QD] = qd; ls[DG_LS_Q] += h * qd;
     }
   }
@@ -870,18 +876,18 @@ static void substep(dgo_world* w, int env, int last) {
 /* -------------------------------------------------- frames and queries */
 typedef struct { v3 p; qt q; v3 v; v3 w; } FrameState;
 /* world pose/velocity of frame fr (-1 = base) of body b.  com selects the inertial frame. */
-static void frame_state(const Scene* s, const double* st, int b, int fr, int com, const double* q_override, FrameState* o) {
+static void frame_state(const Scene* s, const real* st, int b, int fr, int com, const real* q_override, FrameState* o) {
   BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
   body_kinematics(s, st, b, ws, q_override); body_velocities(s, st, b, ws);
   int lk; v3 off; qt qoff;
   if (fr < 0) {
-    const double* bf = body_f(s, b); lk = -1;
+    const real* bf = body_f(s, b); lk = -1;
     if (com) { off = V(bf[DG_BF_REPORT_POS], bf[DG_BF_REPORT_POS + 1], bf[DG_BF_REPORT_POS + 2]); qt t = {bf[DG_BF_REPORT_QUAT], bf[DG_BF_REPORT_QUAT + 1], bf[DG_BF_REPORT_QUAT + 2], bf[DG_BF_REPORT_QUAT + 3]}; qoff = t; }
     else { off = V(0, 0, 0); qt t = {0, 0, 0, 1}; qoff = t; }
   } else {
-    const int32_t* fi = s->FI + fr * DG_FI_STRIDE; const double* ff = s->FF + fr * DG_FF_STRIDE;
+    const int32_t* fi = s->FI + fr * DG_FI_STRIDE; const real* ff = s->FF + fr * DG_FF_STRIDE;
     lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
-    const double* pp = ff + (com ? DG_FF_COM_POS : DG_FF_POS); const double* qq = ff + (com ? DG_FF_COM_QUAT : DG_FF_QUAT);
+    const real* pp = ff + (com ? DG_FF_COM_POS : DG_FF_POS); const real* qq = ff + (com ? DG_FF_COM_QUAT : DG_FF_QUAT);
     off = V(pp[0], pp[1], pp[2]); qt t = {qq[0], qq[1], qq[2], qq[3]}; qoff = t;
   }
   m3 R; v3 p; link_world(ws, lk, &R, &p);
@@ -893,7 +899,7 @@ static void frame_state(const Scene* s, const double* st, int b, int fr, int com
   o->w = mv(&R, wl); o->v = mv(&R, vadd(vl, vcross(wl, off)));
   free(ws);
 }
-int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, double* out) {
+int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, real* out) {
   FrameState f; frame_state(&w->sc, env_state(w, env), body, frame, com, NULL, &f);
   out[0] = f.p.x; out[1] = f.p.y; out[2] = f.p.z; out[3] = f.q.x; out[4] = f.q.y; out[5] = f.q.z; out[6] = f.q.w;
   out[7] = f.v.x; out[8] = f.v.y; out[9] = f.v.z; out[10] = f.w.x; out[11] = f.w.y; out[12] = f.w.z;
@@ -908,8 +914,8 @@ int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int3
  * DLS + null-space projection variant, otherwise (Jaco) the joint-space DLS
  * variant; steps scaled so no joint moves more than IK_MAX_ANGLE; stop when
  * the position error is below IK_RESIDUAL. */
-static void ik_jacobian(const BodyWS* ws, int lk, v3 pe, double* Jm /* [6][n] */) {
-  int n = ws->n; memset(Jm, 0, sizeof(double) * 6 * (size_t)n);
+static void ik_jacobian(const BodyWS* ws, int lk, v3 pe, real* Jm /* [6][n] */) {
+  int n = ws->n; memset(Jm, 0, sizeof(real) * 6 * (size_t)n);
   for (int i = lk; i >= 0; i = ws->parent[i]) {
     v3 sw = ang(&ws->S[i]), sl = lin(&ws->S[i]);
     v3 aw = mv(&ws->Rw[i], sw), al = mv(&ws->Rw[i], sl);
@@ -917,8 +923,8 @@ static void ik_jacobian(const BodyWS* ws, int lk, v3 pe, double* Jm /* [6][n] */
     Jm[0 * n + i] = jl.x; Jm[1 * n + i] = jl.y; Jm[2 * n + i] = jl.z; Jm[3 * n + i] = aw.x; Jm[4 * n + i] = aw.y; Jm[5 * n + i] = aw.z;
   }
 }
-static void run_ik(dgo_world* w, const double* st, int op, const double* act, double* q /* [n] out */) {
-  const Scene* s = &w->sc; const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+static void run_ik(dgo_world* w, const real* st, int op, const real* act, real* q /* [n] out */) {
+  const Scene* s = &w->sc; const int32_t* oi = s->OI + op * DG_OI_STRIDE; const real* of = s->OF + op * DG_OF_STRIDE;
   int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME], flags = oi[DG_OI_FLAGS];
   int use_orn = flags & DG_IK_USE_ORIENTATION, nullsp = flags & DG_IK_NULLSPACE, m = use_orn ? 6 : 3;
   BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
@@ -930,84 +936,84 @@ static void run_ik(dgo_world* w, const double* st, int op, const double* act, do
   qt tq = cur.q;
   if (use_orn) tq = qmul(cur.q, qfrom_euler(act[3], act[4], act[5])); /* ik_controller.py:56-59 */
   const int32_t* fi = s->FI + fr * DG_FI_STRIDE; int lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
-  const double* rest = s->FL + oi[DG_OI_FLIST]; /* rest[n], lower[n], upper[n], range[n] */
-  double lam2 = s->F[DG_HF_IK_LAMBDA_SQ], jd = s->F[DG_HF_IK_JOINT_DAMPING], maxang = s->F[DG_HF_IK_MAX_ANGLE];
-  double g0 = s->F[DG_HF_IK_NULL_REST_GAIN], g1 = s->F[DG_HF_IK_NULL_LIMIT_GAIN];
+  const real* rest = s->FL + oi[DG_OI_FLIST]; /* rest[n], lower[n], upper[n], range[n] */
+  real lam2 = s->F[DG_HF_IK_LAMBDA_SQ], jd = s->F[DG_HF_IK_JOINT_DAMPING], maxang = s->F[DG_HF_IK_MAX_ANGLE];
+  real g0 = s->F[DG_HF_IK_NULL_REST_GAIN], g1 = s->F[DG_HF_IK_NULL_LIMIT_GAIN];
   (void)of;
   for (int it = 0; it < s->ik_iters; it++) {
     FrameState f; frame_state(s, st, b, fr, 1, q, &f);
     v3 ep = vsub(tp, f.p);
     if (vnorm(ep) < s->F[DG_HF_IK_RESIDUAL] && it > 0) break;
-    double dS[6] = {ep.x, ep.y, ep.z, 0, 0, 0};
+    real dS[6] = {ep.x, ep.y, ep.z, 0, 0, 0};
     if (use_orn) {
       qt dq = qmul(tq, qconj(f.q));
       if (dq.w < 0) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
-      double sn = sqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0 * atan2(sn, dq.w);
-      double k = sn > 1e-12 ? an / sn : 2.0;
+      real sn = sqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), an = 2.0 * atan2(sn, dq.w);
+      real k = sn > 1e-12 ? an / sn : 2.0;
       dS[3] = dq.x * k; dS[4] = dq.y * k; dS[5] = dq.z * k;
     }
     body_kinematics(s, st, b, ws, q);
-    double J6[6 * MAXL], J[6 * MAXL]; ik_jacobian(ws, lk, f.p, J6);
+    real J6[6 * MAXL], J[6 * MAXL]; ik_jacobian(ws, lk, f.p, J6);
     for (int r = 0; r < m; r++) for (int c = 0; c < n; c++) J[r * n + c] = J6[r * n + c];
-    double dth[MAXL];
+    real dth[MAXL];
     if (nullsp) {
-      double U[36], y[6];
-      for (int r = 0; r < m; r++) for (int c = 0; c < m; c++) { double t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * J[c * n + k]; U[r * m + c] = t + (r == c ? lam2 : 0.0); }
+      real U[36], y[6];
+      for (int r = 0; r < m; r++) for (int c = 0; c < m; c++) { real t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * J[c * n + k]; U[r * m + c] = t + (r == c ? lam2 : 0.0); }
       spd_solve(m, U, dS, y);
-      for (int k = 0; k < n; k++) { double t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * y[r]; dth[k] = t; }
+      for (int k = 0; k < n; k++) { real t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * y[r]; dth[k] = t; }
       /* null-space velocity: towards the rest pose, away from violated limits */
-      double v0[MAXL], Jv[6], z[6];
+      real v0[MAXL], Jv[6], z[6];
       for (int k = 0; k < n; k++) {
         v0[k] = g0 * (rest[k] - q[k]);
-        double lo = rest[n + k], hi = rest[2 * n + k], rg = rest[3 * n + k];
+        real lo = rest[n + k], hi = rest[2 * n + k], rg = rest[3 * n + k];
         if (q[k] > hi) v0[k] += g1 * (hi - q[k]) / rg;
         if (q[k] < lo) v0[k] += g1 * (lo - q[k]) / rg;
       }
-      for (int r = 0; r < m; r++) { double t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * v0[k]; Jv[r] = t; }
+      for (int r = 0; r < m; r++) { real t = 0; for (int k = 0; k < n; k++) t += J[r * n + k] * v0[k]; Jv[r] = t; }
       spd_solve(m, U, Jv, z);
-      for (int k = 0; k < n; k++) { double t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * z[r]; dth[k] += v0[k] - t; }
+      for (int k = 0; k < n; k++) { real t = 0; for (int r = 0; r < m; r++) t += J[r * n + k] * z[r]; dth[k] += v0[k] - t; }
     } else {
-      double A[12 * 12], rhs[12];
+      real A[12 * 12], rhs[12];
       if (n > 12) n = 12;
-      for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) { double t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * J[k * ws->n + c]; A[r * n + c] = t + (r == c ? jd : 0.0); }
-        double t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * dS[k]; rhs[r] = t; }
+      for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) { real t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * J[k * ws->n + c]; A[r * n + c] = t + (r == c ? jd : 0.0); }
+        real t = 0; for (int k = 0; k < m; k++) t += J[k * ws->n + r] * dS[k]; rhs[r] = t; }
       spd_solve(n, A, rhs, dth); n = ws->n;
     }
-    double mx = 0; for (int k = 0; k < n; k++) if (fabs(dth[k]) > mx) mx = fabs(dth[k]);
-    double sc = mx > maxang ? maxang / mx : 1.0;
+    real mx = 0; for (int k = 0; k < n; k++) if (fabs(dth[k]) > mx) mx = fabs(dth[k]);
+    real sc = mx > maxang ? maxang / mx : 1.0;
     for (int k = 0; k < n; k++) q[k] += sc * dth[k];
   }
   free(ws);
 }
-int dgo_ik(dgo_world* w, int32_t env, int32_t op, const double* action, double* q_out) {
+int dgo_ik(dgo_world* w, int32_t env, int32_t op, const real* action, real* q_out) {
   run_ik(w, env_state(w, env), op, action, q_out); return 0;
 }
 
 /* ------------------------------------------------------ addon program */
-static void set_motor(dgo_world* w, int gl, double kp, double kd, double maxforce) {
-  double* mc = w->mcfg + gl * DG_MC_STRIDE; mc[DG_MC_KP] = kp; mc[DG_MC_KD] = kd; mc[DG_MC_MAX_IMPULSE_SCALE] = maxforce;
+static void set_motor(dgo_world* w, int gl, real kp, real kd, real maxforce) {
+  real* mc = w->mcfg + gl * DG_MC_STRIDE; mc[DG_MC_KP] = kp; mc[DG_MC_KD] = kd; mc[DG_MC_MAX_IMPULSE_SCALE] = maxforce;
 }
-static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t mask) {
-  Scene* s = &w->sc; double* st = env_state(w, env);
+static void run_update_ops(dgo_world* w, int env, const real* act, uint64_t mask) {
+  Scene* s = &w->sc; real* st = env_state(w, env);
   for (int op = 0; op < s->nops; op++) {
-    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const real* of = s->OF + op * DG_OF_STRIDE;
     int code = oi[DG_OI_CODE];
     if (code < DG_OP_JOINT_CONTROL || code > DG_OP_ADMITTANCE) continue;
     if (!((mask >> oi[DG_OI_SLOT]) & 1ULL)) continue;
-    const double* a = act + oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST]; int n = oi[DG_OI_N];
+    const real* a = act + oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST]; int n = oi[DG_OI_N];
     if (code == DG_OP_JOINT_CONTROL) { /* joint_controller.py:40-58 */
       int mode = oi[DG_OI_FLAGS];
       for (int k = 0; k < n; k++) {
-        int gl = il[k]; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; double maxf = link_f(s, gl)[DG_LF_MAX_FORCE];
+        int gl = il[k]; real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; real maxf = link_f(s, gl)[DG_LF_MAX_FORCE];
         if (mode == DG_JC_POSITION) { ls[DG_LS_TARGET_POS] = a[k]; ls[DG_LS_TARGET_VEL] = 0.0; set_motor(w, gl, of[0], of[1], maxf); }
         else if (mode == DG_JC_VELOCITY) { ls[DG_LS_TARGET_VEL] = a[k]; ls[DG_LS_TARGET_POS] = 0.0; set_motor(w, gl, 0.0, of[1], maxf); }
         else ls[DG_LS_TORQUE] = a[k]; /* TORQUE_CONTROL: the velocity motor is left as it was */
       }
     } else if (code == DG_OP_IK_CONTROL) { /* ik_controller.py:51-80 */
-      double q[MAXL]; run_ik(w, st, op, a, q);
+      real q[MAXL]; run_ik(w, st, op, a, q);
       int first = body_i(s, oi[DG_OI_BODY])[DG_BI_FIRST_LINK];
       for (int k = 0; k < n; k++) {
-        int gl = il[k]; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+        int gl = il[k]; real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
         (void)first;
         ls[DG_LS_TARGET_POS] = q[k]; /* joint_cmds[k] pairs with joint_ids[k] (ik_controller.py:69-74) */
         ls[DG_LS_TARGET_VEL] = 0.0; set_motor(w, gl, of[0], of[1], link_f(s, gl)[DG_LF_MAX_FORCE]);
@@ -1021,19 +1027,19 @@ static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t ma
       FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 1, NULL, &f);
       m3 Rf = qmat(f.q); v3 pw = vadd(f.p, mv(&Rf, V(of[0], of[1], of[2])));
       const int32_t* fi = s->FI + oi[DG_OI_FRAME] * DG_FI_STRIDE; int lk = fi[DG_FI_LINK] < 0 ? -1 : fi[DG_FI_LINK] - ws->first;
-      v3 F = V(a[0], a[1], a[2]), T = V(a[3], a[4], a[5]); const double* tgt = s->FL + oi[DG_OI_FLIST];
+      v3 F = V(a[0], a[1], a[2]), T = V(a[3], a[4], a[5]); const real* tgt = s->FL + oi[DG_OI_FLIST];
       for (int k = 0; k < n; k++) {
-        int gl = il[k], j = gl - ws->first; double* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
+        int gl = il[k], j = gl - ws->first; real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF];
         v3 aw = mv(&ws->Rw[j], ang(&ws->S[j])), lw = mv(&ws->Rw[j], lin(&ws->S[j])); int rev = link_i(s, gl)[DG_LI_TYPE] == 0;
         /* is joint j an ancestor of (or equal to) the end-effector link? */
         int anc = 0; for (int i = lk; i >= 0; i = ws->parent[i]) if (i == j) anc = 1;
-        double tau = 0;
+        real tau = 0;
         if (anc) tau += rev ? vdot(F, vcross(aw, vsub(pw, ws->pw[j]))) + vdot(T, aw) : vdot(F, lw);
         /* gravity: every link in the subtree of j */
         for (int i = 0; i < ws->n; i++) {
           int sub = 0; for (int q = i; q >= 0; q = ws->parent[q]) if (q == j) sub = 1;
           if (!sub) continue;
-          const double* lf = link_f(s, ws->first + i);
+          const real* lf = link_f(s, ws->first + i);
           v3 cw = vadd(ws->pw[i], mv(&ws->Rw[i], V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2])));
           v3 w8 = vscale(s->g, lf[DG_LF_MASS] * link_mass_scale(s, st, ws->first + i));
           tau -= rev ? vdot(w8, vcross(aw, vsub(cw, ws->pw[j]))) : vdot(w8, lw);
@@ -1044,24 +1050,24 @@ static void run_update_ops(dgo_world* w, int env, const double* act, uint64_t ma
       free(ws);
     } else if (code == DG_OP_EXTERNAL_FORCE) { /* external_force.py:21-24: WORLD_FRAME force at a world position */
       int b = oi[DG_OI_BODY]; if (body_fixed(s, b)) continue;
-      double* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; double* ex = body_ext(s, st, b);
+      real* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; real* ex = body_ext(s, st, b);
       v3 f = V(a[0], a[1], a[2]); v3 rel = vsub(V(of[0], of[1], of[2]), V(bs[0], bs[1], bs[2])); v3 t = vcross(rel, f);
       ex[0] += f.x; ex[1] += f.y; ex[2] += f.z; ex[3] += t.x; ex[4] += t.y; ex[5] += t.z;
     } else if (code == DG_OP_PROPELLOR) { /* drone_pilot.py:31-37 */
-      int b = oi[DG_OI_BODY]; double* as = st + s->addon_off + oi[DG_OI_STATE_OFF];
+      int b = oi[DG_OI_BODY]; real* as = st + s->addon_off + oi[DG_OI_STATE_OFF];
       as[0] = as[0] + (a[0] - as[0]) * of[2];
       if (body_fixed(s, b)) continue;
       FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 0, NULL, &f);
-      m3 R = qmat(f.q); double* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; double* ex = body_ext(s, st, b);
+      m3 R = qmat(f.q); real* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; real* ex = body_ext(s, st, b);
       v3 fw = mv(&R, V(0, 0, of[0] * as[0])), tw = mv(&R, V(0, 0, of[1] * as[0]));
       v3 t = vadd(vcross(vsub(f.p, V(bs[0], bs[1], bs[2])), fw), tw);
       ex[0] += fw.x; ex[1] += fw.y; ex[2] += fw.z; ex[3] += t.x; ex[4] += t.y; ex[5] += t.z;
     }
   }
 }
-static void set_base_com_pose(const Scene* s, double* st, int b, v3 pc, qt qc) {
+static void set_base_com_pose(const Scene* s, real* st, int b, v3 pc, qt qc) {
   /* p.resetBasePositionAndOrientation takes the pose of the root inertial frame and zeroes the velocity [R] */
-  const double* bf = body_f(s, b); double* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
+  const real* bf = body_f(s, b); real* bs = st + body_i(s, b)[DG_BI_STATE_OFF];
   qt qr = {bf[DG_BF_REPORT_QUAT], bf[DG_BF_REPORT_QUAT + 1], bf[DG_BF_REPORT_QUAT + 2], bf[DG_BF_REPORT_QUAT + 3]};
   qt ql = qnormalize(qmul(qc, qconj(qr))); m3 R = qmat(ql);
   v3 pl = vsub(pc, mv(&R, V(bf[DG_BF_REPORT_POS], bf[DG_BF_REPORT_POS + 1], bf[DG_BF_REPORT_POS + 2])));
@@ -1069,36 +1075,36 @@ static void set_base_com_pose(const Scene* s, double* st, int b, v3 pc, qt qc) {
   if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) bs[DG_BS_LINVEL + k] = 0.0;
 }
 static void run_reset_ops(dgo_world* w, int env) {
-  Scene* s = &w->sc; double* st = env_state(w, env);
+  Scene* s = &w->sc; real* st = env_state(w, env);
   uint64_t episode = (uint64_t)st[DG_ST_EPISODE];
   for (int op = 0; op < s->nops; op++) {
-    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE; int code = oi[DG_OI_CODE];
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const real* of = s->OF + op * DG_OF_STRIDE; int code = oi[DG_OI_CODE];
     if (code == DG_OP_RESPAWN) { /* respawn.py:31-39 */
       uint64_t ep = (oi[DG_OI_FLAGS] & DG_RS_ONCE) ? 0 : episode + 1, ge = (uint64_t)(w->env_base + env);
-      double u[6]; for (int k = 0; k < 6; k++) u[k] = rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)k) - 0.5;
+      real u[6]; for (int k = 0; k < 6; k++) u[k] = rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)k) - 0.5;
       v3 p = V(of[0] + u[0] * of[7], of[1] + u[1] * of[8], of[2] + u[2] * of[9]);
       qt q0 = {of[3], of[4], of[5], of[6]};
       qt q = qmul(q0, qfrom_euler(u[3] * of[10], u[4] * of[11], u[5] * of[12]));
       set_base_com_pose(s, st, oi[DG_OI_BODY], p, q);
     } else if (code == DG_OP_RESET_JOINTS) { /* joint_controller.py:36-38 */
-      const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST];
-      for (int k = 0; k < oi[DG_OI_N]; k++) { double* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
+      const int32_t* il = s->IL + oi[DG_OI_ILIST]; const real* fl = s->FL + oi[DG_OI_FLIST];
+      for (int k = 0; k < oi[DG_OI_N]; k++) { real* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
     } else if (code == DG_OP_RANDOMIZE_COLOR) { /* visual_randomizer.py:40-46 (flat colour instead of a texture) */
-      double* ps = st + s->addon_off + oi[DG_OI_STATE_OFF]; const uint64_t ge = (uint64_t)(w->env_base + env);
+      real* ps = st + s->addon_off + oi[DG_OI_STATE_OFF]; const uint64_t ge = (uint64_t)(w->env_base + env);
       for (int k = 0; k < 3; k++) ps[k] = rng_uniform(w->seed, ge, episode + 1, (uint64_t)op, (uint64_t)k);
     } else if (code == DG_OP_RANDOMIZE_DYNAMICS) { /* dynamics_randomizer.py:24-32 */
-      const double* fl = s->FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N]; double* ps = st + s->addon_off + oi[DG_OI_STATE_OFF];
+      const real* fl = s->FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N]; real* ps = st + s->addon_off + oi[DG_OI_STATE_OFF];
       const uint64_t ge = (uint64_t)(w->env_base + env);
       /* the reference draws in __init__ and again in the constructor's reset(): two rounds at an env's first reset */
       for (int round = (episode == 0 ? 0 : 1); round < 2; round++) {
         const uint64_t ep = round == 0 ? 0 : episode + 1;
         for (int k = 0; k < n; k++) {
-          const double um = of[0] + (of[1] - of[0]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k));
-          const double ud = of[2] + (of[3] - of[2]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k + 1));
+          const real um = of[0] + (of[1] - of[0]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k));
+          const real ud = of[2] + (of[3] - of[2]) * rng_uniform(w->seed, ge, ep, (uint64_t)op, (uint64_t)(2 * k + 1));
           /* new mass = log(U) * CURRENT mass (guards: |log U|, accumulated scale clamped to [of[4], of[5]]) */
-          double sc_ = ps[k] * fabs(log(um)); sc_ = sc_ < of[4] ? of[4] : (sc_ > of[5] ? of[5] : sc_); ps[k] = sc_;
+          real sc_ = ps[k] * fabs(log(um)); sc_ = sc_ < of[4] ? of[4] : (sc_ > of[5] ? of[5] : sc_); ps[k] = sc_;
           /* angularDamping = log(U) * URDF joint damping: body-wide, the last joint's value stays (guard: >= 0) */
-          double da = log(ud) * fl[k]; ps[n] = da > 0.0 ? da : 0.0;
+          real da = log(ud) * fl[k]; ps[n] = da > 0.0 ? da : 0.0;
         }
       }
     }
@@ -1108,9 +1114,9 @@ static void run_reset_ops(dgo_world* w, int env) {
     for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) st[po + i] = st[link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF] + DG_LS_QD];
     if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) st[po + bi[DG_BI_N_LINKS] + k] = st[bi[DG_BI_STATE_OFF] + DG_BS_LINVEL + k];
   }
-  st[DG_ST_EPISODE] = (double)(episode + 1);
+  st[DG_ST_EPISODE] = (real)(episode + 1);
 }
-static double reach_dist(const Scene* s, const double* st, const int32_t* oi) { /* reach_target.py:21-30 */
+static real reach_dist(const Scene* s, const real* st, const int32_t* oi) { /* reach_target.py:21-30 */
   FrameState a, b;
   /* link frames use getLinkState item 4 (URDF frame); bases use the reported (inertial) position */
   frame_state(s, st, oi[DG_OI_BODY2], oi[DG_OI_FRAME2], oi[DG_OI_FRAME2] < 0, NULL, &a);
@@ -1123,18 +1129,18 @@ static double reach_dist(const Scene* s, const double* st, const int32_t* oi) { 
  * that substep's contact forces on the child side; reported in the child link's inertial frame, torque about its origin
  * [R: Bullet's joint feedback is I^A a + Z^A of the child link in its own (inertial) frame]. */
 typedef struct { m3 R; v3 p, w, v, al, a; } LinkMotion;
-static void link_motion(const Scene* s, const double* st, int b, const BodyWS* ws, int lk /* local, -1 base */, LinkMotion* o) {
-  const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; double h = s->h;
+static void link_motion(const Scene* s, const real* st, int b, const BodyWS* ws, int lk /* local, -1 base */, LinkMotion* o) {
+  const int32_t* bi = body_i(s, b); int po = bi[DG_BI_PREV_OFF]; real h = s->h;
   o->R = ws->R0; o->p = ws->p0; o->w = o->v = o->al = o->a = V(0, 0, 0);
   if (!ws->fixed) {
-    const double* bs = st + bi[DG_BI_STATE_OFF]; const double* pv = st + po + ws->n;
+    const real* bs = st + bi[DG_BI_STATE_OFF]; const real* pv = st + po + ws->n;
     o->v = V(bs[DG_BS_LINVEL], bs[DG_BS_LINVEL + 1], bs[DG_BS_LINVEL + 2]); o->w = V(bs[DG_BS_ANGVEL], bs[DG_BS_ANGVEL + 1], bs[DG_BS_ANGVEL + 2]);
     o->a = vscale(vsub(o->v, V(pv[0], pv[1], pv[2])), 1.0 / h); o->al = vscale(vsub(o->w, V(pv[3], pv[4], pv[5])), 1.0 / h);
   }
   int path[MAXL], np = 0; for (int k = lk; k >= 0; k = ws->parent[k]) path[np++] = k;
   for (int t = np - 1; t >= 0; t--) {
-    int j = path[t]; int gl = ws->first + j; const double* lf = link_f(s, gl);
-    double qd = st[link_i(s, gl)[DG_LI_STATE_OFF] + DG_LS_QD], qdd = (qd - st[po + j]) / h;
+    int j = path[t]; int gl = ws->first + j; const real* lf = link_f(s, gl);
+    real qd = st[link_i(s, gl)[DG_LI_STATE_OFF] + DG_LS_QD], qdd = (qd - st[po + j]) / h;
     v3 ax = mv(&ws->Rw[j], V(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2])), r = vsub(ws->pw[j], o->p);
     v3 a1 = vadd(o->a, vadd(vcross(o->al, r), vcross(o->w, vcross(o->w, r)))), v1 = vadd(o->v, vcross(o->w, r));
     if (link_i(s, gl)[DG_LI_TYPE] == 0) { o->al = vadd(o->al, vadd(vscale(ax, qdd), vcross(o->w, vscale(ax, qd)))); o->a = a1; o->v = v1; o->w = vadd(o->w, vscale(ax, qd)); }
@@ -1142,7 +1148,7 @@ static void link_motion(const Scene* s, const double* st, int b, const BodyWS* w
     o->R = ws->Rw[j]; o->p = ws->pw[j];
   }
 }
-static void ft_add_part(const Scene* s, const LinkMotion* m, double mass, v3 c, const m3* Ic, v3 ps, v3* F, v3* T) {
+static void ft_add_part(const Scene* s, const LinkMotion* m, real mass, v3 c, const m3* Ic, v3 ps, v3* F, v3* T) {
   v3 rc = mv(&m->R, c), pc = vadd(m->p, rc);
   v3 ac = vadd(m->a, vadd(vcross(m->al, rc), vcross(m->w, vcross(m->w, rc))));
   v3 f = vscale(vsub(ac, s->g), mass);
@@ -1151,27 +1157,27 @@ static void ft_add_part(const Scene* s, const LinkMotion* m, double mass, v3 c, 
   v3 nt = vadd(mv(&Iw, m->al), vcross(m->w, mv(&Iw, m->w)));
   *F = vadd(*F, f); *T = vadd(*T, vadd(nt, vcross(vsub(pc, ps), f)));
 }
-static void ft_wrench(dgo_world* w, int env, const int32_t* oi, int with_contacts, double* out6) {
-  Scene* s = &w->sc; const double* st = env_state(w, env); int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME];
+static void ft_wrench(dgo_world* w, int env, const int32_t* oi, int with_contacts, real* out6) {
+  Scene* s = &w->sc; const real* st = env_state(w, env); int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME];
   BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); body_kinematics(s, st, b, ws, NULL);
-  const int32_t* il = s->IL + oi[DG_OI_ILIST]; const double* fl = s->FL + oi[DG_OI_FLIST]; const double* ff = s->FF + fr * DG_FF_STRIDE;
+  const int32_t* il = s->IL + oi[DG_OI_ILIST]; const real* fl = s->FL + oi[DG_OI_FLIST]; const real* ff = s->FF + fr * DG_FF_STRIDE;
   int ga = s->FI[fr * DG_FI_STRIDE + DG_FI_LINK], la = ga < 0 ? -1 : ga - ws->first;
   LinkMotion ma; link_motion(s, st, b, ws, la, &ma);
   qt qo = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]}; m3 Ro = qmat(qo);
   m3 Rs = mmul(&ma.R, &Ro); v3 ps = vadd(ma.p, mv(&ma.R, V(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2])));
   v3 F = V(0, 0, 0), T = V(0, 0, 0);
   if (oi[DG_OI_FLAGS] & DG_FT_WHOLE_LINK) {
-    const double* lf = link_f(s, ga); double ms = link_mass_scale(s, st, ga); m3 Ic = msym6(lf + DG_LF_INERTIA);
+    const real* lf = link_f(s, ga); real ms = link_mass_scale(s, st, ga); m3 Ic = msym6(lf + DG_LF_INERTIA);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
     ft_add_part(s, &ma, lf[DG_LF_MASS] * ms, V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]), &Ic, ps, &F, &T);
   } else if (fl[0] > 0.0) {
-    double ms = ga >= 0 ? link_mass_scale(s, st, ga) : 1.0; m3 Ic = msym6(fl + 4);
+    real ms = ga >= 0 ? link_mass_scale(s, st, ga) : 1.0; m3 Ic = msym6(fl + 4);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
     ft_add_part(s, &ma, fl[0] * ms, V(fl[1], fl[2], fl[3]), &Ic, ps, &F, &T);
   }
   int nm = il[0];
   for (int k = 0; k < nm; k++) {
-    int gl = il[1 + k]; const double* lf = link_f(s, gl); double ms = link_mass_scale(s, st, gl); m3 Ic = msym6(lf + DG_LF_INERTIA);
+    int gl = il[1 + k]; const real* lf = link_f(s, gl); real ms = link_mass_scale(s, st, gl); m3 Ic = msym6(lf + DG_LF_INERTIA);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ic.m[r][c] *= ms;
     LinkMotion mk; link_motion(s, st, b, ws, gl - ws->first, &mk);
     ft_add_part(s, &mk, lf[DG_LF_MASS] * ms, V(lf[DG_LF_COM], lf[DG_LF_COM + 1], lf[DG_LF_COM + 2]), &Ic, ps, &F, &T);
@@ -1193,11 +1199,11 @@ static void ft_wrench(dgo_world* w, int env, const int32_t* oi, int with_contact
 }
 /* ft_mode: 0 = after a step (the last substep's contacts count), 1 = plain observe (no contact term), 2 = leave the
  * force/torque columns as they are (envs a masked reset did not touch) */
-static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag, int ft_mode) {
-  Scene* s = &w->sc; const double* st = env_state(w, env);
-  double rsum = 0; int gany[64]; memset(gany, 0, sizeof gany); int any = 0;
+static void run_output_ops(dgo_world* w, int env, real* obs, real* rew, uint8_t* term, real* rew_sum, uint8_t* term_flag, int ft_mode) {
+  Scene* s = &w->sc; const real* st = env_state(w, env);
+  real rsum = 0; int gany[64]; memset(gany, 0, sizeof gany); int any = 0;
   for (int op = 0; op < s->nops; op++) {
-    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const double* of = s->OF + op * DG_OF_STRIDE;
+    const int32_t* oi = s->OI + op * DG_OI_STRIDE; const real* of = s->OF + op * DG_OF_STRIDE;
     int code = oi[DG_OI_CODE], io = oi[DG_OI_IO_OFF]; const int32_t* il = s->IL + oi[DG_OI_ILIST];
     if (code == DG_OP_OBS_JOINT_STATE) { /* joint_state_sensor.py:47-57 */
       int n = oi[DG_OI_N], k2 = n;
@@ -1222,11 +1228,11 @@ static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint
       for (int k = 0; k < oi[DG_OI_N]; k++) if (obs) obs[io + k] = st[s->addon_off + oi[DG_OI_STATE_OFF] + k];
     } else if (code == DG_OP_OBS_FT) {
       if (obs && ft_mode != 2) ft_wrench(w, env, oi, ft_mode == 0, obs + io);
-    } else if (code == DG_OP_REW_REACH) { double r = -reach_dist(s, st, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
+    } else if (code == DG_OP_REW_REACH) { real r = -reach_dist(s, st, oi) * of[0]; if (rew) rew[io] = r; rsum += r; }
     else if (code == DG_OP_REW_ELECTRICITY) { /* electricity_cost.py:15-18 */
-      const int32_t* bi = body_i(s, oi[DG_OI_BODY]); double acc = 0;
-      for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) { const double* ls = st + link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabs(ls[DG_LS_APPLIED] * ls[DG_LS_QD]); }
-      double r = -acc * of[0]; if (rew) rew[io] = r; rsum += r;
+      const int32_t* bi = body_i(s, oi[DG_OI_BODY]); real acc = 0;
+      for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) { const real* ls = st + link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF]; acc += fabs(ls[DG_LS_APPLIED] * ls[DG_LS_QD]); }
+      real r = -acc * of[0]; if (rew) rew[io] = r; rsum += r;
     } else if (code == DG_OP_REW_CONST) { if (rew) rew[io] = of[0]; rsum += of[0]; }
     else if (code == DG_OP_TERM_REACH || code == DG_OP_TERM_TILT || code == DG_OP_TERM_TIMER) {
       int t = 0;
@@ -1247,14 +1253,14 @@ static void run_output_ops(dgo_world* w, int env, double* obs, double* rew, uint
 }
 
 static void sim_step(dgo_world* w, int env) {
-  Scene* s = &w->sc; double* st = env_state(w, env);
+  Scene* s = &w->sc; real* st = env_state(w, env);
   for (int k = 0; k < s->substeps; k++) substep(w, env, k == s->substeps - 1);
   /* external wrenches and joint torques last for one stepSimulation [R] */
-  for (int b = 0; b < s->nb; b++) { if (body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue; double* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
+  for (int b = 0; b < s->nb; b++) { if (body_i(s, b)[DG_BI_FLAGS] & DG_BODY_FROZEN) continue; real* ex = body_ext(s, st, b); for (int k = 0; k < 6; k++) ex[k] = 0.0; }
   for (int l = 0; l < s->nl; l++) st[link_i(s, l)[DG_LI_STATE_OFF] + DG_LS_TORQUE] = 0.0;
 }
 
-static int observe_all(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag, int ft_mode, const uint8_t* fresh) {
+static int observe_all(dgo_world* w, real* obs, real* rew, uint8_t* term, real* rew_sum, uint8_t* term_flag, int ft_mode, const uint8_t* fresh) {
   Scene* s = &w->sc;
   for (int e = 0; e < w->B; e++)
     run_output_ops(w, e, obs ? obs + (size_t)e * s->obs_dim : NULL, rew ? rew + (size_t)e * s->rew_dim : NULL,
@@ -1262,15 +1268,15 @@ static int observe_all(dgo_world* w, double* obs, double* rew, uint8_t* term, do
                    (fresh && !fresh[e]) ? 2 : ft_mode);
   return 0;
 }
-int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag) {
+int dgo_observe(dgo_world* w, real* obs, real* rew, uint8_t* term, real* rew_sum, uint8_t* term_flag) {
   return observe_all(w, obs, rew, term, rew_sum, term_flag, 1, NULL);
 }
 /* reference diy_gym.py:130-148 */
-int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
+int dgo_reset(dgo_world* w, const uint8_t* mask, real* obs) {
   Scene* s = &w->sc;
   for (int e = 0; e < w->B; e++) {
     if (mask && !mask[e]) continue;
-    double* st = env_state(w, e);
+    real* st = env_state(w, e);
     st[DG_ST_STEP] = 0.0;
     run_reset_ops(w, e);
     for (int k = 0; k < s->hot_start; k++) sim_step(w, e);
@@ -1279,14 +1285,14 @@ int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs) {
   return 0;
 }
 /* reference diy_gym.py:187-209 */
-int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* obs, double* rew, uint8_t* term, double* rew_sum,
+int dgo_step(dgo_world* w, const real* actions, uint64_t update_mask, real* obs, real* rew, uint8_t* term, real* rew_sum,
              uint8_t* term_flag) {
   Scene* s = &w->sc;
   /* envs are independent; the motor table is uniform over envs and every env writes the same values
    * into it, so it is brought up to date by env 0 first and the remaining envs can run in parallel */
   int e0 = 0;
   if (w->B > 0) {
-    double* st = env_state(w, 0);
+    real* st = env_state(w, 0);
     if (actions) run_update_ops(w, 0, actions, update_mask);
     st[DG_ST_STEP] += 1.0; sim_step(w, 0); e0 = 1;
   }
@@ -1294,7 +1300,7 @@ int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* 
 #pragma omp parallel for schedule(static)
 #endif
   for (int e = e0; e < w->B; e++) {
-    double* st = env_state(w, e);
+    real* st = env_state(w, e);
     if (actions) run_update_ops(w, e, actions + (size_t)e * s->act_dim, update_mask);
     st[DG_ST_STEP] += 1.0;
     sim_step(w, e);
@@ -1308,37 +1314,37 @@ int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* 
  * formula (:82-85) returns the eye-space z of the nearest surface (negative; -far where nothing is hit).
  * pybullet's DIRECT-mode renderer draws the VISUAL meshes with lighting; this restatement ray-casts the
  * collision geometry, so rgb is not a parity quantity. */
-typedef struct { double t; v3 n; int shape; } RayHit;
-static void ray_sphere(v3 o, v3 d, v3 c, double r, RayHit* h, int sh) {
-  v3 oc = vsub(o, c); double a = vdot(d, d), b = vdot(oc, d), cc = vdot(oc, oc) - r * r, disc = b * b - a * cc;
+typedef struct { real t; v3 n; int shape; } RayHit;
+static void ray_sphere(v3 o, v3 d, v3 c, real r, RayHit* h, int sh) {
+  v3 oc = vsub(o, c); real a = vdot(d, d), b = vdot(oc, d), cc = vdot(oc, oc) - r * r, disc = b * b - a * cc;
   if (disc < 0) return;
-  double t = (-b - sqrt(disc)) / a;
+  real t = (-b - sqrt(disc)) / a;
   if (t > 0 && t < h->t) { h->t = t; h->n = vscale(vsub(vadd(o, vscale(d, t)), c), 1.0 / r); h->shape = sh; }
 }
-static void ray_slabs(v3 o, v3 d, const double* hx, double* tn, double* tf, int* axis, double* sgn) {
-  double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}; *tn = -1e300; *tf = 1e300; *axis = 0; *sgn = 1;
+static void ray_slabs(v3 o, v3 d, const real* hx, real* tn, real* tf, int* axis, real* sgn) {
+  real oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}; *tn = -HUGE_R; *tf = HUGE_R; *axis = 0; *sgn = 1;
   for (int k = 0; k < 3; k++) {
-    if (fabs(dd[k]) < 1e-300) { if (fabs(oo[k]) > hx[k]) { *tn = 1e300; *tf = -1e300; } continue; }
-    double t1 = (-hx[k] - oo[k]) / dd[k], t2 = (hx[k] - oo[k]) / dd[k], s = -1;
-    if (t1 > t2) { double tt = t1; t1 = t2; t2 = tt; s = 1; }
+    if (fabs(dd[k]) < TINY_R) { if (fabs(oo[k]) > hx[k]) { *tn = HUGE_R; *tf = -HUGE_R; } continue; }
+    real t1 = (-hx[k] - oo[k]) / dd[k], t2 = (hx[k] - oo[k]) / dd[k], s = -1;
+    if (t1 > t2) { real tt = t1; t1 = t2; t2 = tt; s = 1; }
     if (t1 > *tn) { *tn = t1; *axis = k; *sgn = s; }
     if (t2 < *tf) *tf = t2;
   }
 }
-static void ray_box(v3 o, v3 d, const m3* R, v3 p, const double* hx, RayHit* h, int sh) {
-  v3 ol = mtv(R, vsub(o, p)), dl = mtv(R, d); double tn, tf, sg; int ax;
+static void ray_box(v3 o, v3 d, const m3* R, v3 p, const real* hx, RayHit* h, int sh) {
+  v3 ol = mtv(R, vsub(o, p)), dl = mtv(R, d); real tn, tf, sg; int ax;
   ray_slabs(ol, dl, hx, &tn, &tf, &ax, &sg);
   if (tn > tf || tn <= 0 || tn >= h->t) return;
   v3 nl = V(ax == 0 ? sg : 0, ax == 1 ? sg : 0, ax == 2 ? sg : 0);
   h->t = tn; h->n = mv(R, nl); h->shape = sh;
 }
-static void ray_capsule(v3 o, v3 d, v3 e0, v3 e1, double r, RayHit* h, int sh) {
-  v3 ax = vsub(e1, e0); double L2 = vdot(ax, ax);
+static void ray_capsule(v3 o, v3 d, v3 e0, v3 e1, real r, RayHit* h, int sh) {
+  v3 ax = vsub(e1, e0); real L2 = vdot(ax, ax);
   if (L2 > 1e-24) {
-    v3 oc = vsub(o, e0); double dax = vdot(d, ax), oax = vdot(oc, ax);
-    double a = vdot(d, d) - dax * dax / L2, b = vdot(oc, d) - oax * dax / L2, c = vdot(oc, oc) - oax * oax / L2 - r * r, disc = b * b - a * c;
+    v3 oc = vsub(o, e0); real dax = vdot(d, ax), oax = vdot(oc, ax);
+    real a = vdot(d, d) - dax * dax / L2, b = vdot(oc, d) - oax * dax / L2, c = vdot(oc, oc) - oax * oax / L2 - r * r, disc = b * b - a * c;
     if (a > 1e-24 && disc >= 0) {
-      double t = (-b - sqrt(disc)) / a, s = (oax + t * dax) / L2;
+      real t = (-b - sqrt(disc)) / a, s = (oax + t * dax) / L2;
       if (t > 0 && t < h->t && s >= 0 && s <= 1) {
         v3 pt = vadd(o, vscale(d, t)); v3 q = vadd(e0, vscale(ax, s));
         h->t = t; h->n = vscale(vsub(pt, q), 1.0 / r); h->shape = sh;
@@ -1347,28 +1353,28 @@ static void ray_capsule(v3 o, v3 d, v3 e0, v3 e1, double r, RayHit* h, int sh) {
   }
   ray_sphere(o, d, e0, r, h, sh); ray_sphere(o, d, e1, r, h, sh);
 }
-static void ray_hull(v3 o, v3 d, const m3* Rl, v3 pl, const double* planes, int np, RayHit* h, int sh) {
-  v3 ol = mtv(Rl, vsub(o, pl)), dl = mtv(Rl, d); double tn = -1e300, tf = 1e300; v3 nn = V(0, 0, 1);
+static void ray_hull(v3 o, v3 d, const m3* Rl, v3 pl, const real* planes, int np, RayHit* h, int sh) {
+  v3 ol = mtv(Rl, vsub(o, pl)), dl = mtv(Rl, d); real tn = -HUGE_R, tf = HUGE_R; v3 nn = V(0, 0, 1);
   for (int k = 0; k < np; k++) {
-    const double* pp = planes + 4 * k; v3 n = V(pp[0], pp[1], pp[2]);
-    double den = vdot(n, dl), dist = vdot(n, ol) + pp[3];
-    if (fabs(den) < 1e-300) { if (dist > 0) return; continue; }
-    double t = -dist / den;
+    const real* pp = planes + 4 * k; v3 n = V(pp[0], pp[1], pp[2]);
+    real den = vdot(n, dl), dist = vdot(n, ol) + pp[3];
+    if (fabs(den) < TINY_R) { if (dist > 0) return; continue; }
+    real t = -dist / den;
     if (den < 0) { if (t > tn) { tn = t; nn = n; } } else if (t < tf) tf = t;
   }
   if (np == 0 || tn > tf || tn <= 0 || tn >= h->t) return;
   h->t = tn; h->n = mv(Rl, nn); h->shape = sh;
 }
-int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t* seg) {
-  Scene* s = &w->sc; const int32_t* I = s->I; const double* F = s->F;
+int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* seg) {
+  Scene* s = &w->sc; const int32_t* I = s->I; const real* F = s->F;
   if (camera < 0 || camera >= I[DG_H_N_CAMERAS]) { set_err("camera %d out of range", camera); return -1; }
-  const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE; const double* cf = F + I[DG_H_OFF_CAMERA_F] + camera * DG_CF_STRIDE;
-  const double* PLN = F + I[DG_H_OFF_PLANE_F];
-  const int W = ci[DG_CI_WIDTH], Hh = ci[DG_CI_HEIGHT]; const double fov = cf[DG_CF_FOV], zn = cf[DG_CF_NEAR], zf = cf[DG_CF_FAR];
-  const double tanh2 = tan(0.5 * fov * M_PI / 180.0), aspect = (double)W / (double)Hh;
+  const int32_t* ci = I + I[DG_H_OFF_CAMERA_I] + camera * DG_CI_STRIDE; const real* cf = F + I[DG_H_OFF_CAMERA_F] + camera * DG_CF_STRIDE;
+  const real* PLN = F + I[DG_H_OFF_PLANE_F];
+  const int W = ci[DG_CI_WIDTH], Hh = ci[DG_CI_HEIGHT]; const real fov = cf[DG_CF_FOV], zn = cf[DG_CF_NEAR], zf = cf[DG_CF_FAR];
+  const real tanh2 = tan(0.5 * fov * M_PI / 180.0), aspect = (real)W / (real)Hh;
   const v3 light = V(0.30151134457776363, 0.30151134457776363, 0.9045340337332909);
   for (int e = 0; e < w->B; e++) {
-    const double* st = env_state(w, e);
+    const real* st = env_state(w, e);
     BodyWS* wsb = (BodyWS*)malloc(sizeof(BodyWS) * (size_t)s->nb);
     for (int b = 0; b < s->nb; b++) body_kinematics(s, st, b, &wsb[b], NULL);
     /* camera pose */
@@ -1382,7 +1388,7 @@ int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t
     WShape* shp = (WShape*)malloc(sizeof(WShape) * (size_t)(s->nsh > 0 ? s->nsh : 1));
     for (int k = 0; k < s->nsh; k++) shape_world(s, wsb, k, &shp[k]);
     for (int row = 0; row < Hh; row++) for (int col = 0; col < W; col++) {
-      const double xn = ((col + 0.5) / W) * 2.0 - 1.0, yn = 1.0 - ((row + 0.5) / Hh) * 2.0;
+      const real xn = ((col + 0.5) / W) * 2.0 - 1.0, yn = 1.0 - ((row + 0.5) / Hh) * 2.0;
       v3 d = mv(&Rc, V(xn * tanh2 * aspect, yn * tanh2, -1.0));
       RayHit h; h.t = zf; h.shape = -1; h.n = V(0, 0, 1);
       for (int k = 0; k < s->nsh; k++) {
@@ -1399,11 +1405,11 @@ int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t
         else { const int32_t* si = s->SI + h.shape * DG_SI_STRIDE; seg[px] = si[DG_SI_BODY] + ((((si[DG_SI_FLAGS] >> 8) & 0xFFFF)) << 24); }
       }
       if (rgb) {
-        double c[3] = {0.75, 0.75, 0.75};
+        real c[3] = {0.75, 0.75, 0.75};
         if (hit) {
           const int hb_ = s->SI[h.shape * DG_SI_STRIDE + DG_SI_BODY]; const int co_ = body_i(s, hb_)[DG_BI_COLOR_OFF];
-          const double* col4 = co_ >= 0 ? st + co_ : body_f(s, hb_) + DG_BF_COLOR;  /* per-env colour of a visual_randomizer */
-          double nl = vdot(h.n, light); double sh = 0.4 + 0.6 * (nl > 0 ? nl : 0);
+          const real* col4 = co_ >= 0 ? st + co_ : body_f(s, hb_) + DG_BF_COLOR;  /* per-env colour of a visual_randomizer */
+          real nl = vdot(h.n, light); real sh = 0.4 + 0.6 * (nl > 0 ? nl : 0);
           for (int k = 0; k < 3; k++) c[k] = col4[k] * sh;
         }
         for (int k = 0; k < 3; k++) rgb[3 * px + k] = c[k];
@@ -1414,17 +1420,17 @@ int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t
   return 0;
 }
 
-int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, double* qdd_out, double* base_acc6_out) {
-  Scene* s = &w->sc; double* st = env_state(w, env);
+int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, real* qdd_out, real* base_acc6_out) {
+  Scene* s = &w->sc; real* st = env_state(w, env);
   BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS));
   body_kinematics(s, st, body, ws, NULL); body_velocities(s, st, body, ws); body_aba(s, st, body, ws);
   for (int i = 0; i < ws->n; i++) qdd_out[i] = ws->qdd[i];
   if (base_acc6_out) for (int k = 0; k < 6; k++) base_acc6_out[k] = ws->a0.v[k];
   free(ws); return 0;
 }
-int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, double* dv_out) {
-  Scene* s = &w->sc; double* st = env_state(w, env);
-  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); double J[MAXV];
+int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, real* dv_out) {
+  Scene* s = &w->sc; real* st = env_state(w, env);
+  BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); real J[MAXV];
   body_kinematics(s, st, body, ws, NULL); body_velocities(s, st, body, ws); body_aba(s, st, body, ws);
   body_response(ws, -1, NULL, dof, J, dv_out);
   free(ws); return 0;

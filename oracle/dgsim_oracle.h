@@ -12,6 +12,15 @@
 extern "C" {
 #endif
 
+/* Arithmetic type of the whole oracle: fp64 (the checker the parity tests use) unless built with -DDGO_REAL=float
+ * (libdgsim_oracle_f32*.so: bench.py's cpu_baseline times the same algorithm at the precision the HIP path computes in).
+ * Every `real*` below is that type; dgo_real_bytes() tells a binding which one it loaded.  The scene blob stays fp64. */
+#ifndef DGO_REAL
+#define DGO_REAL double
+#endif
+typedef DGO_REAL real;
+int32_t dgo_real_bytes(void);
+
 typedef struct dgo_world dgo_world;
 
 /* Build a world of `num_envs` independent copies of the scene blob
@@ -25,37 +34,37 @@ const char* dgo_last_error(void);
 
 int32_t dgo_state_dim(const dgo_world* w);
 /* state is env-major here: state[env * state_dim + k] */
-double* dgo_state(dgo_world* w);
+real* dgo_state(dgo_world* w);
 /* motor configuration table [n_links][DG_MC_STRIDE], uniform over envs */
-double* dgo_motor_cfg(dgo_world* w);
+real* dgo_motor_cfg(dgo_world* w);
 
 /* reset the envs whose mask byte is non-zero (mask == NULL: all), run the reset
  * ops, hot_start sim steps, then write obs[num_envs][obs_dim] for ALL envs
  * (obs may be NULL). */
-int dgo_reset(dgo_world* w, const uint8_t* mask, double* obs);
+int dgo_reset(dgo_world* w, const uint8_t* mask, real* obs);
 
 /* one DIYGym.step(): update ops selected by `update_mask` (bit = DG_OI_SLOT),
  * one simulation step, outputs.  Any output pointer may be NULL.
  *   actions [num_envs][act_dim], obs [num_envs][obs_dim],
  *   rew [num_envs][rew_dim], term [num_envs][term_dim] (0/1),
  *   rew_sum [num_envs], term_any [num_envs] (collapsed per DG_H_* modes) */
-int dgo_step(dgo_world* w, const double* actions, uint64_t update_mask, double* obs, double* rew, uint8_t* term,
-             double* rew_sum, uint8_t* term_flag);
+int dgo_step(dgo_world* w, const real* actions, uint64_t update_mask, real* obs, real* rew, uint8_t* term,
+             real* rew_sum, uint8_t* term_flag);
 
 /* outputs for the current state without stepping */
-int dgo_observe(dgo_world* w, double* obs, double* rew, uint8_t* term, double* rew_sum, uint8_t* term_flag);
+int dgo_observe(dgo_world* w, real* obs, real* rew, uint8_t* term, real* rew_sum, uint8_t* term_flag);
 
 /* world pose + velocity of a frame: out[0..2] pos, [3..6] quat, [7..9] linear
  * velocity, [10..12] angular velocity.  frame = -1: base.  com != 0 selects the
  * inertial frame (getLinkState items 0,1,6,7), else the URDF link frame (4,5). */
-int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, double* out13);
+int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int32_t com, real* out13);
 
 /* camera `camera` (index in the blob's camera table) for every env, by ray casting the collision
  * geometry (reference diy_gym/addons/sensors/camera.py:58-92).  rgb[num_envs][h*w*3] (flat shaded,
  * NOT a parity output), depth[num_envs][h*w] = eye-space z as the reference's formula yields it
  * (negative, -far for background), seg[num_envs][h*w] = uid + ((link + 1) << 24), -1 background.
  * Flat pixel index = row * width + col, row 0 at the top.  Any pointer may be NULL. */
-int dgo_render(dgo_world* w, int32_t camera, double* rgb, double* depth, int32_t* seg);
+int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* seg);
 
 /* diagnostics from the most recent substep of env `env` */
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env);
@@ -64,11 +73,11 @@ int32_t dgo_last_iterations(const dgo_world* w, int32_t env);
 /* stand-alone pieces exposed for known-answer tests */
 /* joint-space inverse dynamics check: returns qdd for body `body` of env `env`
  * at the current state with zero motor action (pure ABA, gravity + damping). */
-int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, double* qdd_out, double* base_acc6_out);
+int dgo_forward_dynamics(dgo_world* w, int32_t env, int32_t body, real* qdd_out, real* base_acc6_out);
 /* joint-space mass matrix inverse column through the ABA impulse response */
-int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, double* dv_out);
+int dgo_unit_response(dgo_world* w, int32_t env, int32_t body, int32_t dof, real* dv_out);
 /* run the IK restatement only; q_out[n_links of body] */
-int dgo_ik(dgo_world* w, int32_t env, int32_t op_index, const double* action, double* q_out);
+int dgo_ik(dgo_world* w, int32_t env, int32_t op_index, const real* action, real* q_out);
 
 #ifdef __cplusplus
 }

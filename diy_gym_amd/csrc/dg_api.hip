@@ -286,7 +286,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
-  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
+  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.warm_off = I[DG_H_WARM_OFF]; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
   sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail; sc.nt = nt; sc.dense = dense ? 1 : 0; sc.dv_base = nb > 0 ? PLB[PLB_DV] : 0;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   // bodies whose solver rows are held in registers by the step kernel

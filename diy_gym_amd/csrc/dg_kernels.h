@@ -56,6 +56,7 @@ struct DevScene {
   int32_t no_sliced_reset;  // DG_NO_SLICED_RESET
   int32_t no_minv_slices;  // DG_NO_MINV_SLICES: the M^-1 columns stay with one lane per env (ablation / tests)
   int32_t nsha; // 1 + the last shape that is not an analytic box (the narrow phase caches a segment per round shape)
+  int32_t warm_off;  // state offset of the contact impulse cache (DG_WS_*), -1: no warm starting
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
@@ -78,7 +79,8 @@ enum { AW_E = 0, AW_R = 9, AW_V = 12, AW_PA = 18, AW_U = 24, AW_D = 30, AW_UU = 
 // transient base block (before the per-link blocks): V, A always; IA, PA, L only when a floating base exists
 enum { AB_V = 0, AB_A = 6, AB_FIXED_STRIDE = 12, AB_IA = 12, AB_PA = 33, AB_L = 39, AB_FLOAT_STRIDE = 60 };
 // contact list entry (body info is per lane: the pair id differs between lanes)
-enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_DVA = 8, CL_NVA = 9, CL_DVB = 10, CL_NVB = 11, CL_MU = 12, CL_STRIDE = 13 };
+// (CL_KEY: DG_CONTACT_KEY(pair, feature), the contact's identity from substep to substep -- warm starting)
+enum { CL_PAIR = 0, CL_P = 1, CL_N = 4, CL_DIST = 7, CL_KEY = 8, CL_DVA = 9, CL_NVA = 10, CL_DVB = 11, CL_NVB = 12, CL_MU = 13, CL_STRIDE = 14 };
 // motor / limit row block per link: b_motor acc_motor b_lo acc_lo b_hi acc_hi
 enum { MR_B = 0, MR_ACC, MR_LO_B, MR_LO_ACC, MR_HI_B, MR_HI_ACC, MR_STRIDE };
 

@@ -90,10 +90,10 @@ DGD void seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
 
 // contact list lives at sc.cont_off: slot 0 = count, then max_contacts entries of CL_STRIDE
 template <int LANES>
-DGD void emit_contact(const Lane<LANES>& ln, int list, int& cnt, int pair, const Hit& h, float flip) {
+DGD void emit_contact(const Lane<LANES>& ln, int list, int& cnt, int pair, const Hit& h, float flip, int feature = 0) {
   if (!h.hit || cnt >= ln.sc.max_contacts) return;
   int o = list + 1 + cnt * CL_STRIDE;
-  ln.L(o + CL_PAIR) = (float)pair;
+  ln.L(o + CL_PAIR) = (float)pair; ln.L(o + CL_KEY) = (float)DG_CONTACT_KEY(pair, feature);
   ln.L3set(o + CL_P, (h.pa + h.pb) * 0.5f);
   ln.L3set(o + CL_N, h.n * flip);
   ln.L(o + CL_DIST) = h.dist;
@@ -177,7 +177,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
         const int oa = sc.tr_off + sa * SC_STRIDE;
         const V3 ca = ln.L3(oa + SC_C);
         // up to four contacts per pair, in fixed slots (sphere: 0; capsule: its two ends; hull: its four deepest corners)
-        float hp[4][3], hn[4][3], hd[4]; unsigned hv = 0u;
+        float hp[4][3], hn[4][3], hd[4]; unsigned hv = 0u; int hf[4] = {0, 1, 0, 0};  // (feature of slot j: capsule end j; a hull's vertex index, below)
         auto keep = [&](int j, const Hit& h, bool ok) {
           if (h.hit && ok) hv |= 1u << j;
           const V3 m = (h.pa + h.pb) * 0.5f, nn = h.n * flip;
@@ -211,7 +211,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              cfp pp = sc.PF + 3 * (poff + (bi4[j] < 0 ? 0 : bi4[j]));
+              cfp pp = sc.PF + 3 * (poff + (bi4[j] < 0 ? 0 : bi4[j])); hf[j] = bi4[j] < 0 ? 0 : bi4[j];
               keep(j, sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin), bi4[j] >= 0);
             }
           }
@@ -226,7 +226,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
             if (((fl >> t) & 1u) && cnt < sc.max_contacts) {
               if (sl == j) {
                 const int o = list + 1 + cnt * CL_STRIDE;
-                ln.L(o + CL_PAIR) = (float)pi; ln.L3set(o + CL_P, v3(hp[t][0], hp[t][1], hp[t][2])); ln.L3set(o + CL_N, v3(hn[t][0], hn[t][1], hn[t][2])); ln.L(o + CL_DIST) = hd[t];
+                ln.L(o + CL_PAIR) = (float)pi; ln.L(o + CL_KEY) = (float)DG_CONTACT_KEY(pi, hf[t]); ln.L3set(o + CL_P, v3(hp[t][0], hp[t][1], hp[t][2])); ln.L3set(o + CL_N, v3(hn[t][0], hn[t][1], hn[t][2])); ln.L(o + CL_DIST) = hd[t];
               }
               cnt++;
             }
@@ -269,7 +269,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
       if (ta == DG_SHAPE_SPHERE) emit_contact(ln, list, cnt, pi, sphere_box(a0, ra, b, margin), flip);
       else if (ta == DG_SHAPE_CAPSULE) {
         emit_contact(ln, list, cnt, pi, sphere_box(a0, ra, b, margin), flip);
-        if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) emit_contact(ln, list, cnt, pi, sphere_box(a1, ra, b, margin), flip);
+        if (sc.SF[sa * DG_SF_STRIDE + DG_SF_PARAMS + 1] > 0.f) emit_contact(ln, list, cnt, pi, sphere_box(a1, ra, b, margin), flip, 1);
       } else if (ta == DG_SHAPE_POINTS) {
         const int abody = sc.SI[sa * DG_SI_STRIDE + DG_SI_BODY], alink = sc.SI[sa * DG_SI_STRIDE + DG_SI_LINK];
         const int poff = sc.SI[sa * DG_SI_STRIDE + DG_SI_POINT_OFF], npts = sc.SI[sa * DG_SI_STRIDE + DG_SI_N_POINTS];
@@ -297,7 +297,7 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
           cfp pp = sc.PF + 3 * (poff + k2);  // per-lane index: vector load
           Hit h = sphere_box(pl + mul(Rl, v3(pp[0], pp[1], pp[2])), 0.f, b, margin);
           h.hit = h.hit && bi4[j] >= 0;
-          emit_contact(ln, list, cnt, pi, h, flip);
+          emit_contact(ln, list, cnt, pi, h, flip, k2);
         }
       }
     }
@@ -318,6 +318,44 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
   else { float a = n.x * n.x + n.y * n.y, k = 1.0f / sqrtf(a); t1 = v3(-n.y * k, n.x * k, 0.f); t2 = v3(-n.z * t1.y, n.z * t1.x, a * k); }
 }
 
+// ---- warm starting ---------------------------------------------------------------------------------------------------
+// The contact impulse cache of an env (state, DG_WS_*): [count][key normal t1 t2] x max_contacts, written at the end of
+// every substep (store_warm_cache) and cleared by a reset.  A row of a contact whose key was there in the previous substep
+// starts from DG_HF_WARMSTART (normal) / DG_HF_WARMSTART_FRICTION (tangents) x the impulse it ended with; the sweeps add
+// the velocity change those starting impulses amount to before their first iteration.
+// Index of the cached entry with this key, -1 if there is none (or no cache).  Called under divergence: the loop bound
+// is uniform over the ACTIVE lanes, the key loads are independent of each other.
+template <int LANES>
+DGD int warm_find(const Lane<LANES>& ln, float key) {
+  const DevScene& sc = ln.sc; if (sc.warm_off < 0) return -1;
+  const int np = (int)ln.S(sc.warm_off); int found = -1;
+  for (int j = 0; j < sc.max_contacts; j++) {
+    if (!__any(j < np)) break;
+    const float kj = ln.S(sc.warm_off + 1 + j * DG_WS_STRIDE + DG_WS_KEY);
+    if (j < np && kj == key && found < 0) found = j;
+  }
+  return found;
+}
+template <int LANES>
+DGD float warm_impulse(const Lane<LANES>& ln, int found, int d) {
+  const DevScene& sc = ln.sc;
+  const float fac = d == 0 ? sc.HF[DG_HF_WARMSTART] : sc.HF[DG_HF_WARMSTART_FRICTION];
+  return (found >= 0 && fac > 0.f) ? fac * ln.S(sc.warm_off + 1 + max(found, 0) * DG_WS_STRIDE + DG_WS_NORMAL + d) : 0.f;
+}
+// this substep's contacts and the impulses their rows ended with (every sweep form leaves them in the rows' `acc` slots)
+template <int LANES>
+DGD void store_warm_cache(const Lane<LANES>& ln, int ncont, int wave_max_cont) {
+  const DevScene& sc = ln.sc; if (sc.warm_off < 0) return;
+  const int rs = sc.crow_tail + 3;
+  ln.Sset(sc.warm_off, (float)ncont);
+  for (int c = 0; c < wave_max_cont; c++) {
+    if (c >= ncont) continue;
+    const int e = sc.warm_off + 1 + c * DG_WS_STRIDE, ro = sc.tr_off + 3 * c * rs + sc.crow_tail + 1;
+    const float key = ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_KEY), i0 = ln.L(ro), i1 = ln.L(ro + rs), i2 = ln.L(ro + 2 * rs);
+    ln.Sset(e + DG_WS_KEY, key); ln.Sset(e + DG_WS_NORMAL, i0); ln.Sset(e + DG_WS_T1, i1); ln.Sset(e + DG_WS_T2, i2);
+  }
+}
+
 // builds the three rows of contact slot c for the lanes whose contact belongs to (uniform) pair `pair`
 template <int LANES>
 DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, bool vel_in_lds, int d_lo = 0, int d_hi = 3) {
@@ -331,6 +369,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
   V3 t1, t2; tangent_basis(n, t1, t2);
   const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
   ln.L(co + CL_MU) = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
+  const int wfound = warm_find(ln, ln.L(co + CL_KEY));
   for (int d = d_lo; d < d_hi; d++) {  // (lane-sliced callers give each lane of an env's group one direction)
     V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
     int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
@@ -350,7 +389,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
     } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
     if (d == 0) { float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-    ln.L(ro + tl) = b; ln.L(ro + tl + 1) = 0.f; ln.L(ro + tl + 2) = diag;
+    ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag;
   }
 }
 
@@ -376,6 +415,7 @@ DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool ve
     V3 t1, t2; tangent_basis(n, t1, t2);
     const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
     ln.L(co + CL_MU) = sc.SF[pa * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[pb * DG_SF_STRIDE + DG_SF_FRICTION];
+    const int wfound = warm_find(ln, ln.L(co + CL_KEY));
     // one side: Jacobian of the body's base coordinates, response through the first six rows of its M^-1, J . v
     auto side = [&](int b, int flags, V3 d, int ro, float& diag, float& jv) {
       cip P = sc.PLB + b * PLB_STRIDE; const int nv = P[PLB_NV], mo = P[PLB_MINV], dvo = P[PLB_DV], g = dvo - sc.dv_base;
@@ -414,7 +454,7 @@ DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool ve
       } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
       float b = -jv;
       if (d == 0) { const float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = 0.f; ln.L(ro + tl + 2) = diag;
+      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag;
     }
   }
   return mine;
@@ -650,6 +690,13 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
     for (int k = 0; k < NTB; k++) dv[k] += r.R[k] * delta;
     const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
   };
+  if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
+    for (int r = 0; r < 3 * wave_max_cont; r++) {
+      DenseRow<NTB> W; load_row(W, sc.tr_off + r * rs); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+#pragma unroll
+      for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * a0;
+    }
+  }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
@@ -797,6 +844,13 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
     for (int i = 0; i < NS; i++) dv[i] += r.R[i] * delta;
     const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
   };
+  if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
+    for (int r = 0; r < 3 * wave_max_cont; r++) {
+      Row W; load_row(W, sc.tr_off + r * rs); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
+    }
+  }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
@@ -927,7 +981,9 @@ DGD int pgs_dense_sliced_regs(const Lane<LANES>& ln, int ncont_primary, uint64_t
         const float jj = ls[(ro + i * SL) * LANES], rr = ls[(ro + nt + i * SL) * LANES];
         cJ[r][i] = in ? jj * rd : 0.f; cR[r][i] = in ? rr : 0.f;
       }
-      cb[r] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdg[r] = has ? dg : 0.f; cacc[r] = 0.f;
+      cb[r] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdg[r] = has ? dg : 0.f; cacc[r] = has ? lq.L(ro + 2 * nt + 1) : 0.f;  // (starting impulse: warm start)
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += cR[r][i] * cacc[r];
     }
   }
   float maxres = 0.f; bool live = validq; int iters_done = 0;
@@ -1074,7 +1130,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   for (int s = 0; s < NSL; s++) {
     const int r = (lane - 16) + 16 * s; const bool has = lane >= 16 && lane < 32 && r < 3 * ncont; const int rr = has ? r : 0, ro = sc.tr_off + rr * rs;
     const float dg = lq.L(ro + 2 * nt + 2), rd = (has && dg > 1e-18f) ? frcp(dg) : 0.f;
-    cbv[s] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdgv[s] = has ? dg : 0.f; caccv[s] = 0.f;
+    cbv[s] = has ? lq.L(ro + 2 * nt) * rd : 0.f; cdgv[s] = has ? dg : 0.f; caccv[s] = has ? lq.L(ro + 2 * nt + 1) : 0.f;  // (starting impulse: warm start)
     cmuv[s] = (has && rr % 3 == 0) ? lq.L(sc.cont_off + 1 + (rr / 3) * CL_STRIDE + CL_MU) : 0.f;  // friction coefficient: with the contact's normal row
   }
 #pragma unroll
@@ -1090,6 +1146,10 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
       }
     }
   }
+  if (sc.warm_off >= 0) static_for<0, 3 * CM>([&](auto rc) {  // warm start: the velocity change the rows' starting impulses amount to
+    constexpr int R = decltype(rc)::value, o = 16 + (R & 15), sl_ = R >> 4;
+    if (R < 3 * ncont) dv += cR[R] * rdl(caccv[sl_], o);
+  });
   float maxres = 0.f; int iters_done = 0;
   // the owner lane's registers hold the row's scalars; v_readlane broadcasts what the other lanes need
   auto contact_row = [&](auto rc, float lim, bool friction) {  // row R (compile time: its registers, its owner lane); lim: friction bound
@@ -1171,10 +1231,11 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   auto BL = [&](unsigned voff, int slot) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (unsigned)slot * W * 4u, 0)); };
   auto G = [&](int slot) -> float { return BL(col_off, slot); };
   const Lane<LANES> lq(sc, ln.mt, ln.lds, ln.st - ln.env + eq, eq, validq);  // tables only
-  const int ncont = __shfl(ncont_primary, q);
   float* const acc = accl + q;  // acc[id * EPW]
   const int n_acc = 3 * maxc + 3 * sc.nl;
-  for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = 0.f;
+  const int ncont = __shfl(ncont_primary, q), rsw = sc.crow_tail + 3;
+  // (contact rows start from the impulse their builder left in the row -- warm start -- the others from zero)
+  for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = (sc.warm_off >= 0 && id < 3 * ncont) ? BL(col_off, sc.tr_off + id * rsw + 2 * sc.nt + 1) : 0.f;
   float dv[NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) dv[i] = 0.f;
@@ -1225,6 +1286,13 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
     const float res = delta * r.diag; maxres = fmaxf(maxres, res * res);
   };
   const int r0 = sc.tr_off, c0 = sc.cont_off + 1;
+  if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
+    for (int r = 0; r < 3 * wave_max_cont; r++) {
+      Row W; load_row(W, r0 + r * rs, c0 + (r / 3) * CL_STRIDE, r); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
+    }
+  }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
@@ -1493,7 +1561,10 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
         for (int k = 0; k < RN; k++) { const bool hk = has && k < n; const int kk = k < n ? k : 0; const float j = W(ro + g + kk), rr = W(ro + nt + g + kk); cJ[r][k] = hk ? j : 0.f; cR[r][k] = hk ? rr : 0.f; }
         const float bb = W(ro + 2 * nt), dd = W(ro + 2 * nt + 2);
-        cb[r] = has ? bb : 0.f; cdg[r] = has ? dd : 1.f; cdi[r] = (has && dd > 1e-18f) ? frcp(dd) : 0.f; cacc[r] = 0.f;
+        cb[r] = has ? bb : 0.f; cdg[r] = has ? dd : 1.f; cdi[r] = (has && dd > 1e-18f) ? frcp(dd) : 0.f;
+        const float a0 = W(ro + 2 * nt + 1); cacc[r] = (has && cdi[r] != 0.f) ? a0 : 0.f;  // (starting impulse: warm start)
+#pragma unroll
+        for (int k = 0; k < RN; k++) rdv[k] += cR[r][k] * cacc[r];
       }
     }
   }
@@ -1629,7 +1700,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
           if (j < nb2 && ncont + j < sc.max_contacts) {
             float* dst = ln.lds + (sc.cont_off + 1 + (ncont + j) * CL_STRIDE) * envs_per_wave(LANES);  // per-lane destination entry
 #pragma unroll
-            for (int k = 0; k < CL_DIST + 1; k++) dst[k * envs_per_wave(LANES)] = ln.L(sc.cont2_off + 1 + j * CL_STRIDE + k);
+            for (int k = 0; k < CL_KEY + 1; k++) dst[k * envs_per_wave(LANES)] = ln.L(sc.cont2_off + 1 + j * CL_STRIDE + k);
           }
         }
         ncont = min(ncont + nb2, sc.max_contacts); ln.L(sc.cont_off) = (float)ncont;
@@ -1762,6 +1833,21 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   bool has_generic = false;
   for (int b = 0; b < sc.nba; b++) if (ln.bi(b)[DG_BI_N_LINKS] > 0 && b != sc.reg_body[0] && b != sc.reg_body[1]) has_generic = true;
   const float thr_abs = sqrtf(thr);  // the register rows track |residual|; same test as residual^2 <= thr
+  if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
+    const int nvm = sc.nv_max; const bool two = sc.crow_tail > 2 * nvm;
+    for (int c = 0; c < wave_max_cont; c++) {
+      const bool has = c < ncont; const int co = sc.cont_off + 1 + c * CL_STRIDE;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int ro = sc.tr_off + (3 * c + d) * rs; const float a0 = has ? ln.L(ro + sc.crow_tail + 1) : 0.f;
+        if (a0 != 0.f) {
+          lds_axpy(ln, (int)ln.L(co + CL_DVA), ro + nvm, a0, nvm);
+          if (two && (int)ln.L(co + CL_NVB) > 0) lds_axpy(ln, (int)ln.L(co + CL_DVB), ro + 3 * nvm, a0, nvm);
+        }
+      }
+    }
+    lds_to_regs(0); lds_to_regs(1);
+  }
   for (int it = 0; it < sc.iters; it++) {
     float maxres = 0.f, maxabs = 0.f;
     // motor rows of every body first, then joint-limit rows of every body (oracle order; rows of different
@@ -1837,6 +1923,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   }  // unsliced
   prof.stamp(PS_PGS);
   if (primary) {
+  store_warm_cache(ln, ncont, wave_max_cont);
   if (diag_out && ln.valid) {  // include/diygym_hip.h: dg_world_set_diag_buffer
     int32_t* d = diag_out + (size_t)DG_DIAG_STRIDE * ln.env;
     d[DG_DIAG_CONTACTS] = ncont; d[DG_DIAG_PGS_ITERS] = iters_done;
@@ -2292,6 +2379,7 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
     }
   }
   for (int b = 0; b < sc.nba; b++) save_prev_velocities(ln, b);  // force/torque sensors: no acceleration across a reset
+  if (sc.warm_off >= 0) ln.Sset(sc.warm_off, 0.f);  // a reset teleports bodies: no contact persists across it
   ln.Sset(DG_ST_EPISODE, (float)(episode + 1ull));
 }
 

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 8
+#define DG_VERSION 9
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -70,6 +70,7 @@ enum {
   DG_H_OFF_CAMERA_F,
   DG_H_OFF_OP_F,
   DG_H_OFF_FLIST,
+  DG_H_WARM_OFF,     /* state offset of the contact impulse cache (DG_WS_*), or -1: no warm starting */
   DG_H_INT_COUNT /* header length in I[] */
 };
 
@@ -92,8 +93,18 @@ enum {
   DG_HF_IK_NULL_REST_GAIN,
   DG_HF_IK_NULL_LIMIT_GAIN,
   DG_HF_CONTACT_MARGIN, /* speculative contact distance                   */
+  DG_HF_WARMSTART,      /* a contact that persists (same pair, same feature) starts its NORMAL row from this factor x the
+                           impulse it ended the previous substep with (Bullet: m_warmstartingFactor 0.85 [R]); 0 = off */
+  DG_HF_WARMSTART_FRICTION, /* the same for its two friction rows (Bullet starts friction rows from zero [R])          */
   DG_HF_FLOAT_COUNT
 };
+
+/* ---- contact impulse cache (per-env state at DG_H_WARM_OFF, only when DG_HF_WARMSTART* > 0 and the scene has pairs) ----
+ * [count] then max_contacts entries [key, normal, t1, t2]: the contacts of the env's most recent substep and the impulses
+ * their rows ended with.  key = candidate pair index * 64 + feature (sphere / fitted capsule: 0; capsule against a box:
+ * which end; hull against a box: the hull vertex index & 63).  A reset clears the count. */
+enum { DG_WS_KEY = 0, DG_WS_NORMAL, DG_WS_T1, DG_WS_T2, DG_WS_STRIDE };
+#define DG_CONTACT_KEY(pair, feature) ((pair) * 64 + ((feature) & 63))
 
 /* ---- per-env state prefix --------------------------------------------- */
 enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_EPISODE /* resets so far (RNG stream) */,

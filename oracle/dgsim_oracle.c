@@ -238,7 +238,7 @@ typedef struct {
   int32_t* I; real* F; int64_t ni, nf;
   int nb, nl, nfr, nsh, npairs, nops;
   int act_dim, obs_dim, rew_dim, term_dim, substeps, iters, max_steps, hot_start, ik_iters, state_dim;
-  int addon_off, max_contacts, rew_mode, term_mode, n_term_groups;
+  int addon_off, max_contacts, rew_mode, term_mode, n_term_groups, warm_off;
   const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
   const real *BF, *LF, *FF, *SF, *PF, *OF, *FL;
   real h; v3 g;
@@ -251,6 +251,7 @@ typedef struct {
   real dist; /* signed distance (negative = penetration) */
   real mu;
   int shape_a, shape_b;      /* global shape indices */
+  int key;                   /* DG_CONTACT_KEY(candidate pair, feature): identity of the contact from substep to substep */
   v3 t1, t2; real imp[3];  /* friction directions and the solved impulses (normal, t1, t2), filled in after the sweeps */
 } Contact;
 
@@ -300,6 +301,7 @@ static int parse_scene(Scene* s, const int32_t* I, int64_t ni, const double* F64
   s->substeps = I[DG_H_SUBSTEPS]; s->iters = I[DG_H_SOLVER_ITERS]; s->max_steps = I[DG_H_MAX_EPISODE_STEPS];
   s->hot_start = I[DG_H_HOT_START]; s->ik_iters = I[DG_H_IK_ITERS]; s->state_dim = I[DG_H_STATE_DIM];
   s->addon_off = I[DG_H_ADDON_STATE_OFF]; s->max_contacts = I[DG_H_MAX_CONTACTS];
+  s->warm_off = I[DG_H_WARM_OFF];
   s->rew_mode = I[DG_H_REW_MODE]; s->term_mode = I[DG_H_TERM_MODE]; s->n_term_groups = I[DG_H_N_TERM_GROUPS];
   s->BI = I + I[DG_H_OFF_BODY_I]; s->LI = I + I[DG_H_OFF_LINK_I]; s->FI = I + I[DG_H_OFF_FRAME_I];
   s->SI = I + I[DG_H_OFF_SHAPE_I]; s->PI = I + I[DG_H_OFF_PAIR_I]; s->OI = I + I[DG_H_OFF_OP_I]; s->IL = I + I[DG_H_OFF_ILIST];
@@ -557,9 +559,9 @@ static void shape_world(const Scene* s, const BodyWS* wsb, int sh, WShape* o) {
   o->R = mmul(&Rl, &Rs); o->p = vadd(pl, mv(&Rl, V(sf[DG_SF_POS], sf[DG_SF_POS + 1], sf[DG_SF_POS + 2])));
   o->prm = sf + DG_SF_PARAMS; o->mu = sf[DG_SF_FRICTION]; o->poff = si[DG_SI_POINT_OFF]; o->npts = si[DG_SI_N_POINTS];
 }
-static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, real dist) {
+static void add_contact(Contact* cs, int* nc, int maxc, const WShape* a, const WShape* b, v3 pa, v3 pb, v3 n, real dist, int key) {
   if (*nc >= maxc) return;
-  Contact* c = &cs[(*nc)++];
+  Contact* c = &cs[(*nc)++]; c->key = key;
   c->body_a = a->body; c->link_a = a->llink; c->body_b = b->body; c->link_b = b->llink; c->shape_a = a->id; c->shape_b = b->id;
   c->imp[0] = c->imp[1] = c->imp[2] = 0.0;
   c->p = vscale(vadd(pa, pb), 0.5); c->n = n; c->dist = dist; c->mu = a->mu * b->mu; /* Bullet combines friction by product [R] */
@@ -629,8 +631,9 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
     /* canonical order: lower type id first, except that a box is always `b` */
     if (a->type == DG_SHAPE_BOX || (b->type != DG_SHAPE_BOX && a->type > b->type)) { const WShape* t = a; a = b; b = t; flip = -1.0; }
     v3 pa, pb, n; real dist;
-    #define EMIT() do { if (flip > 0) add_contact(cs, &nc, s->max_contacts, a, b, pa, pb, n, dist); \
-                        else add_contact(cs, &nc, s->max_contacts, b, a, pb, pa, vscale(n, -1.0), dist); } while (0)
+    #define EMIT_F(feature) do { if (flip > 0) add_contact(cs, &nc, s->max_contacts, a, b, pa, pb, n, dist, DG_CONTACT_KEY(pi, feature)); \
+                        else add_contact(cs, &nc, s->max_contacts, b, a, pb, pa, vscale(n, -1.0), dist, DG_CONTACT_KEY(pi, feature)); } while (0)
+    #define EMIT() EMIT_F(0)
     if (a->type == DG_SHAPE_SPHERE && b->type == DG_SHAPE_SPHERE) {
       if (sphere_sphere(a->p, a->prm[0], b->p, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
     } else if (a->type == DG_SHAPE_SPHERE && b->type == DG_SHAPE_BOX) {
@@ -645,7 +648,7 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
     } else if (a->type == DG_SHAPE_CAPSULE && b->type == DG_SHAPE_BOX) {
       v3 e0, e1; seg_ends(a, &e0, &e1);
       if (sphere_box(e0, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
-      if (a->prm[1] > 0 && sphere_box(e1, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT();
+      if (a->prm[1] > 0 && sphere_box(e1, a->prm[0], b, margin, &pa, &pb, &n, &dist)) EMIT_F(1);
     } else if (a->type == DG_SHAPE_POINTS && b->type == DG_SHAPE_BOX) {
       /* hull vertices against the box: keep the 4 deepest (ties -> lower index) */
       int bi[4] = {-1, -1, -1, -1}; real bd[4] = {HUGE_R, HUGE_R, HUGE_R, HUGE_R};
@@ -660,10 +663,11 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
       for (int j = 0; j < 4; j++) if (bi[j] >= 0) {
         const real* pp = s->PF + 3 * (a->poff + bi[j]);
         v3 pwk = vadd(pl, mv(&Rl, V(pp[0], pp[1], pp[2])));
-        if (sphere_box(pwk, 0.0, b, margin, &pa, &pb, &n, &dist)) EMIT();
+        if (sphere_box(pwk, 0.0, b, margin, &pa, &pb, &n, &dist)) EMIT_F(bi[j]);
       }
     }
     #undef EMIT
+    #undef EMIT_F
   }
   return nc;
 }
@@ -822,6 +826,27 @@ static void substep(dgo_world* w, int env, int last) {
       r->normal_row = crow[k]; r->mu = cs[k].mu; frow[k][d] = nr++;
     }
   }
+  /* warm starting (btSequentialImpulseConstraintSolver: m_appliedImpulse = cp.m_appliedImpulse * m_warmstartingFactor [R]):
+   * a contact that was there in the previous substep -- same candidate pair, same feature -- starts from a fraction of the
+   * impulses its rows ended with, applied to the velocity change before the first sweep */
+  real* warm = s->warm_off >= 0 ? st + s->warm_off : NULL;
+  if (warm) {
+    const real wfac[3] = {s->F[DG_HF_WARMSTART], s->F[DG_HF_WARMSTART_FRICTION], s->F[DG_HF_WARMSTART_FRICTION]};
+    const int np = (int)warm[0];
+    for (int k = 0; k < nc; k++) {
+      const real* e = NULL;
+      for (int j = 0; j < np && !e; j++) if ((int)warm[1 + j * DG_WS_STRIDE + DG_WS_KEY] == cs[k].key) e = warm + 1 + j * DG_WS_STRIDE;
+      if (!e) continue;
+      const int ri[3] = {crow[k], frow[k][0], frow[k][1]};
+      for (int d = 0; d < 3; d++) {
+        if (ri[d] < 0 || wfac[d] <= 0) continue;
+        Row* r = &rows[ri[d]]; const real imp = wfac[d] * e[DG_WS_NORMAL + d];
+        r->acc = imp;
+        BodyWS* A = &wsb[r->body_a]; for (int j = 0; j < 6 + A->n; j++) A->dv[j] += r->RA[j] * imp;
+        if (r->body_b >= 0) { BodyWS* Bw = &wsb[r->body_b]; for (int j = 0; j < 6 + Bw->n; j++) Bw->dv[j] += r->RB[j] * imp; }
+      }
+    }
+  }
   /* projected Gauss-Seidel with the residual early-out (pybullet solverResidualThreshold [R]) */
   real thr = s->F[DG_HF_RESIDUAL_THRESHOLD]; int it;
   for (it = 0; it < s->iters; it++) {
@@ -844,6 +869,13 @@ static void substep(dgo_world* w, int env, int last) {
     cs[k].imp[0] = crow[k] >= 0 ? rows[crow[k]].acc : 0.0;
     cs[k].imp[1] = frow[k][0] >= 0 ? rows[frow[k][0]].acc : 0.0; cs[k].imp[2] = frow[k][1] >= 0 ? rows[frow[k][1]].acc : 0.0;
     w->last_cs[(size_t)env * MAXC + k] = cs[k];
+  }
+  if (warm) { /* this substep's contacts and impulses, for the next one */
+    warm[0] = (real)nc;
+    for (int k = 0; k < nc; k++) {
+      real* e = warm + 1 + k * DG_WS_STRIDE;
+      e[DG_WS_KEY] = (real)cs[k].key; e[DG_WS_NORMAL] = cs[k].imp[0]; e[DG_WS_T1] = cs[k].imp[1]; e[DG_WS_T2] = cs[k].imp[2];
+    }
   }
   for (int k = 0; k < nr; k++) if (rows[k].motor_link >= 0) st[link_i(s, rows[k].motor_link)[DG_LI_STATE_OFF] + DG_LS_APPLIED] = rows[k].acc / h;
   /* apply velocity changes, integrate positions (btMultiBody::stepPositionsMultiDof [R]) */
@@ -1114,6 +1146,7 @@ static void run_reset_ops(dgo_world* w, int env) {
     for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) st[po + i] = st[link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF] + DG_LS_QD];
     if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) st[po + bi[DG_BI_N_LINKS] + k] = st[bi[DG_BI_STATE_OFF] + DG_BS_LINVEL + k];
   }
+  if (s->warm_off >= 0) st[s->warm_off] = 0.0; /* a reset teleports bodies: no contact persists across it */
   st[DG_ST_EPISODE] = (real)(episode + 1);
 }
 static real reach_dist(const Scene* s, const real* st, const int32_t* oi) { /* reach_target.py:21-30 */

@@ -552,7 +552,7 @@ def test_fp32_build_of_the_oracle_and_what_it_says_about_tolerances():
     maze = os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml')
     a, b = DIYGym(maze, num_envs=8, seed=5, backend_factory=ob.OracleBackend), DIYGym(maze, num_envs=8, seed=5, backend_factory=f32)
     L = a.layout
-    eff = [o + 5 for o in L.link_state_off]; kin = [k for k in range(L.state_dim) if k not in eff]
+    eff = [o + 5 for o in L.link_state_off]; kin = [k for k in range(L.physical_dim) if k not in eff]   # (not the cached contact impulses)
     drift = 0.0
     for _ in range(60):
         act = (torch.rand((8, 4), generator=gen) * 2 - 1) * 10.0

@@ -41,6 +41,23 @@ def make_pair(name, B, seed=5, **engine):
     return gpu, cpu
 
 
+def phys_state(env):
+    """[B, physical_dim] state WITHOUT the cached contact impulses behind it (warm starting, DG_WS_*): how a statically
+    indeterminate support splits between contacts is not unique, so those are compared on their own (warm_cache)."""
+    return np.asarray(env.sim.get_state())[:, :env.layout.physical_dim]
+
+
+def warm_cache(env):
+    """(count [B], keys [B, max_contacts], impulses [B, max_contacts, 3]) of the contact impulse cache; entries past the count zeroed."""
+    L = env.layout
+    st = np.asarray(env.sim.get_state(), dtype=np.float64)[:, L.warm_off:]
+    n = st[:, 0].astype(int)
+    e = st[:, 1:1 + 4 * L.max_contacts].reshape(st.shape[0], L.max_contacts, 4).copy()
+    for b in range(st.shape[0]):
+        e[b, n[b]:] = 0.0
+    return n, e[:, :, 0].astype(int), e[:, :, 1:]
+
+
 def effort_columns(env):
     """Observation / reward columns that report motor torques.  With the solver's residual early-out
     (1e-7 on the squared velocity error, pybullet's default) the split of an impulse between rows is only
@@ -95,7 +112,7 @@ def test_initial_state_and_reset_match():
         # bodies are determined to the solver's residual threshold (sqrt(1e-7) = 3e-4 m/s); efforts are O(100 N m) and,
         # for arms resting against each other, carry that velocity residual times the controller's damping gain
         # (measured 1.3e-4 relative on the touching scene, tools/gpu_reset_diff.py)
-        assert np.allclose(gpu.sim.get_state(), cpu.sim.get_state(), rtol=3e-4, atol=5e-4), name
+        assert np.allclose(phys_state(gpu), phys_state(cpu), rtol=3e-4, atol=5e-4), name
         ft = _ft_columns(gpu)   # (force/torque readings are O(1000) N in the touching scene: relative to the vector's size)
         keep = torch.ones(gpu.sim.obs.shape[1], dtype=torch.bool); keep[ft] = False
         assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs()[:, keep].max()) < 5e-4, name
@@ -155,7 +172,7 @@ def test_child_model_attached_by_one_of_its_links_40_steps(tmp_path):
     gpu = DIYGym(str(path), num_envs=5, device='cuda:0', seed=5); cpu = DIYGym(str(path), num_envs=5, seed=5, backend_factory=OracleBackend)
     w = rollout(gpu, cpu, 40)
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
 
 
 def test_arms_in_contact_30_steps():
@@ -238,7 +255,7 @@ def test_cart_tree_every_feature_converged_solver():
     # electricity_cost (reference electricity_cost.py:15-18) on the GPU against the oracle: the column exists, is not
     # trivially zero, and agrees as tightly as the efforts it is computed from
     assert effort_columns(gpu)[1] and w['rew_effort_max'] > 1e-3 and w['rew_effort_rel'] < 2e-3, w
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < CART_STATE_TOL
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < CART_STATE_TOL
 
 
 def test_r2d2_maze_40_steps():
@@ -248,10 +265,10 @@ def test_r2d2_maze_40_steps():
     converged scenes.  Asserted: base pose (5e-3), base twist, every joint angle and joint rate.
     Blind to: hull thinning (the wheels' hulls are thinned identically on both sides), no warm starting."""
     gpu, cpu = make_pair('maze', 19)
-    assert gpu.sim.lanes in (8, 16, 32) and gpu.layout.state_dim < 100  # walls and plane carry no per-env state
+    assert gpu.sim.lanes in (8, 16, 32) and gpu.layout.physical_dim < 100  # walls and plane carry no per-env state
     w = rollout(gpu, cpu, 40, scale=10.0)
     assert w['term_mismatch'] == 0
-    a, b = gpu.sim.get_state(), cpu.sim.get_state()
+    a, b = phys_state(gpu), phys_state(cpu)
     L = gpu.layout
     so = L.body_state_off[[i for i in range(L.n_bodies) if L.body_n_links[i] > 0][0]]
     assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
@@ -288,7 +305,7 @@ def test_contact_budget_cuts_the_list_in_pair_order(env_vars, lanes):
     w = rollout(gpu, cpu, 20, scale=0.2)
     assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(5)] and int(d[:, 0].max()) == 7
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
 
 
 @pytest.mark.parametrize('name,B,env_vars', [('maze', 19, {}), ('readme', 5, {}), ('readme', 6, {'DG_NO_WAVE_ENV': '1'}), ('marbles', 70, {}),
@@ -315,7 +332,7 @@ def test_masked_reset_in_the_lane_sliced_modes(name, B, env_vars):
     keep = (mask == 0).numpy()
     assert np.array_equal(before[keep], after[keep])           # untouched envs: not a bit changed
     assert not np.array_equal(before[~keep], after[~keep])
-    assert np.allclose(after, cpu.sim.get_state(), rtol=3e-4, atol=2e-3), np.abs(after - cpu.sim.get_state()).max()
+    assert np.allclose(phys_state(gpu), phys_state(cpu), rtol=3e-4, atol=2e-3), np.abs(phys_state(gpu) - phys_state(cpu)).max()
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 2e-3
     w = rollout(gpu, cpu, 5, scale=scale, seed=3)
     assert w['term_mismatch'] == 0 and w['obs'] < (2e-2 if name == 'maze' else 5e-3), w
@@ -338,7 +355,7 @@ def test_creeping_velocities_in_the_denormal_range_of_their_squares():
             st[e, so + 7] = 0.5 * v   # a creeping base as well
     gpu.sim.set_state(st); cpu.sim.set_state(st)
     w = rollout(gpu, cpu, 6, scale=10.0)
-    a, b = np.array(gpu.sim.get_state()), np.array(cpu.sim.get_state())
+    a, b = np.array(phys_state(gpu)), np.array(phys_state(cpu))
     assert np.isfinite(a).all() and w['term_mismatch'] == 0
     assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < 5e-3, np.abs(a - b).max()
 
@@ -372,7 +389,7 @@ def test_marbles_against_the_wheels_of_r2d2():
         most = max(most, int(d[:, 0].max()))
     assert most >= 6   # wheels + body on the plane, marbles on the plane and against the robot
     assert np.isfinite(np.array(gpu.sim.get_state())).all()
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-2
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 2e-2
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 5e-3
 
 
@@ -408,7 +425,7 @@ def test_from_the_readme_resting_contacts_60_steps():
         worst_power = max(worst_power, float(((gpu.sim.rew.cpu() - cpu.sim.rew).abs()[:, er] / (1.0 + cpu.sim.rew[:, er].abs())).max()))
     assert er and worst_power < 2e-2, worst_power   # electricity_cost column over the whole resting rollout
     assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(3)] and int(d[:, 0].min()) >= 20
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 2e-3
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 2e-3
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 1e-4
 
 
@@ -602,7 +619,7 @@ def test_masked_reset_only_touches_masked_envs():
     after = gpu.sim.get_state()
     keep = mask.numpy() == 0
     assert np.array_equal(before[keep], after[keep])
-    assert np.abs(after - cpu.sim.get_state()).max() < 2e-3
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 2e-3
 
 
 # ---- converged-solver twins of the loosely-conditioned contact scenes ---------------------------------------------------
@@ -646,7 +663,7 @@ def single_steps_from_the_oracle_state(gpu, cpu, steps, scale=1.0, seed=0, actfi
         if actfix:
             actfix(act)
         gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
-        a, b = gpu.sim.get_state(), cpu.sim.get_state()
+        a, b = phys_state(gpu), phys_state(cpu)
         w['kin'] = max(w['kin'], float(np.abs(a - b)[:, kin].max()))
         if eff:
             w['eff_rel'] = max(w['eff_rel'], float((np.abs(a - b)[:, eff] / (1.0 + np.abs(b[:, eff]))).max()))
@@ -702,7 +719,7 @@ def test_marbles_against_the_wheels_converged_solver():
         most = max(most, int(d[:, 0].max()))
     assert most >= 6
     kin, eff = state_columns(gpu.layout)
-    a, b = gpu.sim.get_state(), cpu.sim.get_state()
+    a, b = phys_state(gpu), phys_state(cpu)
     assert np.abs(a - b)[:, kin].max() < 2e-3 and (np.abs(a - b)[:, eff] / (1.0 + np.abs(b[:, eff]))).max() < 5e-2
     assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()) < 2e-3
     del tree['solver_iterations']
@@ -731,7 +748,7 @@ def test_ur5_with_three_finger_gripper_asset_30_steps():
     assert gpu.layout.n_links == 17
     w = rollout(gpu, cpu, 30, scale=0.5)
     assert w['obs'] < 2e-3 and w['effort_rel'] < 2e-2 and w['term_mismatch'] == 0, w
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 5e-3
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
 
 
 def test_spawn_multiple_scene_100_steps():
@@ -752,7 +769,62 @@ def test_spawn_multiple_scene_100_steps():
     w = rollout(gpu, cpu, 100, scale=0.1)
     assert w['obs'] < 1e-3 and w['term_mismatch'] == 0, w
     assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(33)] and int(d[:, 0].max()) >= 3
-    assert np.abs(gpu.sim.get_state() - cpu.sim.get_state()).max() < 1e-2
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 1e-2
     # the clones got different respawn draws
     o = cpu.sim.obs
     assert float((o[:, 0:2] - o[:, 3:5]).abs().max()) > 1e-2 and float((o[:, 3:5] - o[:, 6:8]).abs().max()) > 1e-2
+
+
+# ---- warm starting ---------------------------------------------------------------------------------------------------------
+def test_warm_started_contacts_cache_and_iterations():
+    """Contact warm starting (engine parameters warmstart / warmstart_friction, DG_WS_* cache in the state): marbles at rest
+    on the plane, one contact each, so the cached impulses are unique.  Asserted against the oracle: the cache itself
+    (count, the keys = pair * 64 + feature in contact order, normal impulses to 1e-3 relative = m g h), that from the
+    second step of resting the sweeps of BOTH implementations leave in < 10 iterations (a cold start takes more), that a
+    masked reset clears the cache of the reset envs only, and that with warmstart = 0 no cache exists (state as before)."""
+    gpu, cpu = make_pair('marbles', 9)
+    assert gpu.layout.warm_off > 0 and gpu.layout.state_dim == gpu.layout.warm_off + 1 + 4 * gpu.layout.max_contacts
+    d = gpu.sim.enable_diagnostics()
+    zero = torch.zeros((9, gpu.layout.act_dim))
+    for i in range(60):   # (they spawn a little above the plane and settle)
+        gpu.sim.step(gpu._all_slots, zero.to(gpu.device)); cpu.sim.step(cpu._all_slots, zero)
+    for i in range(5):
+        gpu.sim.step(gpu._all_slots, zero.to(gpu.device)); cpu.sim.step(cpu._all_slots, zero)
+        assert int(d[:, 1].max()) < 10 and max(cpu.sim.iterations(e) for e in range(9)) < 10
+    ng, kg, ig = warm_cache(gpu); nc, kc, ic = warm_cache(cpu)
+    assert ng.tolist() == nc.tolist() == [4] * 9 and np.array_equal(kg, kc)   # three marbles on the plane + one marble-marble pair inside the margin (impulse 0)
+    assert np.abs(ig[:, :, 0] - ic[:, :, 0]).max() < 1e-3 * ic[:, :, 0].max() and ic[:, :3, 0].min() > 0.1   # 10 kg x 9.81 / 480 = 0.2 N s
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 1e-3
+    mask = torch.zeros(9, dtype=torch.uint8); mask[[2, 5]] = 1
+    gpu.sim.reset(mask.to(gpu.device)); cpu.sim.reset(mask)
+    ng, kg, _ = warm_cache(gpu); nc, kc, _ = warm_cache(cpu)
+    assert ng.tolist() == nc.tolist() and np.array_equal(kg, kc)
+    cold, _ = make_pair('marbles', 9, warmstart=0.0)
+    assert cold.layout.warm_off == -1 and cold.layout.state_dim == gpu.layout.warm_off
+
+
+@pytest.mark.parametrize('name,env_vars,lanes,steps,tol,scale', [
+    ('readme', {}, 1, 30, 2e-3, 0.2), ('readme', {'DG_NO_WAVE_ENV': '1'}, 4, 30, 2e-3, 0.2), ('readme', {'DG_NO_NARROW_MODES': '1'}, -16, 30, 2e-3, 0.2),
+    ('readme', {'DG_NO_NARROW_MODES': '1', 'DG_NO_SLICED_GLOBAL': '1'}, 0, 30, 2e-3, 0.2),
+    ('marbles', {}, None, 100, 2e-3, 1.0), ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3, 1.0), ('marbles', {'DG_MAX_LANES': '8', 'DG_NO_REG_ROWS': '1'}, 8, 100, 2e-3, 1.0),
+    ('touching', {}, 64, 30, 5e-3, 0.3), ('touching', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-3, 0.3), ('touching', {'DG_NO_HELPER_WAVE': '1'}, 64, 30, 5e-3, 0.3),
+    ('cart_tree', {}, 64, 20, 2e-2, 1.0),
+])
+def test_warm_start_factor_of_bullet_in_every_sweep_form(name, env_vars, lanes, steps, tol, scale):
+    """The other setting of the two engine parameters -- Bullet's own, warmstart = 0.85 on the normal row [R], plus 0.5 on
+    the friction rows so that every starting impulse is exercised -- through every form of the sweeps (one env per
+    wavefront, lane-sliced from LDS / registers / the global workspace, 64 envs per wavefront streamed, the
+    arm-per-half-wavefront registers, the generic rows), against the oracle."""
+    os.environ.update(env_vars)
+    try:
+        gpu, cpu = make_pair(name, 9, warmstart=0.85, warmstart_friction=0.5)
+    finally:
+        for k in env_vars:
+            del os.environ[k]
+    if lanes is not None:
+        assert gpu.sim.lanes == lanes
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, steps, scale=scale)
+    assert w['obs'] < tol and w['term_mismatch'] == 0, w
+    ng, kg, _ = warm_cache(gpu); nc, kc, _ = warm_cache(cpu)
+    assert ng.tolist() == nc.tolist() and np.array_equal(kg, kc) and int(ng.max()) >= 1

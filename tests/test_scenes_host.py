@@ -41,7 +41,7 @@ def test_maze_generator_is_seeded_and_scene_compiles(tmp_path):
     wall_uid = env.models['wall_0'].uid
     row = SI[SI[:, K.SI_BODY] == wall_uid][0]
     assert row[K.SI_TYPE] == K.SHAPE_BOX and row[K.SI_FLAGS] & K.SHAPE_WORLD
-    assert env.layout.body_state_off[wall_uid] == -1 and env.layout.state_dim < 100
+    assert env.layout.body_state_off[wall_uid] == -1 and env.layout.physical_dim < 100
     # one broad-phase group per (R2D2, static shape)
     assert I[K.H_N_GROUPS] == n_walls + 1 and I[K.H_N_PAIRS] == 16 * (n_walls + 1)
     assert I[K.H_MAX_CONTACTS] == 12  # the generator's max_contacts key

@@ -486,6 +486,89 @@ DGD void lds_axpy(const Lane<LANES>& ln, int y, int x, float alpha, int n) {  //
   }
 }
 
+// ---- starting impulses of the motor rows (DG_HF_MOTOR_GUESS) -----------------------------------------------------------
+// Without the clamps the motor rows of one body are the linear system  A lambda = b,  A = M^-1 restricted to the motorised
+// joints (symmetric positive definite), b = the rows' velocity targets.  The sweeps start from its solution clamped to the
+// rows' impulse bounds instead of from zero: the same fixed point, reached in ~6 sweeps instead of ~35 for a
+// position-controlled arm (the oracle does the same; Bullet starts from zero [R]).
+// Register form, up to six joints: M row-major 6 x 6 (zero-padded), smax[i] = 0 for a joint without a motor.  acc = the
+// starting impulses, dv += M acc.
+DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv) {
+  float P[21], rhs[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    rhs[i] = smax[i] > 0.f ? b[i] : 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; j++) P[i * (i + 1) / 2 + j] = i == j ? (smax[i] > 0.f ? M[i * 6 + i] : 1.f) : ((smax[i] > 0.f && smax[j] > 0.f) ? M[i * 6 + j] : 0.f);
+  }
+  chol6(P); chol6_solve(P, rhs, x);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i], -smax[i], smax[i]);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) dv[c] += M[i * 6 + c] * acc[i];
+}
+// LDS form for a body with at most six joints (fixed or floating base): reads the joint block of M^-1 and the rows'
+// right-hand sides, writes the starting impulses into the rows' MR_ACC slots (every sweep form picks them up there and
+// adds the velocity change they amount to before its first iteration).
+template <int LANES>
+DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
+  const DevScene& sc = ln.sc; const float h = sc.h;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
+  const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
+  float M[36], bb[6], smax[6], acc[6], dv[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const bool has = i < n; const int ic = has ? i : 0;
+    const float maxf = ln.mt.v[3 * (first + ic) + 2]; smax[i] = has ? (maxf < 0.f ? -maxf : maxf * h) : 0.f;
+    bb[i] = has ? ln.L(mo0 + ic * MR_STRIDE + MR_B) : 0.f; dv[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) { const float m = ln.L(mvo + (k0 + ic) * nv + k0 + (c < n ? c : 0)); M[i * 6 + c] = (has && c < n) ? m : 0.f; }
+  }
+  chain_motor_guess(M, bb, smax, acc, dv);
+#pragma unroll
+  for (int i = 0; i < 6; i++) if (i < n) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
+}
+// LDS form for a body with more than six joints: packed Cholesky of the motorised block in the (free) transient region --
+// call it after the dynamics and before the contact rows are built there.  The motor table is uniform over the envs, so
+// every loop bound and every slot index is wave-uniform.
+template <int LANES>
+DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
+  const DevScene& sc = ln.sc; const float h = sc.h;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
+  const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
+  uint32_t motors = 0u; int k = 0;
+  for (int i = 0; i < n && i < 32; i++) { const float maxf = ln.mt.v[3 * (first + i) + 2]; if ((maxf < 0.f ? -maxf : maxf * h) > 0.f) { motors |= 1u << i; k++; } }
+  if (k == 0) return;
+  auto nth = [&](int a) { uint32_t m = motors; for (int t = 0; t < a; t++) m &= m - 1; return __ffs((int)m) - 1; };  // a-th motorised joint
+  const int A = sc.tr_off, Y = A + k * (k + 1) / 2;  // packed lower triangle (diagonal inverted, as chol6), then y / x
+  auto at = [&](int a, int c) { return A + a * (a + 1) / 2 + c; };
+  for (int a = 0; a < k; a++) { const int ia = nth(a); for (int c = 0; c <= a; c++) ln.L(at(a, c)) = ln.L(mvo + (k0 + ia) * nv + k0 + nth(c)); }
+  for (int a = 0; a < k; a++) {
+    for (int c = 0; c <= a; c++) {
+      const float s = ln.L(at(a, c)) - lds_dot(ln, at(a, 0), at(c, 0), c);
+      ln.L(at(a, c)) = a == c ? __frsqrt_rn(fmaxf(s, 1e-30f)) : s * ln.L(at(c, c));
+    }
+  }
+  for (int a = 0; a < k; a++) ln.L(Y + a) = (ln.L(mo0 + nth(a) * MR_STRIDE + MR_B) - lds_dot(ln, at(a, 0), Y, a)) * ln.L(at(a, a));
+  for (int a = k - 1; a >= 0; a--) {
+    float s = ln.L(Y + a);
+    for (int t = a + 1; t < k; t++) s -= ln.L(at(t, a)) * ln.L(Y + t);
+    ln.L(Y + a) = s * ln.L(at(a, a));
+  }
+  for (int a = 0; a < k; a++) {
+    const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * h;
+    ln.L(mo0 + i * MR_STRIDE + MR_ACC) = __builtin_amdgcn_fmed3f(ln.L(Y + a), -lim, lim);
+  }
+}
+template <int LANES>
+DGD void motor_guess(const Lane<LANES>& ln, int b) {
+  if (!(ln.sc.HF[DG_HF_MOTOR_GUESS] > 0.f)) return;
+  const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0) return;
+  if (n <= 6) motor_guess_small(ln, b); else motor_guess_lds(ln, b);
+}
+
 // one PGS update of contact row at ro; returns the squared velocity residual
 template <int LANES>
 DGD float solve_crow(const Lane<LANES>& ln, int ro, int co, float lo, float hi, bool live, bool has) {
@@ -697,6 +780,11 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
       for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * a0;
     }
   }
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
+    DenseCol<NTB> W; load_motor(W, __ffsll((long long)m) - 1);
+#pragma unroll
+    for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * W.acc;
+  }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
@@ -851,6 +939,11 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
       for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
     }
   }
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
+    Col W; load_motor(W, __ffsll((long long)m) - 1);
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * W.acc;
+  }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
     maxres = 0.f;
@@ -959,7 +1052,10 @@ DGD int pgs_dense_sliced_regs(const Lane<LANES>& ln, int ncont_primary, uint64_t
     for (int i = 0; i < NS; i++) { const int k = i * SL + sl; const float v = ls[(col - base + i * SL) * LANES]; lR[gl][i] = (have && k >= base && k < base + nv) ? v : 0.f; }
     const float dg = lq.L(col + j - base);
     ldg[gl] = have ? dg : 1.f; lrd[gl] = have ? frcp(dg) : 0.f;
-    mb[gl] = have ? lq.L(mo + MR_B) : 0.f; mlim[gl] = (have && ((rows.motors >> gl) & 1ull)) ? lim : 0.f; macc[gl] = 0.f;
+    mb[gl] = have ? lq.L(mo + MR_B) : 0.f; mlim[gl] = (have && ((rows.motors >> gl) & 1ull)) ? lim : 0.f;
+    macc[gl] = (have && ((rows.motors >> gl) & 1ull)) ? lq.L(mo + MR_ACC) : 0.f;  // (starting impulse: motor_guess)
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += lR[gl][i] * macc[gl];
     lb[0][gl] = lq.L(mo + MR_LO_B); la[0][gl] = have ? lq.L(mo + MR_LO_ACC) : -1.f; lb[1][gl] = lq.L(mo + MR_HI_B); la[1][gl] = have ? lq.L(mo + MR_HI_ACC) : -1.f;
     lji[gl] = j >> LOG; lmine[gl] = (j & (SL - 1)) == sl;
   }
@@ -1110,7 +1206,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   const bool has_motor = isj && ((rows.motors >> ml) & 1ull);
   float ldg = 1.f, lrd = 0.f, mb = 0.f, mlim = 0.f, macc = 0.f, lb0 = 0.f, la0 = -1.f, lb1 = 0.f, la1 = -1.f;
   if (isj) {
-    ldg = lq.L(mcol + lane - mbase); lrd = frcp(ldg); mb = lq.L(mmo + MR_B); mlim = has_motor ? mlimv : 0.f;
+    ldg = lq.L(mcol + lane - mbase); lrd = frcp(ldg); mb = lq.L(mmo + MR_B); mlim = has_motor ? mlimv : 0.f; macc = has_motor ? lq.L(mmo + MR_ACC) : 0.f;  // (starting impulse: motor_guess)
     lb0 = lq.L(mmo + MR_LO_B); la0 = lq.L(mmo + MR_LO_ACC); lb1 = lq.L(mmo + MR_HI_B); la1 = lq.L(mmo + MR_HI_ACC);
   }
   const uint64_t jmask = __ballot(isj), jmotor = __ballot(has_motor);
@@ -1146,6 +1242,10 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
       }
     }
   }
+  static_for<0, NLM>([&](auto jc) {  // the velocity change the motor rows' starting impulses amount to
+    constexpr int j = decltype(jc)::value;
+    if ((jmotor >> j) & 1ull) dv += lRd[j] * rdl(macc, j);
+  });
   if (sc.warm_off >= 0) static_for<0, 3 * CM>([&](auto rc) {  // warm start: the velocity change the rows' starting impulses amount to
     constexpr int R = decltype(rc)::value, o = 16 + (R & 15), sl_ = R >> 4;
     if (R < 3 * ncont) dv += cR[R] * rdl(caccv[sl_], o);
@@ -1235,7 +1335,9 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   const int n_acc = 3 * maxc + 3 * sc.nl;
   const int ncont = __shfl(ncont_primary, q), rsw = sc.crow_tail + 3;
   // (contact rows start from the impulse their builder left in the row -- warm start -- the others from zero)
-  for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = (sc.warm_off >= 0 && id < 3 * ncont) ? BL(col_off, sc.tr_off + id * rsw + 2 * sc.nt + 1) : 0.f;
+  // (per-lane slots: the whole offset goes through the vector operand)
+  for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = (sc.warm_off >= 0 && id < 3 * ncont) ? BL(col_off + (unsigned)(sc.tr_off + id * rsw + 2 * sc.nt + 1) * W * 4u, 0) : 0.f;
+  for (int gl = sl; gl < sc.nl; gl += SL) acc[(3 * maxc + gl) * EPW] = BL(col_off + (unsigned)(sc.PLL[gl * PLL_STRIDE + PLL_MROW] + MR_ACC) * W * 4u, 0);  // motor rows: motor_guess (zero without it)
   float dv[NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) dv[i] = 0.f;
@@ -1292,6 +1394,11 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
 #pragma unroll
       for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
     }
+  }
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
+    Col W; load_motor(W, __ffsll((long long)m) - 1);
+#pragma unroll
+    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * W.acc;
   }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
@@ -1533,6 +1640,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
     for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
   }
+  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv);  // the sweeps start next to their fixed point
   // limit rows some lane of the wavefront has active (the flags cannot change during the sweeps): bit 2 i + side.  Rows
   // nobody needs are skipped with a wave-uniform branch, so a sweep costs what the wavefront's active limits cost
   unsigned lim_rows = 0u;
@@ -1714,6 +1822,13 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     const int hf = ln.bi(hb)[DG_BI_FIRST_LINK], hn = ln.bi(hb)[DG_BI_N_LINKS];
     setup_link_rows(ln, 0, hf, limit_mask, limit_rows); setup_link_rows(ln, hf + hn, sc.nl, limit_mask, limit_rows);
   } else setup_link_rows(ln, 0, sc.nl, limit_mask, limit_rows);
+  // ---- starting impulses of the motor rows (motor_guess): bodies with more than six joints need the transient region,
+  // which is free between the dynamics and the contact rows; register-chain bodies are done where their rows end up
+  // (in registers, or below once it is known that this substep streams every row)
+  for (int b = 0; b < sc.nba; b++) {
+    if (ln.bi(b)[DG_BI_N_LINKS] == 0 || b == sc.reg_body[0] || b == sc.reg_body[1] || (helper_rows && b == hb)) continue;
+    motor_guess(ln, b);
+  }
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   // all-dense scenes: the sweeps start from a zero velocity change held in registers, so until they finish the LDS
   // velocity-change blocks are free -- park the generalised velocities there for the row right-hand sides
@@ -1795,6 +1910,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   // (motors and limits included) goes through the dense streaming sweeps instead
   constexpr bool FW = FULLWAVE || PAR;
   if (all_dense || (sc.dense && (wave_max_cont > 0 || limit_mask != 0ull) && sc.nl <= 32)) {  // (active limit rows: streamed too -- the register sweeps of this path carry motor rows only)
+    for (int k = 0; k < 2; k++) if (sc.reg_body[k] >= 0) motor_guess(ln, sc.reg_body[k]);  // (<= 6 joints: no workspace needed)
     if (sc.nt <= 8) iters_done = pgs_dense<LANES, 8, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
     else if (sc.nt <= 16) iters_done = pgs_dense<LANES, 16, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
     else if (sc.nt <= 24) iters_done = pgs_dense<LANES, 24, PROF, FW>(ln, ncont, wave_max_cont, limit_rows, prof);
@@ -1833,6 +1949,15 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   bool has_generic = false;
   for (int b = 0; b < sc.nba; b++) if (ln.bi(b)[DG_BI_N_LINKS] > 0 && b != sc.reg_body[0] && b != sc.reg_body[1]) has_generic = true;
   const float thr_abs = sqrtf(thr);  // the register rows track |residual|; same test as residual^2 <= thr
+  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) {  // the motor rows start next to their fixed point (motor_guess)
+#pragma unroll
+    for (int k = 0; k < NBR; k++) if (sc.reg_body[k] >= 0) chain_motor_guess(rM[k], rb[k], smax[k], racc[k], rdv[k]);
+    if (has_generic) for (int b = 0; b < sc.nba; b++) {  // (their starting impulses are in the rows' MR_ACC slots)
+      const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || b == sc.reg_body[0] || b == sc.reg_body[1]) continue;
+      const int first = ln.bi(b)[DG_BI_FIRST_LINK], k0 = ln.fixed(b) ? 0 : 6, nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
+      for (int i = 0; i < n; i++) { const float a0 = ln.L(ln.pll(first + i)[PLL_MROW] + MR_ACC); lds_axpy(ln, dvo, mvo + (k0 + i) * nv, a0, nv); }
+    }
+  }
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
     const int nvm = sc.nv_max; const bool two = sc.crow_tail > 2 * nvm;
     for (int c = 0; c < wave_max_cont; c++) {

@@ -78,6 +78,9 @@ DEFAULTS = dict(
     # landed with -- tests/test_oracle_kat.py::test_force_torque_sensor_sees_contact_forces_on_the_child_side).
     warmstart=1.0,
     warmstart_friction=0.0,
+    # motor rows start from the clamped direct solution of their body's unclamped motor system instead of zero (same
+    # fixed point; 35 -> 6 sweeps for ur_high_5, 26 -> 1 for from_the_readme); 0 = Bullet's cold start [R]
+    motor_guess=1.0,
 )
 
 
@@ -591,6 +594,7 @@ class SceneBuilder:
         HF[K.HF_CONTACT_MARGIN] = p['contact_margin']
         HF[K.HF_WARMSTART] = p['warmstart']
         HF[K.HF_WARMSTART_FRICTION] = p['warmstart_friction']
+        HF[K.HF_MOTOR_GUESS] = p['motor_guess']
         off = K.HF_FLOAT_COUNT
         chunks_f = [HF]
         for name, t in tables_f:

@@ -96,6 +96,8 @@ enum {
   DG_HF_WARMSTART,      /* a contact that persists (same pair, same feature) starts its NORMAL row from this factor x the
                            impulse it ended the previous substep with (Bullet: m_warmstartingFactor 0.85 [R]); 0 = off */
   DG_HF_WARMSTART_FRICTION, /* the same for its two friction rows (Bullet starts friction rows from zero [R])          */
+  DG_HF_MOTOR_GUESS,    /* > 0: the motor rows of a body start from the clamped solution of the body's unclamped motor system
+                           (M^-1 restricted to the motorised joints) lambda = b instead of from zero                      */
   DG_HF_FLOAT_COUNT
 };
 

@@ -786,6 +786,25 @@ static void substep(dgo_world* w, int env, int last) {
       }
     }
   }
+  /* Starting impulses of the motor rows (DG_HF_MOTOR_GUESS): without the clamps a body's motor rows are the linear system
+   * (M^-1 restricted to the motorised joints) lambda = b, solved directly here and clamped to the rows' bounds -- the
+   * sweeps then start next to their fixed point instead of at zero (Bullet starts at zero [R]; the fixed point is the
+   * same, the residual early-out fires after ~6 sweeps instead of ~35 for a position-controlled arm). */
+  if (s->F[DG_HF_MOTOR_GUESS] > 0) {
+    int r0 = 0;
+    for (int b = 0; b < s->nb; b++) {
+      BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
+      for (int r = r0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
+      if (k == 0) continue;
+      real A[MAXL * MAXL], bb[MAXL], x[MAXL];
+      for (int j = 0; j < k; j++) { bb[j] = rows[idx[j]].b; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]]; }
+      if (!spd_solve(k, A, bb, x)) continue;
+      for (int j = 0; j < k; j++) {
+        Row* r = &rows[idx[j]]; real imp = x[j] < r->lo ? r->lo : (x[j] > r->hi ? r->hi : x[j]);
+        r->acc = imp; for (int q = 0; q < 6 + ws->n; q++) ws->dv[q] += r->RA[q] * imp;
+      }
+    }
+  }
   for (int b = 0; b < s->nb; b++) {
     BodyWS* ws = &wsb[b];
     for (int i = 0; i < ws->n; i++) {

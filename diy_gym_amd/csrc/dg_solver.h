@@ -494,16 +494,30 @@ DGD void lds_axpy(const Lane<LANES>& ln, int y, int x, float alpha, int n) {  //
 // Register form, up to six joints: M row-major 6 x 6 (zero-padded), smax[i] = 0 for a joint without a motor.  acc = the
 // starting impulses, dv += M acc.
 DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv) {
-  float P[21], rhs[6], x[6];
+  // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
+  // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal)
+  float P[21], rhs[6], x[6], sd[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * 6 + i], 1e-30f)) : 0.f;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    rhs[i] = smax[i] > 0.f ? b[i] : 0.f;
+    rhs[i] = b[i] * sd[i];
 #pragma unroll
-    for (int j = 0; j <= i; j++) P[i * (i + 1) / 2 + j] = i == j ? (smax[i] > 0.f ? M[i * 6 + i] : 1.f) : ((smax[i] > 0.f && smax[j] > 0.f) ? M[i * 6 + j] : 0.f);
+    for (int j = 0; j <= i; j++) P[i * (i + 1) / 2 + j] = i == j ? 1.f : M[i * 6 + j] * sd[i] * sd[j];
   }
-  chol6(P); chol6_solve(P, rhs, x);
 #pragma unroll
-  for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i], -smax[i], smax[i]);
+  for (int i = 0; i < 6; i++) {  // chol6 with the pivot floor
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float t = P[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= P[i * (i + 1) / 2 + k] * P[j * (j + 1) / 2 + k];
+      P[i * (i + 1) / 2 + j] = i == j ? __frsqrt_rn(fmaxf(t, 1e-6f)) : t * P[j * (j + 1) / 2 + j];
+    }
+  }
+  chol6_solve(P, rhs, x);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i] * sd[i], -smax[i], smax[i]);
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -541,17 +555,21 @@ DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
   uint32_t motors = 0u; int k = 0;
   for (int i = 0; i < n && i < 32; i++) { const float maxf = ln.mt.v[3 * (first + i) + 2]; if ((maxf < 0.f ? -maxf : maxf * h) > 0.f) { motors |= 1u << i; k++; } }
   if (k == 0) return;
-  auto nth = [&](int a) { uint32_t m = motors; for (int t = 0; t < a; t++) m &= m - 1; return __ffs((int)m) - 1; };  // a-th motorised joint
-  const int A = sc.tr_off, Y = A + k * (k + 1) / 2;  // packed lower triangle (diagonal inverted, as chol6), then y / x
+  const bool all = k == n;  // (every joint has a motor: the usual case -- pybullet gives every joint one at load)
+  auto nth = [&](int a) { if (all) return a; uint32_t m = motors; for (int t = 0; t < a; t++) m &= m - 1; return __ffs((int)m) - 1; };  // a-th motorised joint
+  // workspace in the transient region: packed lower triangle (diagonal inverted, as chol6), then y / x, then the scaling
+  const int A = sc.tr_off, Y = A + k * (k + 1) / 2 + 8, S = Y + k + 8;
   auto at = [&](int a, int c) { return A + a * (a + 1) / 2 + c; };
-  for (int a = 0; a < k; a++) { const int ia = nth(a); for (int c = 0; c <= a; c++) ln.L(at(a, c)) = ln.L(mvo + (k0 + ia) * nv + k0 + nth(c)); }
+  // symmetric scaling to a unit diagonal (finger and shoulder joints differ by 1e5 in M^-1; this is an fp32 factorisation)
+  for (int a = 0; a < k; a++) { const int ia = nth(a); ln.L(S + a) = __frsqrt_rn(fmaxf(ln.L(mvo + (k0 + ia) * nv + k0 + ia), 1e-30f)); }
+  for (int a = 0; a < k; a++) { const int ia = nth(a); const float sa = ln.L(S + a); for (int c = 0; c < a; c++) ln.L(at(a, c)) = ln.L(mvo + (k0 + ia) * nv + k0 + nth(c)) * sa * ln.L(S + c); ln.L(at(a, a)) = 1.f; }
   for (int a = 0; a < k; a++) {
     for (int c = 0; c <= a; c++) {
       const float s = ln.L(at(a, c)) - lds_dot(ln, at(a, 0), at(c, 0), c);
-      ln.L(at(a, c)) = a == c ? __frsqrt_rn(fmaxf(s, 1e-30f)) : s * ln.L(at(c, c));
+      ln.L(at(a, c)) = a == c ? __frsqrt_rn(fmaxf(s, 1e-6f)) : s * ln.L(at(c, c));  // (pivot floored at 1e-6 of its diagonal)
     }
   }
-  for (int a = 0; a < k; a++) ln.L(Y + a) = (ln.L(mo0 + nth(a) * MR_STRIDE + MR_B) - lds_dot(ln, at(a, 0), Y, a)) * ln.L(at(a, a));
+  for (int a = 0; a < k; a++) ln.L(Y + a) = (ln.L(mo0 + nth(a) * MR_STRIDE + MR_B) * ln.L(S + a) - lds_dot(ln, at(a, 0), Y, a)) * ln.L(at(a, a));
   for (int a = k - 1; a >= 0; a--) {
     float s = ln.L(Y + a);
     for (int t = a + 1; t < k; t++) s -= ln.L(at(t, a)) * ln.L(Y + t);
@@ -559,7 +577,7 @@ DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
   }
   for (int a = 0; a < k; a++) {
     const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * h;
-    ln.L(mo0 + i * MR_STRIDE + MR_ACC) = __builtin_amdgcn_fmed3f(ln.L(Y + a), -lim, lim);
+    ln.L(mo0 + i * MR_STRIDE + MR_ACC) = __builtin_amdgcn_fmed3f(ln.L(Y + a) * ln.L(S + a), -lim, lim);
   }
 }
 template <int LANES>

@@ -796,11 +796,14 @@ static void substep(dgo_world* w, int env, int last) {
       BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
       for (int r = r0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
       if (k == 0) continue;
-      real A[MAXL * MAXL], bb[MAXL], x[MAXL];
-      for (int j = 0; j < k; j++) { bb[j] = rows[idx[j]].b; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]]; }
+      /* (symmetrically scaled to a unit diagonal first: finger joints and shoulder joints differ by 1e5 in M^-1, and the
+       * device solves this in fp32) */
+      real A[MAXL * MAXL], bb[MAXL], x[MAXL], sc_[MAXL];
+      for (int j = 0; j < k; j++) sc_[j] = 1.0 / sqrt(rows[idx[j]].RA[6 + dof[j]]);
+      for (int j = 0; j < k; j++) { bb[j] = rows[idx[j]].b * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l]; }
       if (!spd_solve(k, A, bb, x)) continue;
       for (int j = 0; j < k; j++) {
-        Row* r = &rows[idx[j]]; real imp = x[j] < r->lo ? r->lo : (x[j] > r->hi ? r->hi : x[j]);
+        Row* r = &rows[idx[j]]; real imp = x[j] * sc_[j]; imp = imp < r->lo ? r->lo : (imp > r->hi ? r->hi : imp);
         r->acc = imp; for (int q = 0; q < 6 + ws->n; q++) ws->dv[q] += r->RA[q] * imp;
       }
     }

@@ -206,8 +206,8 @@ static m6 rigid_inertia(real m, v3 c, const m3* Ic) {
 }
 /* solve A x = b for SPD 6x6 (Cholesky); returns 0 on failure */
 static int spd_solve(int n, const real* A, const real* b, real* x) {
-  real L[12 * 12];
-  if (n > 12) return 0;
+  real L[MAXV * MAXV];
+  if (n > MAXV) return 0;
   memset(L, 0, sizeof L);
   for (int i = 0; i < n; i++)
     for (int j = 0; j <= i; j++) {
@@ -215,7 +215,7 @@ static int spd_solve(int n, const real* A, const real* b, real* x) {
       for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
       if (i == j) { if (s <= 0) return 0; L[i * n + i] = sqrt(s); } else L[i * n + j] = s / L[j * n + j];
     }
-  real y[12];
+  real y[MAXV];
   for (int i = 0; i < n; i++) { real s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k]; y[i] = s / L[i * n + i]; }
   for (int i = n - 1; i >= 0; i--) { real s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
   return 1;

@@ -36,6 +36,7 @@ SYMBOLS = {
     'dg_world_step': (ctypes.c_int32, [_vp, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dg_world_observe': (ctypes.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dg_world_frame_state': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
+    'dg_world_apply_wrench': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     'dg_world_render': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     'dg_world_set_diag_buffer': (ctypes.c_int32, [_vp, _vp]),
     'dg_world_set_profile_buffer': (ctypes.c_int32, [_vp, _vp]),
@@ -179,6 +180,38 @@ class HipBackend:
         self._check(self.lib.dg_world_frame_state(self.handle, _ptr(self.state), int(body), int(frame), int(bool(com)), _ptr(out),
                                                   self._stream()))
         return out
+
+    # -- batched p.applyExternalForce / p.applyExternalTorque for addons written in Python ----------------------------
+    LINK_FRAME, WORLD_FRAME = 1, 2   # pybullet's flag values
+
+    def _rows3(self, name, v):
+        """``v`` as a contiguous float32 ``[num_envs, 3]`` tensor on this device: one 3-vector for every env, or one per env."""
+        if v is None:
+            return None
+        t = torch.as_tensor(v, dtype=torch.float32, device=self.device) if not isinstance(v, torch.Tensor) else v.to(device=self.device, dtype=torch.float32)
+        if t.numel() == 3:
+            t = t.reshape(1, 3).expand(self.num_envs, 3)
+        if t.numel() != 3 * self.num_envs:
+            raise ValueError('%s must have 3 or %d x 3 elements, got shape %s' % (name, self.num_envs, tuple(t.shape)))
+        return t.reshape(self.num_envs, 3).contiguous()
+
+    def apply_external_force(self, body, frame, force, pos=None, flags=2):
+        """``p.applyExternalForce(uid, linkIndex, forceObj, posObj, flags)`` for every env at once (``force``: ``[B, 3]`` or
+        one 3-vector; ``pos``: likewise, default the origin).  ``frame`` is the index ``Model.get_frame_id`` returns
+        (-1: the base).  The force acts during the next ``step`` only, like pybullet's; see ``dg_world_apply_wrench``."""
+        self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), _ptr(self._rows3('force', force)),
+                                                   _ptr(self._rows3('pos', pos)), None, self._stream()))
+
+    def apply_external_wrench(self, body, frame, force, pos, torque, flags=2):
+        """Force at ``pos`` and torque in ONE launch (what the compiled ``propellor`` op does: its base torque is
+        ``r x F + T`` summed before it is added to the state, so this form reproduces that op bit for bit)."""
+        self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), _ptr(self._rows3('force', force)),
+                                                   _ptr(self._rows3('pos', pos)), _ptr(self._rows3('torque', torque)), self._stream()))
+
+    def apply_external_torque(self, body, frame, torque, flags=2):
+        """``p.applyExternalTorque(uid, linkIndex, torqueObj, flags)`` for every env at once."""
+        self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), None, None,
+                                                   _ptr(self._rows3('torque', torque)), self._stream()))
 
     def camera_resolution(self, camera):
         I, K = self.layout.I, _scene_constants()

@@ -534,4 +534,24 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
   return DG_OK;
 }
 
+int32_t dg_world_apply_wrench(dg_world* w, float* state, int32_t body, int32_t frame, int32_t flags, const float* force, const float* pos,
+                              const float* torque, void* stream) {
+  if (!w || !state) return fail(DG_ERR_ARG, "null argument");
+  if (body < 0 || body >= w->sc.nb) return fail(DG_ERR_ARG, "body %d out of range", body);
+  const int32_t* I = w->I.data();
+  if (I[I[DG_H_OFF_BODY_I] + body * DG_BI_STRIDE + DG_BI_FLAGS] & DG_BODY_FROZEN) return fail(DG_ERR_ARG, "body %d is part of the frozen static world: it has no state to push on", body);
+  if (flags != DG_WRENCH_WORLD_FRAME && flags != DG_WRENCH_LINK_FRAME) return fail(DG_ERR_ARG, "flags must be DG_WRENCH_LINK_FRAME (1) or DG_WRENCH_WORLD_FRAME (2)");
+  int gf = -1;  // `frame` is the body-local pybullet joint index; the kernels use the global frame index
+  if (frame >= 0) {
+    const int32_t* FI = I + I[DG_H_OFF_FRAME_I]; int seen = 0; bool found = false;
+    for (int f = 0; f < w->sc.nfr; f++) if (FI[f * DG_FI_STRIDE + DG_FI_BODY] == body) { if (seen == frame) { gf = f; found = true; break; } seen++; }
+    if (!found) return fail(DG_ERR_ARG, "body %d has no frame %d", body, frame);
+  }
+  if (!force && !torque) return DG_OK;
+  DG_ON_DEVICE(w->device);
+  launch_table(w->lanes).wrench(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, state, body, gf, flags == DG_WRENCH_LINK_FRAME ? 1 : 0, force, pos, torque, w->d_gws);
+  HIP_TRY(hipGetLastError());
+  return DG_OK;
+}
+
 }  // extern "C"

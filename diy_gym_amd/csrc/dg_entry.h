@@ -144,5 +144,20 @@ __global__ __launch_bounds__(64) void frame_kernel(DevScene sc, MotorTable mt, f
   o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w; o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
 }
 
+// dg_world_apply_wrench: p.applyExternalForce / p.applyExternalTorque for user addons written in Python (reference
+// examples/drone_pilot/drone_pilot.py:34-37, diy_gym/addons/controllers/external_force.py:24), every env at once;
+// force / pos / torque are [num_envs][3] or null (= zero).  Consumed by the next dg_world_step.
+template <int LANES>
+__global__ __launch_bounds__(64) void wrench_kernel(DevScene sc, MotorTable mt, float* state, int body, int frame, int link_frame,
+                                                     const float* force, const float* pos, const float* torque, float* gws) {
+  extern __shared__ float smem[];
+  constexpr int ACTIVE = envs_per_wave(LANES);
+  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
+  Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + env, env, true);
+  ln.kinematics(body);
+  auto row = [&](const float* p) { return p ? v3(p[3 * (size_t)env], p[3 * (size_t)env + 1], p[3 * (size_t)env + 2]) : v3(0.f, 0.f, 0.f); };
+  apply_frame_wrench(ln, body, frame, row(force), row(pos), row(torque), link_frame != 0);
+}
 
 }  // namespace dg

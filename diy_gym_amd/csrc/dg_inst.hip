@@ -58,6 +58,9 @@ static void l_observe(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTabl
 static void l_frame(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws) {
   hipLaunchKernelGGL(frame_kernel<L>, grid, dim3(64), lds, st, sc, mt, state, body, frame, com, out, gws);
 }
+static void l_wrench(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int link_frame, const float* force, const float* pos, const float* torque, float* gws) {
+  hipLaunchKernelGGL(wrench_kernel<L>, grid, dim3(64), lds, st, sc, mt, state, body, frame, link_frame, force, pos, torque, gws);
+}
 static void l_pose(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws) {
   hipLaunchKernelGGL(pose_kernel<L>, grid, dim3(64), lds, st, sc, mt, state, ncam, CI, CF, table, gws);
 }
@@ -68,7 +71,7 @@ static hipError_t l_prepare(int lds) {
   }
   hipError_t e = DGL(l_prepare_step)(lds);
 #define DG_ATTR(K) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-  DG_ATTR(reset_kernel<L>); DG_ATTR(observe_kernel<L>); DG_ATTR(frame_kernel<L>); DG_ATTR(pose_kernel<L>);
+  DG_ATTR(reset_kernel<L>); DG_ATTR(observe_kernel<L>); DG_ATTR(frame_kernel<L>); DG_ATTR(wrench_kernel<L>); DG_ATTR(pose_kernel<L>);
 #undef DG_ATTR
 #if DG_LANES == 64
   if (e == hipSuccess) e = l_prepare_par_64(lds);
@@ -83,7 +86,7 @@ extern const LaunchTable DGL(g_launch_table) = {
 #else
     nullptr,
 #endif
-    l_reset, l_observe, l_frame, l_pose};
+    l_reset, l_observe, l_frame, l_wrench, l_pose};
 #endif
 #endif
 

@@ -15,6 +15,7 @@ struct LaunchTable {
   void (*reset)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, const uint8_t* mask, float* obs, float* gws);
   void (*observe)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, float* obs, float* rew, uint8_t* term, float* rew_sum, uint8_t* term_flag, float* gws);
   void (*frame)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int com, float* out, float* gws);
+  void (*wrench)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int body, int frame, int link_frame, const float* force, const float* pos, const float* torque, float* gws);
   void (*pose)(dim3 grid, int lds, hipStream_t st, DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws);
 };
 const LaunchTable& launch_table(int lanes);  // lanes in {64, 32, 16, 8, 4, 0, -16}

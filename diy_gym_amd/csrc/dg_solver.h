@@ -2376,6 +2376,30 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
   return iters;
 }
 
+// p.applyExternalForce / p.applyExternalTorque on frame `fr` (global frame index, -1: base) of body b: a force `f` acting at
+// `pos` and a torque `t`, all three in the frame's axes with `pos` relative to its origin (link_frame) or in world
+// coordinates, added to what the body feels during the NEXT simulation step only: the base's external wrench (state:
+// world frame, about the base origin) and -- for a frame on a movable link -- the torques of the joints between that link
+// and the base (J^T of the wrench).  POSE of the body must be current.  The compiled ops (external_force, propellor) and
+// the C-ABI entry dg_world_apply_wrench (user addons written in Python) share this function, bit for bit.
+template <int LANES>
+DGD void apply_frame_wrench(const Lane<LANES>& ln, int b, int fr, V3 f, V3 pos, V3 t, bool link_frame) {
+  const DevScene& sc = ln.sc;
+  V3 F = f, T = t, P = pos;
+  if (link_frame) { V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); const M3 R = qmat(fq); F = mul(R, f); T = mul(R, t); P = fp + mul(R, pos); }
+  if (!ln.fixed(b)) {
+    const V3 tq = cross(P - ln.base_pos(b), F) + T; const int eo = ln.ext_off(b);
+    ln.Sset(eo, ln.S(eo) + F.x); ln.Sset(eo + 1, ln.S(eo + 1) + F.y); ln.Sset(eo + 2, ln.S(eo + 2) + F.z);
+    ln.Sset(eo + 3, ln.S(eo + 3) + tq.x); ln.Sset(eo + 4, ln.S(eo + 4) + tq.y); ln.Sset(eo + 5, ln.S(eo + 5) + tq.z);
+  }
+  for (int k = fr < 0 ? -1 : sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK]; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
+    const int po = ln.pll(k)[PLL_POSE], lo = ln.li(k)[DG_LI_STATE_OFF]; cfp lf = ln.lf(k);
+    const V3 axw = mul(ln.LR(po), v3(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]));
+    const float tau = ln.li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(P - ln.L3(po + 6), F) + T) : dot(axw, F);
+    ln.Sset(lo + DG_LS_TORQUE, ln.S(lo + DG_LS_TORQUE) + tau);
+  }
+}
+
 // ------------------------------------------------------------ addon program
 template <int LANES>
 DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t mask, int only_body = -1, int skip_body = -1, int32_t* diag = nullptr) {
@@ -2447,20 +2471,15 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
         tau += of[3] * (tgt[k] - ln.S(lo + DG_LS_Q)) - of[4] * ln.S(lo + DG_LS_QD);
         ln.Sset(lo + DG_LS_TORQUE, ln.S(lo + DG_LS_TORQUE) + tau);
       }
-    } else if (code == DG_OP_EXTERNAL_FORCE) {
+    } else if (code == DG_OP_EXTERNAL_FORCE) {  // external_force.py:24: p.applyExternalForce(uid, -1, action, xyz, WORLD_FRAME)
       const int b = oi[DG_OI_BODY]; if (ln.fixed(b)) continue;
-      const int eo = ln.ext_off(b); V3 f = v3(a[0], a[1], a[2]); V3 t = cross(v3(of[0], of[1], of[2]) - ln.base_pos(b), f);
-      ln.Sset(eo, ln.S(eo) + f.x); ln.Sset(eo + 1, ln.S(eo + 1) + f.y); ln.Sset(eo + 2, ln.S(eo + 2) + f.z);
-      ln.Sset(eo + 3, ln.S(eo + 3) + t.x); ln.Sset(eo + 4, ln.S(eo + 4) + t.y); ln.Sset(eo + 5, ln.S(eo + 5) + t.z);
-    } else if (code == DG_OP_PROPELLOR) {
+      apply_frame_wrench(ln, b, -1, v3(a[0], a[1], a[2]), v3(of[0], of[1], of[2]), v3(0.f, 0.f, 0.f), false);
+    } else if (code == DG_OP_PROPELLOR) {  // drone_pilot.py:31-37: thrust along and torque about the motor frame's z, LINK_FRAME
       const int b = oi[DG_OI_BODY], so = sc.addon_off + oi[DG_OI_STATE_OFF];
-      float w = ln.S(so); w = w + (a[0] - w) * of[2]; ln.Sset(so, w);
+      // (separately rounded product and sum: a user addon doing the same two steps with torch gets the same bits)
+      float w = ln.S(so); w = __fadd_rn(w, __fmul_rn(a[0] - w, of[2])); ln.Sset(so, w);
       if (ln.fixed(b)) continue;
-      V3 fp, fv, fw; Q4 fq; ln.frame_state(b, oi[DG_OI_FRAME], false, fp, fq, fv, fw, false);
-      M3 R = qmat(fq); V3 fwd = mul(R, v3(0.f, 0.f, of[0] * w)), tw = mul(R, v3(0.f, 0.f, of[1] * w));
-      V3 t = cross(fp - ln.base_pos(b), fwd) + tw; const int eo = ln.ext_off(b);
-      ln.Sset(eo, ln.S(eo) + fwd.x); ln.Sset(eo + 1, ln.S(eo + 1) + fwd.y); ln.Sset(eo + 2, ln.S(eo + 2) + fwd.z);
-      ln.Sset(eo + 3, ln.S(eo + 3) + t.x); ln.Sset(eo + 4, ln.S(eo + 4) + t.y); ln.Sset(eo + 5, ln.S(eo + 5) + t.z);
+      apply_frame_wrench(ln, b, oi[DG_OI_FRAME], v3(0.f, 0.f, __fmul_rn(of[0], w)), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, __fmul_rn(of[1], w)), true);
     }
   }
 }

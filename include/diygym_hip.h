@@ -100,6 +100,20 @@ int32_t dg_world_observe(dg_world* w, const float* state, float* obs, float* rew
 int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int32_t frame, int32_t com, float* out,
                              void* stream);
 
+/* Replaces p.applyExternalForce(uid, linkIndex, force, pos, flags) + p.applyExternalTorque(uid, linkIndex, torque, flags)
+ * for addons that are NOT compiled into the step kernel -- a user's Python addon acting on the world from its update()
+ * hook (reference examples/drone_pilot/drone_pilot.py:34-37, diy_gym/addons/addon.py:80-81 registry, :91-186 hooks;
+ * diy_gym/addons/controllers/external_force.py:24) -- every env at once: force, pos, torque are device arrays
+ * [num_envs][3] (any may be NULL = zero).  `frame` is the pybullet joint index of the link (-1 = base).  flags as in
+ * pybullet: DG_WRENCH_LINK_FRAME -- force / torque in the link frame's axes, pos relative to its origin;
+ * DG_WRENCH_WORLD_FRAME -- all three in world coordinates.  The wrench acts during the NEXT dg_world_step only
+ * (pybullet clears external forces after every stepSimulation) and adds to what compiled ops apply.  For a frame on a
+ * movable link the joints between it and the base receive J^T of the wrench.  The compiled external_force / propellor
+ * ops run the same device function, so a Python addon built on this entry reproduces them bit for bit. */
+enum { DG_WRENCH_LINK_FRAME = 1, DG_WRENCH_WORLD_FRAME = 2 };
+int32_t dg_world_apply_wrench(dg_world* w, float* state, int32_t body, int32_t frame, int32_t flags, const float* force,
+                              const float* pos, const float* torque, void* stream);
+
 /* Replaces Camera.observe -> p.computeProjectionMatrixFOV / p.getCameraImage (reference
  * diy_gym/addons/sensors/camera.py:44,58-92) for camera `camera` of the scene, all envs:
  *   rgb   float [num_envs][h*w*3]  flat shaded body colour (NOT a parity output: pybullet renders visual meshes)

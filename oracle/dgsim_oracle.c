@@ -1119,6 +1119,34 @@ static void run_update_ops(dgo_world* w, int env, const real* act, uint64_t mask
     }
   }
 }
+/* p.applyExternalForce / p.applyExternalTorque on frame `fr` (global frame index, -1 base) of body b for one env, as a user
+ * addon written in Python issues them (drone_pilot.py:34-37): base wrench + J^T on the joints between the link and the base */
+int dgo_apply_wrench(dgo_world* w, int32_t body, int32_t frame, int32_t link_frame, const real* force, const real* pos, const real* torque) {
+  Scene* s = &w->sc;
+  if (body < 0 || body >= s->nb || (body_i(s, body)[DG_BI_FLAGS] & DG_BODY_FROZEN)) { set_err("bad body %d", body); return 1; }
+  for (int e = 0; e < w->B; e++) {
+    real* st = env_state(w, e);
+    v3 F = force ? V(force[3 * e], force[3 * e + 1], force[3 * e + 2]) : V(0, 0, 0), T = torque ? V(torque[3 * e], torque[3 * e + 1], torque[3 * e + 2]) : V(0, 0, 0);
+    v3 P = pos ? V(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) : V(0, 0, 0);
+    if (link_frame) { FrameState f; frame_state(s, st, body, frame, 0, NULL, &f); m3 R = qmat(f.q); F = mv(&R, F); T = mv(&R, T); P = vadd(f.p, mv(&R, P)); }
+    if (!body_fixed(s, body)) {
+      real* bs = st + body_i(s, body)[DG_BI_STATE_OFF]; real* ex = body_ext(s, st, body);
+      v3 t = vadd(vcross(vsub(P, V(bs[0], bs[1], bs[2])), F), T);
+      ex[0] += F.x; ex[1] += F.y; ex[2] += F.z; ex[3] += t.x; ex[4] += t.y; ex[5] += t.z;
+    }
+    if (frame >= 0) {
+      BodyWS* ws = (BodyWS*)malloc(sizeof(BodyWS)); body_kinematics(s, st, body, ws, NULL);
+      for (int k = s->FI[frame * DG_FI_STRIDE + DG_FI_LINK]; k >= 0; k = link_i(s, k)[DG_LI_PARENT]) {
+        const real* lf = link_f(s, k); int lk = k - ws->first;
+        v3 axw = mv(&ws->Rw[lk], V(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]));
+        real tau = link_i(s, k)[DG_LI_TYPE] == 0 ? vdot(axw, vadd(vcross(vsub(P, ws->pw[lk]), F), T)) : vdot(axw, F);
+        st[link_i(s, k)[DG_LI_STATE_OFF] + DG_LS_TORQUE] += tau;
+      }
+      free(ws);
+    }
+  }
+  return 0;
+}
 static void set_base_com_pose(const Scene* s, real* st, int b, v3 pc, qt qc) {
   /* p.resetBasePositionAndOrientation takes the pose of the root inertial frame and zeroes the velocity [R] */
   const real* bf = body_f(s, b); real* bs = st + body_i(s, b)[DG_BI_STATE_OFF];

@@ -66,6 +66,11 @@ int dgo_frame_state(dgo_world* w, int32_t env, int32_t body, int32_t frame, int3
  * Flat pixel index = row * width + col, row 0 at the top.  Any pointer may be NULL. */
 int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* seg);
 
+/* p.applyExternalForce + p.applyExternalTorque for every env (force / pos / torque: [num_envs][3] or NULL = zero), frame =
+ * GLOBAL frame index (-1 base), link_frame != 0: vectors in the link frame's axes, pos relative to its origin.  Acts during
+ * the next dgo_step only.  The checker of dg_world_apply_wrench. */
+int dgo_apply_wrench(dgo_world* w, int32_t body, int32_t frame, int32_t link_frame, const real* force, const real* pos, const real* torque);
+
 /* diagnostics from the most recent substep of env `env` */
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env);
 int32_t dgo_last_iterations(const dgo_world* w, int32_t env);

@@ -47,6 +47,7 @@ def lib(path=None):
         L.dgo_unit_response.argtypes = [vp, i32, i32, i32, vp]
         L.dgo_ik.argtypes = [vp, i32, i32, vp, vp]
         L.dgo_render.argtypes = [vp, i32, vp, vp, vp]
+        L.dgo_apply_wrench.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         _LIBS[path] = L
     return _LIBS[path]
 
@@ -151,6 +152,32 @@ class OracleBackend:
         if seg is not None:
             seg.copy_(torch.from_numpy(s32))
         self.last_render64 = (r64, d64, s32)
+
+    LINK_FRAME, WORLD_FRAME = 1, 2
+
+    def _rows3(self, v):
+        if v is None:
+            return None
+        a = np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=self.real)
+        return np.ascontiguousarray(np.broadcast_to(a.reshape(-1, 3), (self.num_envs, 3)))
+
+    def apply_external_force(self, body, frame, force, pos=None, flags=2):
+        gf = -1 if frame < 0 else self._global_frame(body, frame)
+        f, p = self._rows3(force), self._rows3(pos)
+        if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), _p(f), _p(p), None):
+            raise RuntimeError(self.L.dgo_last_error().decode())
+
+    def apply_external_wrench(self, body, frame, force, pos, torque, flags=2):
+        gf = -1 if frame < 0 else self._global_frame(body, frame)
+        f, p, t = self._rows3(force), self._rows3(pos), self._rows3(torque)
+        if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), _p(f), _p(p), _p(t)):
+            raise RuntimeError(self.L.dgo_last_error().decode())
+
+    def apply_external_torque(self, body, frame, torque, flags=2):
+        gf = -1 if frame < 0 else self._global_frame(body, frame)
+        t = self._rows3(torque)
+        if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), None, None, _p(t)):
+            raise RuntimeError(self.L.dgo_last_error().decode())
 
     def motor_cfg(self):
         return self._mcfg[:self.n_links].copy()

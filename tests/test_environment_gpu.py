@@ -268,3 +268,46 @@ def test_unindexed_device_string_is_accepted():
     cam = [a for r in env.receptors.values() for a in r.addons.values() if hasattr(a, 'camera_index')][0]
     out = cam.observe()
     assert out['depth'].shape[0] == 4 and bool(torch.isfinite(out['depth']).all())
+
+
+def test_python_hook_addon_equals_the_compiled_propellor_bit_for_bit():
+    """A user addon that acts on the world from Python: the reference's Propellor (examples/drone_pilot/drone_pilot.py:10-40;
+    registry diy_gym/addons/addon.py:80-81, hooks :91-186) written as a plain hook addon on ``env.sim.apply_external_*``
+    (dg_world_apply_wrench) against the compiled DG_OP_PROPELLOR, same dict actions, 40 steps incl. terminal resets:
+    the whole state is bit-identical with the one-launch form; with pybullet's two separate calls the base torque is
+    summed in another order, so that form is equal to 1e-6 relative instead."""
+    import yaml
+    import diy_gym_amd.examples  # noqa: F401
+    from diy_gym_amd import DIYGym
+    from diy_gym_amd.addons.addon import AddonFactory
+    from diy_gym_amd.config import Configuration
+    from user_addons import PyPropellor, PyPropellorTwoCalls
+    AddonFactory.register_addon('py_propellor', PyPropellor)
+    AddonFactory.register_addon('py_propellor2', PyPropellorTwoCalls)
+    tree = yaml.safe_load(open(DRONE))
+    motors = sorted(k for k, v in tree['drone'].items() if isinstance(v, dict) and v.get('addon') == 'propellor')
+    assert len(motors) == 4
+    B = 257
+
+    def make(addon_name):
+        t = yaml.safe_load(open(DRONE))
+        for m in motors:
+            t['drone'][m]['addon'] = addon_name
+        return DIYGym(Configuration.from_dict('drone_pilot', t), num_envs=B, device='cuda:0', seed=4)
+
+    compiled, hooked, hooked2 = make('propellor'), make('py_propellor'), make('py_propellor2')
+    assert not compiled._hook_addons and len(hooked._hook_addons) == 4
+    gen = torch.Generator().manual_seed(1)
+    for step in range(40):
+        act = {'drone': {m: torch.rand((B, 1), generator=gen).to('cuda:0') for m in motors}}
+        oc, _, tc, _ = compiled.step(act); oh, _, th, _ = hooked.step(act); o2, _, _, _ = hooked2.step(act)
+        for m in motors:
+            assert torch.equal(oc['drone'][m], oh['drone'][m]), (step, m)   # rotor speeds
+        assert compiled.layout.addon_off == hooked.layout.addon_off   # (the compiled rotors keep their speed behind it, the hooked ones in Python)
+        assert torch.equal(compiled.sim.state[:compiled.layout.addon_off], hooked.sim.state[:hooked.layout.addon_off]), step
+        a, b = compiled.sim.state[:compiled.layout.addon_off, :B], hooked2.sim.state[:hooked2.layout.addon_off, :B]
+        assert float(((a - b).abs() / (1.0 + a.abs())).max()) < 1e-5, step
+        done = compiled.sim.term_flag.clone()
+        assert torch.equal(done, hooked.sim.term_flag)
+        compiled.reset(done); hooked.reset(done); hooked2.reset(done)
+    assert float(compiled.sim.state[2, :B].min()) < 4.9   # they flew / fell: the forces did something

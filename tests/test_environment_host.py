@@ -287,3 +287,30 @@ def test_three_finger_gripper_asset_loads_and_steps():
         for _ in range(10):
             o, _, _, _ = env.step({})
         assert torch.isfinite(o['arm']['joints']['position']).all()
+
+
+def test_python_hook_addon_pushes_on_the_world_like_the_compiled_op():
+    """The batched ``sim.apply_external_force`` API for user addons (reference addon.py:80-186 plugin contract, external_force.py:9-24):
+    a plain Python hook addon equals the compiled ``external_force`` addon on the oracle backend (same arithmetic, fp64)."""
+    import copy
+    import yaml
+    from diy_gym_amd.addons.addon import AddonFactory
+    from diy_gym_amd.config import Configuration
+    from user_addons import PyExternalForce
+    AddonFactory.register_addon('py_external_force', PyExternalForce)
+    tree = yaml.safe_load(open(os.path.join(ROOT, 'tests', 'golden', 'basic_env_nocam.yaml')))
+    forces = [(r, k) for r, v in tree.items() if isinstance(v, dict) for k, a in v.items() if isinstance(a, dict) and a.get('addon') == 'external_force']
+    assert forces
+    hooked_tree = copy.deepcopy(tree)
+    for r, k in forces:
+        hooked_tree[r][k]['addon'] = 'py_external_force'
+    a = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=3, backend_factory=OracleBackend)
+    b = DIYGym(Configuration.from_dict('basic_env', hooked_tree), num_envs=3, backend_factory=OracleBackend)
+    assert len(b._hook_addons) == len(forces) and not a._hook_addons
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(50):
+        act = {r: {k: (torch.rand((3, 3), generator=gen) * 2 - 1) * 10.0} for r, k in forces}
+        a.step(act); b.step(act)
+    n = a.layout.addon_off
+    assert np.allclose(a.sim.get_state()[:, :n], b.sim.get_state()[:, :n], rtol=0, atol=1e-12)
+    assert np.abs(a.sim.get_state()[:, :n]).max() > 1.0

@@ -330,10 +330,65 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
   struct Px { V3 d; float idd; RayHit h; int row, col; bool inside; };
   Px px[2];
   const int n_entries = overflow ? sc.nsh : total;
-  // ---------------- phase B: a 16 x 8 tile per wavefront at a time (lane: column lane & 15, rows lane >> 4 and (lane >> 4) + 4)
-  const int ntx = (W + 15) >> 4, ntiles = ntx * ((nrows + 7) >> 3);
-  for (int tile = wv; tile < ntiles; tile += 4) {  // consecutive tiles (row-major) go to the four wavefronts: neighbours in time and in memory
-    const int tyi = tile / ntx, c0 = (tile - tyi * ntx) << 4, q0 = r0 + 8 * tyi, qn = min(8, r0 + nrows - q0);  // tile rows [q0, q0 + qn)
+  // ---------------- phase B: a STRIP of eight full image rows per wavefront at a time, 16 x 8 tiles inside it (lane: column
+  // lane & 15, rows lane >> 4 and (lane >> 4) + 4).  The strip comes first: its list is culled once against the strip's
+  // cone, frustum and separating faces (the tests a tile makes, 13 times less often), the tiles then only look at the
+  // strip's survivors, and a strip without any -- most of a picture of the sky -- is one contiguous piece of each output
+  // image and is filled with 16-byte stores.
+  __shared__ float s_stage[4][640];  // per wavefront: a tile's depth (128), segmentation (128) and rgb (384) on their way to 16-byte stores
+  const bool wide = (W & 3) == 0 && !(diag & 64);  // every 4-pixel piece of a row is 16-byte aligned (diag 64: scalar stores, for tests)
+  const int ntx = (W + 15) >> 4, nstrips = (nrows + 7) >> 3;
+  const size_t img = (size_t)env * W * H;
+  for (int strip = wv; strip < nstrips; strip += 4) {
+    const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
+    unsigned long long smask[2] = {~0ull, ~0ull};  // the strip's candidates among the band's list (entries 0..63, 64..127)
+    if (!overflow) {
+      V3 saxis; float scos, ssin; cone_of(0.f, (float)W, (float)q0, (float)(q0 + qn), saxis, scos, ssin);
+      const V3 eL = rayA, eR = rayA + rayB * (float)W, eT = rayA + rayC * (float)q0, eB = rayA + rayC * (float)(q0 + qn);
+      V3 nL = cross(eL, rayC), nR = cross(eR, rayC), nT = cross(eT, rayB), nB = cross(eB, rayB);
+      if (dot(nL, rayB) > 0.f) nL = -nL;
+      if (dot(nR, rayB) < 0.f) nR = -nR;
+      if (dot(nT, rayC) > 0.f) nT = -nT;
+      if (dot(nB, rayC) < 0.f) nB = -nB;
+      smask[0] = smask[1] = 0ull;
+      for (int base = 0; base < total; base += 64) {
+        const int j = min(base + lane, total - 1);
+        const V3 ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); const float eb = s_f[j][RL_BOUND];
+        const bool boxed = no_cull || (s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
+        const bool cand = base + lane < total && boxed && (no_cull || cone_pass(ev, eb, saxis, scos, ssin)) && s_i[j][RLI_TYPE] >= 0;
+        unsigned long long keep = __ballot(cand);
+        if (!no_cull) for (unsigned long long mm = keep; mm; mm &= mm - 1) {
+          const int bit = __ffsll((long long)mm) - 1, jj = base + bit, type = s_i[jj][RLI_TYPE];  // wave-uniform
+          if (type != DG_SHAPE_BOX && type != DG_SHAPE_POINTS) continue;
+          const int po = s_i[jj][RLI_PLANE_OFF], nout = s_i[jj][RLI_NOUT]; bool sep = false;
+          for (int f0 = 0; f0 < nout; f0 += 64) { const int f = min(f0 + lane, nout - 1); sep = sep || (s_pl[po + f][3] > 0.f && s_pl[po + f][0] * saxis.x + s_pl[po + f][1] * saxis.y + s_pl[po + f][2] * saxis.z >= ssin + 1e-5f); }
+          if (__any(sep)) { keep &= ~(1ull << bit); continue; }
+          const int pto = s_i[jj][RLI_PT_OFF], npt = s_i[jj][RLI_NPT]; bool inL = false, inR = false, inT = false, inB = false;
+          for (int f0 = 0; f0 < npt; f0 += 64) {
+            const bool have = f0 + lane < npt; const int f = min(f0 + lane, npt - 1); const V3 w = v3(s_pt[pto + f][0], s_pt[pto + f][1], s_pt[pto + f][2]);
+            inL = inL || (have && dot(nL, w) <= 0.f); inR = inR || (have && dot(nR, w) <= 0.f); inT = inT || (have && dot(nT, w) <= 0.f); inB = inB || (have && dot(nB, w) <= 0.f);
+          }
+          if (npt > 0 && (!__any(inL) || !__any(inR) || !__any(inT) || !__any(inB))) keep &= ~(1ull << bit);
+        }
+        smask[base >> 6] = keep;
+      }
+      if (!(smask[0] | smask[1]) || (diag & 2)) {  // nothing in sight: the strip's rows are one contiguous piece of every image
+        const size_t o0 = img + (size_t)q0 * W; const int count = qn * W;
+        if (wide) {
+          const float4 dz = make_float4(-zf, -zf, -zf, -zf), bg = make_float4(0.75f, 0.75f, 0.75f, 0.75f); const int4 sgm = make_int4(-1, -1, -1, -1);
+          if (depth) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<float4*>(depth + o0)[i] = dz;
+          if (seg) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<int4*>(seg + o0)[i] = sgm;
+          if (rgb) for (int i = lane; i < 3 * count / 4; i += 64) reinterpret_cast<float4*>(rgb + 3 * o0)[i] = bg;
+        } else {
+          if (depth) for (int i = lane; i < count; i += 64) depth[o0 + i] = -zf;
+          if (seg) for (int i = lane; i < count; i += 64) seg[o0 + i] = -1;
+          if (rgb) for (int i = lane; i < 3 * count; i += 64) rgb[3 * o0 + i] = 0.75f;
+        }
+        continue;
+      }
+    }
+  for (int txi = 0; txi < ntx; txi++) {
+    const int c0 = txi << 4;  // tile: columns [c0, c0 + 16) of the strip
     V3 axis; float cos_t, sin_t;
     cone_of((float)c0, (float)min(c0 + 16, W), (float)q0, (float)(q0 + qn), axis, cos_t, sin_t);
     // the tile's four side planes through the eye, outward normals (rays are A + c B + r C, so the plane of a column
@@ -359,7 +414,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
       else { cfp s = tb + j * RS_STRIDE; ev = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; eb = s[RS_BOUND]; }
       // the entry's image-space box against the tile's rectangle first (four compares), then the sphere-cone test
       const bool boxed = overflow || no_cull || (s_bb[j][1] >= (float)c0 && s_bb[j][0] <= (float)min(c0 + 16, W) && s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
-      const bool cand = base + lane < n_entries && boxed && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
+      const bool cand = base + lane < n_entries && boxed && (overflow || ((smask[(base >> 6) & 1] >> lane) & 1ull)) && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
       for (unsigned long long mm = (diag & 2) ? 0ull : __ballot(cand); mm; mm &= mm - 1) {
         const int jj = base + __ffsll((long long)mm) - 1;  // wave-uniform
         if (!overflow) {
@@ -417,27 +472,56 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
         }
       }
     }
+    // ---- the tile's pixels out: through LDS into 16-byte stores (four pixels of depth / segmentation, 1 1/3 of rgb per lane)
+    float vdepth[2]; int vsegm[2]; float vcol[2][3];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      if (!px[u].inside) continue;
       const RayHit& h = px[u].h;
-      const bool hit = h.shape >= 0 && (h.t >= zn || (diag & 32)); const size_t o = (size_t)env * W * H + (size_t)px[u].row * W + px[u].col;
-      if (depth) depth[o] = hit ? -h.t : -zf;
-      if (seg) {
-        int vseg = -1;
-        if (hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vseg = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
-        seg[o] = vseg;
-      }
-      if (rgb) {
-        float c0r = 0.75f, c1r = 0.75f, c2r = 0.75f;
-        if (hit) {
-          cfp colr = tb + h.shape * RS_STRIDE + RS_COLOR;  // per-lane index: vector loads from the env's table
-          const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
-          c0r = colr[0] * shd; c1r = colr[1] * shd; c2r = colr[2] * shd;
-        }
-        rgb[3 * o] = c0r; rgb[3 * o + 1] = c1r; rgb[3 * o + 2] = c2r;
+      const bool hit = h.shape >= 0 && (h.t >= zn || (diag & 32));
+      vdepth[u] = hit ? -h.t : -zf; vsegm[u] = -1; vcol[u][0] = vcol[u][1] = vcol[u][2] = 0.75f;
+      if (seg && hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vsegm[u] = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
+      if (rgb && hit) {
+        cfp colr = tb + h.shape * RS_STRIDE + RS_COLOR;  // per-lane index: vector loads from the env's table
+        const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
+        vcol[u][0] = colr[0] * shd; vcol[u][1] = colr[1] * shd; vcol[u][2] = colr[2] * shd;
       }
     }
+    if (wide) {
+      float* sg = s_stage[wv]; const int ncols = min(16, W - c0);  // (a multiple of 4)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();  // the previous tile's reads are done
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int pi = ((lane >> 4) + 4 * u) * 16 + (lane & 15);
+        sg[pi] = vdepth[u]; sg[128 + pi] = __builtin_bit_cast(float, vsegm[u]); sg[256 + 3 * pi] = vcol[u][0]; sg[256 + 3 * pi + 1] = vcol[u][1]; sg[256 + 3 * pi + 2] = vcol[u][2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (lane < 32) {  // depth / segmentation: row lane >> 2, pixels 4 (lane & 3) .. + 3
+        const int row = lane >> 2, g4 = (lane & 3) * 4;
+        if (row < qn && g4 < ncols) {
+          const size_t o = img + (size_t)(q0 + row) * W + c0 + g4;
+          if (depth) *reinterpret_cast<float4*>(depth + o) = *reinterpret_cast<const float4*>(sg + row * 16 + g4);
+          if (seg) *reinterpret_cast<float4*>(seg + o) = *reinterpret_cast<const float4*>(sg + 128 + row * 16 + g4);
+        }
+      }
+      if (rgb) {
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {  // 96 16-byte pieces: row m / 12, floats 4 (m % 12) .. + 3 of the row's 48
+          const int m = lane + 64 * rnd, row = m / 12, part = m - row * 12;
+          if (m < 96 && row < qn && 4 * part < 3 * ncols)
+            *reinterpret_cast<float4*>(rgb + 3 * (img + (size_t)(q0 + row) * W + c0) + 4 * part) = *reinterpret_cast<const float4*>(sg + 256 + row * 48 + 4 * part);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!px[u].inside) continue;
+        const size_t o = img + (size_t)px[u].row * W + px[u].col;
+        if (depth) depth[o] = vdepth[u];
+        if (seg) seg[o] = vsegm[u];
+        if (rgb) { rgb[3 * o] = vcol[u][0]; rgb[3 * o + 1] = vcol[u][1]; rgb[3 * o + 2] = vcol[u][2]; }
+      }
+    }
+  }
   }
 }
 

@@ -2384,18 +2384,30 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 // the C-ABI entry dg_world_apply_wrench (user addons written in Python) share this function, bit for bit.
 template <int LANES>
 DGD void apply_frame_wrench(const Lane<LANES>& ln, int b, int fr, V3 f, V3 pos, V3 t, bool link_frame) {
+  // Every product and sum below is rounded on its own (no fused multiply-add): inlined into the step kernel the compiled
+  // ops pass literal zeros, and a compiler free to contract would fuse e.g. `r x F + R t` differently there than in
+  // wrench_kernel, where the same vectors arrive from memory.  With contraction off the two are the same bits.
+#pragma clang fp contract(off)
   const DevScene& sc = ln.sc;
   V3 F = f, T = t, P = pos;
-  if (link_frame) { V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); const M3 R = qmat(fq); F = mul(R, f); T = mul(R, t); P = fp + mul(R, pos); }
+  if (link_frame) {
+    V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); const M3 R = qmat(fq);
+    F = v3(R.m[0] * f.x + R.m[1] * f.y + R.m[2] * f.z, R.m[3] * f.x + R.m[4] * f.y + R.m[5] * f.z, R.m[6] * f.x + R.m[7] * f.y + R.m[8] * f.z);
+    T = v3(R.m[0] * t.x + R.m[1] * t.y + R.m[2] * t.z, R.m[3] * t.x + R.m[4] * t.y + R.m[5] * t.z, R.m[6] * t.x + R.m[7] * t.y + R.m[8] * t.z);
+    P = v3(fp.x + (R.m[0] * pos.x + R.m[1] * pos.y + R.m[2] * pos.z), fp.y + (R.m[3] * pos.x + R.m[4] * pos.y + R.m[5] * pos.z), fp.z + (R.m[6] * pos.x + R.m[7] * pos.y + R.m[8] * pos.z));
+  }
   if (!ln.fixed(b)) {
-    const V3 tq = cross(P - ln.base_pos(b), F) + T; const int eo = ln.ext_off(b);
+    const V3 bp = ln.base_pos(b), r = v3(P.x - bp.x, P.y - bp.y, P.z - bp.z);
+    const V3 tq = v3((r.y * F.z - r.z * F.y) + T.x, (r.z * F.x - r.x * F.z) + T.y, (r.x * F.y - r.y * F.x) + T.z); const int eo = ln.ext_off(b);
     ln.Sset(eo, ln.S(eo) + F.x); ln.Sset(eo + 1, ln.S(eo + 1) + F.y); ln.Sset(eo + 2, ln.S(eo + 2) + F.z);
     ln.Sset(eo + 3, ln.S(eo + 3) + tq.x); ln.Sset(eo + 4, ln.S(eo + 4) + tq.y); ln.Sset(eo + 5, ln.S(eo + 5) + tq.z);
   }
   for (int k = fr < 0 ? -1 : sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK]; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
     const int po = ln.pll(k)[PLL_POSE], lo = ln.li(k)[DG_LI_STATE_OFF]; cfp lf = ln.lf(k);
-    const V3 axw = mul(ln.LR(po), v3(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]));
-    const float tau = ln.li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(P - ln.L3(po + 6), F) + T) : dot(axw, F);
+    const M3 Rk = ln.LR(po); const V3 pk = ln.L3(po + 6), a = v3(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]);
+    const V3 axw = v3(Rk.m[0] * a.x + Rk.m[1] * a.y + Rk.m[2] * a.z, Rk.m[3] * a.x + Rk.m[4] * a.y + Rk.m[5] * a.z, Rk.m[6] * a.x + Rk.m[7] * a.y + Rk.m[8] * a.z);
+    const V3 r = v3(P.x - pk.x, P.y - pk.y, P.z - pk.z), m = v3((r.y * F.z - r.z * F.y) + T.x, (r.z * F.x - r.x * F.z) + T.y, (r.x * F.y - r.y * F.x) + T.z);
+    const float tau = ln.li(k)[DG_LI_TYPE] == 0 ? axw.x * m.x + axw.y * m.y + axw.z * m.z : axw.x * F.x + axw.y * F.y + axw.z * F.z;
     ln.Sset(lo + DG_LS_TORQUE, ln.S(lo + DG_LS_TORQUE) + tau);
   }
 }

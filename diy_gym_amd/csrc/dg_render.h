@@ -335,14 +335,13 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
   // cone, frustum and separating faces (the tests a tile makes, 13 times less often), the tiles then only look at the
   // strip's survivors, and a strip without any -- most of a picture of the sky -- is one contiguous piece of each output
   // image and is filled with 16-byte stores.
-  __shared__ float s_stage[4][640];  // per wavefront: a tile's depth (128), segmentation (128) and rgb (384) on their way to 16-byte stores
   const bool wide = (W & 3) == 0 && !(diag & 64);  // every 4-pixel piece of a row is 16-byte aligned (diag 64: scalar stores, for tests)
   const int ntx = (W + 15) >> 4, nstrips = (nrows + 7) >> 3;
   const size_t img = (size_t)env * W * H;
   for (int strip = wv; strip < nstrips; strip += 4) {
     const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
     unsigned long long smask[2] = {~0ull, ~0ull};  // the strip's candidates among the band's list (entries 0..63, 64..127)
-    if (!overflow) {
+    if (!overflow && !(diag & 128)) {  // (diag 128: no strip-level culling, every tile looks at the whole list)
       V3 saxis; float scos, ssin; cone_of(0.f, (float)W, (float)q0, (float)(q0 + qn), saxis, scos, ssin);
       const V3 eL = rayA, eR = rayA + rayB * (float)W, eT = rayA + rayC * (float)q0, eB = rayA + rayC * (float)(q0 + qn);
       V3 nL = cross(eL, rayC), nR = cross(eR, rayC), nT = cross(eT, rayB), nB = cross(eB, rayB);
@@ -472,7 +471,8 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
         }
       }
     }
-    // ---- the tile's pixels out: through LDS into 16-byte stores (four pixels of depth / segmentation, 1 1/3 of rgb per lane)
+    // ---- the tile's pixels out (staging them through LDS into 16-byte stores was measured: no gain, and the 10 KB of LDS cost a
+    // workgroup per CU -- the stores are not what this kernel waits for)
     float vdepth[2]; int vsegm[2]; float vcol[2][3];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -486,32 +486,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene sc, cip CI, cfp CF
         vcol[u][0] = colr[0] * shd; vcol[u][1] = colr[1] * shd; vcol[u][2] = colr[2] * shd;
       }
     }
-    if (wide) {
-      float* sg = s_stage[wv]; const int ncols = min(16, W - c0);  // (a multiple of 4)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();  // the previous tile's reads are done
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int pi = ((lane >> 4) + 4 * u) * 16 + (lane & 15);
-        sg[pi] = vdepth[u]; sg[128 + pi] = __builtin_bit_cast(float, vsegm[u]); sg[256 + 3 * pi] = vcol[u][0]; sg[256 + 3 * pi + 1] = vcol[u][1]; sg[256 + 3 * pi + 2] = vcol[u][2];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-      if (lane < 32) {  // depth / segmentation: row lane >> 2, pixels 4 (lane & 3) .. + 3
-        const int row = lane >> 2, g4 = (lane & 3) * 4;
-        if (row < qn && g4 < ncols) {
-          const size_t o = img + (size_t)(q0 + row) * W + c0 + g4;
-          if (depth) *reinterpret_cast<float4*>(depth + o) = *reinterpret_cast<const float4*>(sg + row * 16 + g4);
-          if (seg) *reinterpret_cast<float4*>(seg + o) = *reinterpret_cast<const float4*>(sg + 128 + row * 16 + g4);
-        }
-      }
-      if (rgb) {
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {  // 96 16-byte pieces: row m / 12, floats 4 (m % 12) .. + 3 of the row's 48
-          const int m = lane + 64 * rnd, row = m / 12, part = m - row * 12;
-          if (m < 96 && row < qn && 4 * part < 3 * ncols)
-            *reinterpret_cast<float4*>(rgb + 3 * (img + (size_t)(q0 + row) * W + c0) + 4 * part) = *reinterpret_cast<const float4*>(sg + 256 + row * 48 + 4 * part);
-        }
-      }
-    } else {
+    {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         if (!px[u].inside) continue;

@@ -493,56 +493,66 @@ DGD void lds_axpy(const Lane<LANES>& ln, int y, int x, float alpha, int n) {  //
 // position-controlled arm (the oracle does the same; Bullet starts from zero [R]).
 // Register form, up to six joints: M row-major 6 x 6 (zero-padded), smax[i] = 0 for a joint without a motor.  acc = the
 // starting impulses, dv += M acc.
-DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv) {
+template <int N>
+DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv) {
   // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
-  // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal)
-  float P[21], rhs[6], x[6], sd[6];
+  // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal.  Packed lower triangle with
+  // the diagonal stored inverted, as chol6: multiply-only.)
+  float P[N * (N + 1) / 2], y[N], x[N], sd[N];
 #pragma unroll
-  for (int i = 0; i < 6; i++) sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * 6 + i], 1e-30f)) : 0.f;
+  for (int i = 0; i < N; i++) sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f;
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    rhs[i] = b[i] * sd[i];
-#pragma unroll
-    for (int j = 0; j <= i; j++) P[i * (i + 1) / 2 + j] = i == j ? 1.f : M[i * 6 + j] * sd[i] * sd[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) {  // chol6 with the pivot floor
+  for (int i = 0; i < N; i++) {
 #pragma unroll
     for (int j = 0; j <= i; j++) {
-      float t = P[i * (i + 1) / 2 + j];
+      float t = i == j ? 1.f : M[i * N + j] * sd[i] * sd[j];
 #pragma unroll
       for (int k = 0; k < j; k++) t -= P[i * (i + 1) / 2 + k] * P[j * (j + 1) / 2 + k];
       P[i * (i + 1) / 2 + j] = i == j ? __frsqrt_rn(fmaxf(t, 1e-6f)) : t * P[j * (j + 1) / 2 + j];
     }
   }
-  chol6_solve(P, rhs, x);
 #pragma unroll
-  for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i] * sd[i], -smax[i], smax[i]);
+  for (int i = 0; i < N; i++) {
+    float t = b[i] * sd[i];
 #pragma unroll
-  for (int i = 0; i < 6; i++)
+    for (int k = 0; k < i; k++) t -= P[i * (i + 1) / 2 + k] * y[k];
+    y[i] = t * P[i * (i + 1) / 2 + i];
+  }
 #pragma unroll
-    for (int c = 0; c < 6; c++) dv[c] += M[i * 6 + c] * acc[i];
+  for (int i = N - 1; i >= 0; i--) {
+    float t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++) t -= P[k * (k + 1) / 2 + i] * x[k];
+    x[i] = t * P[i * (i + 1) / 2 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i] * sd[i], -smax[i], smax[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int c = 0; c < N; c++) dv[c] += M[i * N + c] * acc[i];
 }
-// LDS form for a body with at most six joints (fixed or floating base): reads the joint block of M^-1 and the rows'
-// right-hand sides, writes the starting impulses into the rows' MR_ACC slots (every sweep form picks them up there and
-// adds the velocity change they amount to before its first iteration).
-template <int LANES>
+DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv) { chain_motor_guess_n<6>(M, b, smax, acc, dv); }
+// LDS form for a body with at most N joints (fixed or floating base): reads the joint block of M^-1 and the rows'
+// right-hand sides into registers, writes the starting impulses into the rows' MR_ACC slots (every sweep form picks them
+// up there and adds the velocity change they amount to before its first iteration).
+template <int LANES, int N>
 DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
   const DevScene& sc = ln.sc; const float h = sc.h;
   const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
   const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
-  float M[36], bb[6], smax[6], acc[6], dv[6];
+  float M[N * N], bb[N], smax[N], acc[N], dv[N];
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < N; i++) {
     const bool has = i < n; const int ic = has ? i : 0;
     const float maxf = ln.mt.v[3 * (first + ic) + 2]; smax[i] = has ? (maxf < 0.f ? -maxf : maxf * h) : 0.f;
     bb[i] = has ? ln.L(mo0 + ic * MR_STRIDE + MR_B) : 0.f; dv[i] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 6; c++) { const float m = ln.L(mvo + (k0 + ic) * nv + k0 + (c < n ? c : 0)); M[i * 6 + c] = (has && c < n) ? m : 0.f; }
+    for (int c = 0; c < N; c++) { const float m = ln.L(mvo + (k0 + ic) * nv + k0 + (c < n ? c : 0)); M[i * N + c] = (has && c < n) ? m : 0.f; }
   }
-  chain_motor_guess(M, bb, smax, acc, dv);
+  chain_motor_guess_n<N>(M, bb, smax, acc, dv);
 #pragma unroll
-  for (int i = 0; i < 6; i++) if (i < n) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
+  for (int i = 0; i < N; i++) if (i < n) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
 }
 // LDS form for a body with more than six joints: packed Cholesky of the motorised block in the (free) transient region --
 // call it after the dynamics and before the contact rows are built there.  The motor table is uniform over the envs, so
@@ -584,7 +594,7 @@ template <int LANES>
 DGD void motor_guess(const Lane<LANES>& ln, int b) {
   if (!(ln.sc.HF[DG_HF_MOTOR_GUESS] > 0.f)) return;
   const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0) return;
-  if (n <= 6) motor_guess_small(ln, b); else motor_guess_lds(ln, b);
+  if (n <= 6) motor_guess_small<LANES, 6>(ln, b); else if (n <= 8) motor_guess_small<LANES, 8>(ln, b); else if (n <= 12) motor_guess_small<LANES, 12>(ln, b); else motor_guess_lds(ln, b);
 }
 
 // one PGS update of contact row at ro; returns the squared velocity residual

@@ -38,6 +38,7 @@ SYMBOLS = {
     'dg_world_frame_state': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp]),
     'dg_world_apply_wrench': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     'dg_world_render': (ctypes.c_int32, [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    'dg_world_set_render_diag': (ctypes.c_int32, [_vp, ctypes.c_int32]),
     'dg_world_set_diag_buffer': (ctypes.c_int32, [_vp, _vp]),
     'dg_world_set_profile_buffer': (ctypes.c_int32, [_vp, _vp]),
 }
@@ -230,6 +231,10 @@ class HipBackend:
         if seg is not None:
             self._require_numel('seg', seg, px, torch.int32)
         self._check(self.lib.dg_world_render(self.handle, _ptr(self.state), int(camera), _ptr(rgb), _ptr(depth), _ptr(seg), self._stream()))
+
+    def set_render_diag(self, flags):
+        """Diagnostic switches of ``render`` (1: no culling -- the brute-force picture; see dg_world_set_render_diag)."""
+        self._check(self.lib.dg_world_set_render_diag(self.handle, int(flags)))
 
     def motor_cfg(self):
         cfg = np.zeros((self.n_links, 3), dtype=np.float64)

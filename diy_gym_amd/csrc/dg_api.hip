@@ -58,6 +58,9 @@ struct dg_world {
   bool par = false;  // step runs as two wavefronts per workgroup (helper wave)
   bool no_par_reset = false;  // DG_NO_PAR_RESET: masked resets through reset_kernel<64> (one wavefront, generic solver)
   float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
+  int cu_count = 1;     // multiProcessorCount of `device`, read once in dg_world_create
+  int render_diag = 0;  // DG_RENDER_NO_CULL / DG_RENDER_DIAG at creation (diagnostics), dg_world_set_render_diag later
+  int render_wpe = 2;   // wavefronts per SIMD of the render kernel's build (DG_RENDER_WPE=3: the spilling build)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
   ~dg_world() {  // also the clean-up of a dg_world_create that failed half way
     DeviceGuard g(device);
@@ -166,6 +169,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     }
   slot += tr + 8;  // + padding for the chunked vector helpers
   const int total = slot;
+  { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); w->cu_count = std::max(prop.multiProcessorCount, 1); }  // (the one query)
   int lanes = 64; const int LDS_MAX = 160 * 1024;
   if (const char* ml = getenv("DG_MAX_LANES")) { const int v = atoi(ml); if (v == 32 || v == 16 || v == 8 || v == 4 || v == 1) lanes = v; }
   // all-dense scenes (every row indexed by global DoF, no register-chain body) can put spare lanes to work in the
@@ -178,8 +182,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // 16 links, or a contact budget above 12) at a batch that gives every SIMD at most one such wavefront -- every row of the
   // scene then sits in registers (pgs_wave_env) and four times as many SIMDs work.  (from_the_readme at 1 024 envs: 5.6 -> 3.8 ms.)
   if (sliceable && lanes > 1 && !getenv("DG_MAX_LANES") && !getenv("DG_NO_NARROW_MODES") && !getenv("DG_NO_WAVE_ENV") && nt <= 32 && nl <= 32 && maxc <= 32 && (nl > 16 || maxc > 12) && total * 4 <= LDS_MAX) {
-    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (num_envs <= 4 * prop.multiProcessorCount) lanes = 1;
+    if (num_envs <= 4 * w->cu_count) lanes = 1;
   }
   if (lanes == 1 && !(sliceable && nt <= 32 && nl <= 32 && maxc <= 32)) lanes = 4;  // (DG_MAX_LANES=1 on a scene the mode does not hold)
   if (sliceable && lanes == 1) min_lanes = 1;  // (asked for with DG_MAX_LANES=1, or picked above)
@@ -187,8 +190,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // Latency: a big batch of a sliceable scene that still leaves most SIMDs without a wavefront (fewer than two
   // workgroups per CU) is cut into smaller workgroups -- the sweeps get more lanes per env, the rest loses nothing.
   if (sliceable && lanes >= min_lanes && num_envs >= 2048 && !getenv("DG_MAX_LANES") && !getenv("DG_NO_NARROW_MODES")) {
-    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    while (lanes > 8 && (num_envs + lanes - 1) / lanes < 2 * prop.multiProcessorCount) lanes >>= 1;
+    while (lanes > 8 && (num_envs + lanes - 1) / lanes < 2 * w->cu_count) lanes >>= 1;
   }
   if (lanes < min_lanes) {
     // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer
@@ -202,6 +204,8 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     { const int per = envs_per_wave(lanes); const size_t blocks = ((size_t)num_envs + per - 1) / per;  // [workgroup][slot][lane]
       HIP_TRY(hipMalloc((void**)&w->d_gws, sizeof(float) * blocks * (size_t)total * (size_t)per)); }
   }
+  w->render_diag = (getenv("DG_RENDER_NO_CULL") ? 1 : 0) | (getenv("DG_RENDER_DIAG") ? atoi(getenv("DG_RENDER_DIAG")) : 0);
+  if (const char* e = getenv("DG_RENDER_WPE")) w->render_wpe = atoi(e) == 3 ? 3 : 2;
   w->lanes = lanes; w->lds_bytes = lanes > 0 ? total * lanes * 4 : (lanes < 0 ? (3 * maxc + 3 * nl) * 16 * 4 : 0);
   // ---- device tables (floats converted once)
   std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
@@ -486,15 +490,19 @@ int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* 
   // whole launch -- with >= 1024 envs one workgroup renders a whole image.
   const int W = ci[DG_CI_WIDTH], H = ci[DG_CI_HEIGHT];
   int band_rows;
-  { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, w->device));
-    const int want_blocks = 4 * std::max(prop.multiProcessorCount, 1), bands_per_env = std::max(1, (want_blocks + w->num_envs - 1) / w->num_envs);
+  { const int want_blocks = 4 * std::max(w->cu_count, 1), bands_per_env = std::max(1, (want_blocks + w->num_envs - 1) / w->num_envs);
     band_rows = std::max(8, ((H + bands_per_env - 1) / bands_per_env + 7) / 8 * 8); }
   band_rows = std::min(band_rows, H);
   const int nbands = (H + band_rows - 1) / band_rows;
   const long long blocks = (long long)nbands * w->num_envs;  // the env index is folded into grid.x (grid.y stops at 65535)
   if (blocks > 0x7fffffffLL) return fail(DG_ERR_UNSUPPORTED, "render: %lld workgroups exceed the grid limit", blocks);
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
-                     (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, (getenv("DG_RENDER_NO_CULL") ? 1 : 0) | (getenv("DG_RENDER_DIAG") ? atoi(getenv("DG_RENDER_DIAG")) : 0));
+  if (w->render_wpe == 3) {
+    hipLaunchKernelGGL(render_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+                     (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, w->render_diag);
+  } else {
+    hipLaunchKernelGGL(render_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+                     (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, w->render_diag);
+  }
   HIP_TRY(hipGetLastError());
   return DG_OK;
 }
@@ -531,6 +539,12 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
   DG_ON_DEVICE(w->device);
   launch_table(w->lanes).frame(grid_of(w), w->lds_bytes, (hipStream_t)stream, w->sc, w->mt, const_cast<float*>(state), body, gf, com, out, w->d_gws);
   HIP_TRY(hipGetLastError());
+  return DG_OK;
+}
+
+int32_t dg_world_set_render_diag(dg_world* w, int32_t flags) {
+  if (!w) return fail(DG_ERR_ARG, "null argument");
+  w->render_diag = flags;
   return DG_OK;
 }
 

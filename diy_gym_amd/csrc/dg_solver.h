@@ -2392,19 +2392,52 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
 // world frame, about the base origin) and -- for a frame on a movable link -- the torques of the joints between that link
 // and the base (J^T of the wrench).  POSE of the body must be current.  The compiled ops (external_force, propellor) and
 // the C-ABI entry dg_world_apply_wrench (user addons written in Python) share this function, bit for bit.
+// (Context-free copies of the quaternion helpers: with contraction off inside them their results do not depend on what the
+// compiler finds around the call once it is inlined -- see apply_frame_wrench.)
+DGD Q4 qmul_x(Q4 a, Q4 b) {
+#pragma clang fp contract(off)
+  Q4 r = {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+  return r;
+}
+DGD Q4 qnormalize_x(Q4 a) {
+#pragma clang fp contract(off)
+  const float n = __frsqrt_rn(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  Q4 r = {a.x * n, a.y * n, a.z * n, a.w * n};
+  return r;
+}
+DGD M3 qmat_x(Q4 q) {
+#pragma clang fp contract(off)
+  const float n = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, s = n > 0.f ? 2.0f * __frcp_rn(n) : 0.f;
+  const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  M3 R = {{1.f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.f - (xx + yy)}};
+  return R;
+}
+DGD V3 mulx(const M3& R, V3 v) {
+#pragma clang fp contract(off)
+  return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
 template <int LANES>
 DGD void apply_frame_wrench(const Lane<LANES>& ln, int b, int fr, V3 f, V3 pos, V3 t, bool link_frame) {
-  // Every product and sum below is rounded on its own (no fused multiply-add): inlined into the step kernel the compiled
-  // ops pass literal zeros, and a compiler free to contract would fuse e.g. `r x F + R t` differently there than in
-  // wrench_kernel, where the same vectors arrive from memory.  With contraction off the two are the same bits.
+  // Every product and sum below is rounded on its own (no fused multiply-add), and the pose of a frame that is rigidly
+  // attached to the base comes straight from the state through the context-free helpers above: inlined into the step
+  // kernel the compiled ops pass literal zeros and sit among other arithmetic, and a compiler free to contract would fuse
+  // e.g. `r x F + R t` differently there than in wrench_kernel, where the same vectors arrive from memory.  This way the
+  // two are the same bits (tests/test_environment_gpu.py::test_python_hook_addon_equals_the_compiled_propellor_bit_for_bit).
 #pragma clang fp contract(off)
   const DevScene& sc = ln.sc;
+  const int gl = fr < 0 ? -1 : sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK];
   V3 F = f, T = t, P = pos;
   if (link_frame) {
-    V3 fp, fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); const M3 R = qmat(fq);
-    F = v3(R.m[0] * f.x + R.m[1] * f.y + R.m[2] * f.z, R.m[3] * f.x + R.m[4] * f.y + R.m[5] * f.z, R.m[6] * f.x + R.m[7] * f.y + R.m[8] * f.z);
-    T = v3(R.m[0] * t.x + R.m[1] * t.y + R.m[2] * t.z, R.m[3] * t.x + R.m[4] * t.y + R.m[5] * t.z, R.m[6] * t.x + R.m[7] * t.y + R.m[8] * t.z);
-    P = v3(fp.x + (R.m[0] * pos.x + R.m[1] * pos.y + R.m[2] * pos.z), fp.y + (R.m[3] * pos.x + R.m[4] * pos.y + R.m[5] * pos.z), fp.z + (R.m[6] * pos.x + R.m[7] * pos.y + R.m[8] * pos.z));
+    V3 fp; M3 R;
+    if (gl < 0) {  // on the base: pose from the state
+      const Q4 qb = ln.base_quat(b); const V3 pb = ln.base_pos(b); V3 off = v3(0.f, 0.f, 0.f); Q4 qo = {0.f, 0.f, 0.f, 1.f};
+      if (fr >= 0) { cfp ff = sc.FF + fr * DG_FF_STRIDE + DG_FF_POS; off = v3(ff[0], ff[1], ff[2]); Q4 tq = {ff[3], ff[4], ff[5], ff[6]}; qo = tq; }
+      const V3 ro = mulx(qmat_x(qb), off); fp = v3(pb.x + ro.x, pb.y + ro.y, pb.z + ro.z); R = qmat_x(qnormalize_x(qmul_x(qb, qo)));
+    } else { V3 fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); R = qmat_x(fq); }
+    F = mulx(R, f); T = mulx(R, t);
+    const V3 rp = mulx(R, pos); P = v3(fp.x + rp.x, fp.y + rp.y, fp.z + rp.z);
   }
   if (!ln.fixed(b)) {
     const V3 bp = ln.base_pos(b), r = v3(P.x - bp.x, P.y - bp.y, P.z - bp.z);
@@ -2412,7 +2445,7 @@ DGD void apply_frame_wrench(const Lane<LANES>& ln, int b, int fr, V3 f, V3 pos, 
     ln.Sset(eo, ln.S(eo) + F.x); ln.Sset(eo + 1, ln.S(eo + 1) + F.y); ln.Sset(eo + 2, ln.S(eo + 2) + F.z);
     ln.Sset(eo + 3, ln.S(eo + 3) + tq.x); ln.Sset(eo + 4, ln.S(eo + 4) + tq.y); ln.Sset(eo + 5, ln.S(eo + 5) + tq.z);
   }
-  for (int k = fr < 0 ? -1 : sc.FI[fr * DG_FI_STRIDE + DG_FI_LINK]; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
+  for (int k = gl; k >= 0; k = ln.li(k)[DG_LI_PARENT]) {
     const int po = ln.pll(k)[PLL_POSE], lo = ln.li(k)[DG_LI_STATE_OFF]; cfp lf = ln.lf(k);
     const M3 Rk = ln.LR(po); const V3 pk = ln.L3(po + 6), a = v3(lf[DG_LF_AXIS], lf[DG_LF_AXIS + 1], lf[DG_LF_AXIS + 2]);
     const V3 axw = v3(Rk.m[0] * a.x + Rk.m[1] * a.y + Rk.m[2] * a.z, Rk.m[3] * a.x + Rk.m[4] * a.y + Rk.m[5] * a.z, Rk.m[6] * a.x + Rk.m[7] * a.y + Rk.m[8] * a.z);

@@ -136,17 +136,18 @@ def test_gripper_camera_at_the_baseline_batch_1024_envs_200x200():
         seg = first['segmentation_mask']
         assert int(seg.min()) >= -1 and int((seg[seg >= 0] & 0xFFFFFF).max() if (seg >= 0).any() else 0) < n_bodies
     # the cone culling must not change a single pixel: render again with every shape tested for every pixel group
-    os.environ['DG_RENDER_NO_CULL'] = '1'
     try:
         for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
             cam = env.receptors[rec].addons[name]
             culled = {k: v.clone() for k, v in cam.observe().items()}
             env._tick += 1
+            env.sim.set_render_diag(1)
             brute = cam.observe()
+            env.sim.set_render_diag(0); env._tick += 1
             for k in culled:
                 assert torch.equal(culled[k], brute[k]), (name, k)
     finally:
-        del os.environ['DG_RENDER_NO_CULL']
+        env.sim.set_render_diag(0)
     env._tick += 1
     seen = (env.receptors['from_the_readme'].addons['overview'].observe()['segmentation_mask'] >= 0).float().mean()
     assert float(seen) > 0.3   # the overview camera does see the table, the arm and R2D2

@@ -22,7 +22,7 @@ for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
     cam = env.receptors[rec].addons[name]; cam.observe(); rgb, depth, seg = cam._buffers
     for label, args in (('rgb+depth', (rgb, depth, None)), ('depth only', (None, depth, None))):
         for diag in os.environ.get('DIAGS', '0').split(','):
-            os.environ['DG_RENDER_DIAG'] = diag
+            env.sim.set_render_diag(int(diag))
             ms = t(lambda: env.sim.render(cam.camera_index, *args))
             nbytes = B * 200 * 200 * (16 if args[0] is not None else 4)
             print('%-10s %-10s diag %s: pose+render %.3f ms -> %.0f GB/s of image writes' % (name, label, diag, ms, nbytes / ms / 1e6), flush=True)
@@ -32,7 +32,7 @@ import ctypes
 lib = env.sim.lib
 lib.dg_debug_render_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]
 buf = (ctypes.c_uint64 * 16)()
-os.environ['DG_RENDER_DIAG'] = '16'
+env.sim.set_render_diag(16)
 for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
     cam = env.receptors[rec].addons[name]; rgb, depth, seg = cam._buffers
     lib.dg_debug_render_counters(buf, 1)

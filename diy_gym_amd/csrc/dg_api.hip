@@ -205,7 +205,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       HIP_TRY(hipMalloc((void**)&w->d_gws, sizeof(float) * blocks * (size_t)total * (size_t)per)); }
   }
   w->render_diag = (getenv("DG_RENDER_NO_CULL") ? 1 : 0) | (getenv("DG_RENDER_DIAG") ? atoi(getenv("DG_RENDER_DIAG")) : 0);
-  if (const char* e = getenv("DG_RENDER_WPE")) w->render_wpe = atoi(e) == 3 ? 3 : 2;
+  if (const char* e = getenv("DG_RENDER_WPE")) { const int v = atoi(e); w->render_wpe = (v == 3 || v == 1) ? v : 2; }
   w->lanes = lanes; w->lds_bytes = lanes > 0 ? total * lanes * 4 : (lanes < 0 ? (3 * maxc + 3 * nl) * 16 * 4 : 0);
   // ---- device tables (floats converted once)
   std::vector<float> Ff((size_t)n_f); for (int64_t k = 0; k < n_f; k++) Ff[(size_t)k] = (float)F[k];
@@ -291,7 +291,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
-  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.warm_off = I[DG_H_WARM_OFF]; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
+  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.warm_off = I[DG_H_WARM_OFF]; sc.debug_keep_ext = getenv("DG_DEBUG_KEEP_EXT") ? 1 : 0; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
   sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail; sc.nt = nt; sc.dense = dense ? 1 : 0; sc.dv_base = nb > 0 ? PLB[PLB_DV] : 0;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   // bodies whose solver rows are held in registers by the step kernel
@@ -496,7 +496,10 @@ int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* 
   const int nbands = (H + band_rows - 1) / band_rows;
   const long long blocks = (long long)nbands * w->num_envs;  // the env index is folded into grid.x (grid.y stops at 65535)
   if (blocks > 0x7fffffffLL) return fail(DG_ERR_UNSUPPORTED, "render: %lld workgroups exceed the grid limit", blocks);
-  if (w->render_wpe == 3) {
+  if (w->render_wpe == 1) {
+    hipLaunchKernelGGL(render_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
+                     (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, w->render_diag);
+  } else if (w->render_wpe == 3) {
     hipLaunchKernelGGL(render_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->sc, w->d_CI, w->d_CF, w->d_PLN, camera, w->ncam,
                      (cfp)w->d_render_table, rgb, depth, seg, band_rows, nbands, w->render_diag);
   } else {

@@ -54,13 +54,17 @@ __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, fl
   }
 }
 
-struct RayHit { float t; V3 n; int shape; };
+// Near plane: a surface the ray ENTERS nearer than tmin (= the camera's near distance; t is eye-space depth, the rays have
+// z = -1) neither shows nor hides anything -- what clipping at the near plane does in a rasteriser.  In particular the link a
+// camera is mounted on (its eye sits ON a face of that link's hull, at t = +-1 ulp) cannot blank the picture, whichever
+// way the last bit falls.
+struct RayHit { float t; V3 n; int shape; float tmin; };
 
 DGD void ray_sphere(V3 o, V3 d, V3 c, float r, RayHit& h, int sh) {
   const V3 oc = o - c; const float a = dot(d, d), b = dot(oc, d), cc = dot(oc, oc) - r * r, disc = b * b - a * cc;
   if (disc < 0.f) return;
   const float t = fdiv(-b - sqrtf(disc), a);
-  if (t > 0.f && t < h.t) { h.t = t; h.n = ((o + d * t) - c) * __frcp_rn(r); h.shape = sh; }
+  if (t >= h.tmin && t < h.t) { h.t = t; h.n = ((o + d * t) - c) * __frcp_rn(r); h.shape = sh; }
 }
 DGD void ray_box(V3 o, V3 d, const M3& R, V3 p, float hx, float hy, float hz, RayHit& h, int sh) {
   const V3 ol = tmul(R, o - p), dl = tmul(R, d);
@@ -76,7 +80,7 @@ DGD void ray_box(V3 o, V3 d, const M3& R, V3 p, float hx, float hy, float hz, Ra
       tf = fminf(tf, t2);
     }
   }
-  if (tn > tf || tn <= 0.f || tn >= h.t) return;
+  if (tn > tf || tn < h.tmin || tn >= h.t) return;
   h.t = tn; h.n = mul(R, v3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f)); h.shape = sh;
 }
 DGD void ray_capsule(V3 o, V3 d, V3 e0, V3 e1, float r, RayHit& h, int sh) {
@@ -86,7 +90,7 @@ DGD void ray_capsule(V3 o, V3 d, V3 e0, V3 e1, float r, RayHit& h, int sh) {
     const float iL2 = __frcp_rn(L2); const float a = dot(d, d) - dax * dax * iL2, b = dot(oc, d) - oax * dax * iL2, c = dot(oc, oc) - oax * oax * iL2 - r * r, disc = b * b - a * c;
     if (a > 1e-24f && disc >= 0.f) {
       const float t = fdiv(-b - sqrtf(disc), a), s = (oax + t * dax) * iL2;
-      if (t > 0.f && t < h.t && s >= 0.f && s <= 1.f) { h.t = t; h.n = ((o + d * t) - (e0 + ax * s)) * __frcp_rn(r); h.shape = sh; }
+      if (t >= h.tmin && t < h.t && s >= 0.f && s <= 1.f) { h.t = t; h.n = ((o + d * t) - (e0 + ax * s)) * __frcp_rn(r); h.shape = sh; }
     }
   }
   ray_sphere(o, d, e0, r, h, sh); ray_sphere(o, d, e1, r, h, sh);
@@ -99,7 +103,7 @@ DGD void ray_hull(V3 o, V3 d, const M3& Rl, V3 pl, cfp planes, int np, RayHit& h
     if (fabsf(den) < 1e-30f) { if (dist > 0.f) miss = true; }
     else { const float t = -dist * __frcp_rn(den); if (den < 0.f) { if (t > tn) { tn = t; nn = n; } } else tf = fminf(tf, t); }
   }
-  if (miss || tn > tf || tn <= 0.f || tn >= h.t) return;
+  if (miss || tn > tf || tn < h.tmin || tn >= h.t) return;
   h.t = tn; h.n = mul(Rl, nn); h.shape = sh;
 }
 
@@ -155,7 +159,7 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
   }
   bool alive[2];
 #pragma unroll
-  for (int u = 0; u < 2; u++) alive[u] = !miss[u] && tn[u] > 0.f && tn[u] < h[u].t;
+  for (int u = 0; u < 2; u++) alive[u] = !miss[u] && tn[u] >= h[u].tmin && tn[u] < h[u].t;
   if (!__any(alive[0] || alive[1])) return;
   for (int k = nout; k < np; k++) {
     const float nx = pl[k][0], ny = pl[k][1], nz = pl[k][2], dist = pl[k][3];
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       px[u].inside = prow < qn && pcol < W;
       px[u].row = q0 + min(prow, qn - 1); px[u].col = min(pcol, W - 1);
       px[u].d = ray(px[u].col + 0.5f, px[u].row + 0.5f); px[u].idd = __frcp_rn(dot(px[u].d, px[u].d));
-      px[u].h.t = zf; px[u].h.shape = -1; px[u].h.n = v3(0.f, 0.f, 1.f);
+      px[u].h.t = zf; px[u].h.shape = -1; px[u].h.n = v3(0.f, 0.f, 1.f); px[u].h.tmin = (diag & 32) ? 1e-30f : zn;
     }
     for (int base = 0; base < n_entries; base += 64) {
       const int j = min(base + lane, n_entries - 1);

@@ -2116,6 +2116,7 @@ DGD void sim_step(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, fl
   const DevScene& sc = ln.sc;
   for (int k = 0; k < sc.substeps; k++) { substep<LANES, PROF, PAR, SLICED, FULLWAVE>(ln, diag_out, prof, smem, gws, k); prof.stamp(PS_INTEGRATE); }
   if (SLICED && (int)threadIdx.x >= envs_per_wave(LANES)) return;
+  if (sc.debug_keep_ext) return;
   for (int b = 0; b < sc.nba; b++) { if (ln.frozen(b)) continue; const int eo = ln.ext_off(b); for (int k = 0; k < 6; k++) ln.Sset(eo + k, 0.f); }
   for (int gl = 0; gl < sc.nl; gl++) ln.Sset(ln.li(gl)[DG_LI_STATE_OFF] + DG_LS_TORQUE, 0.f);
 }

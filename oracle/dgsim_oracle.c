@@ -1397,12 +1397,15 @@ int dgo_step(dgo_world* w, const real* actions, uint64_t update_mask, real* obs,
  * formula (:82-85) returns the eye-space z of the nearest surface (negative; -far where nothing is hit).
  * pybullet's DIRECT-mode renderer draws the VISUAL meshes with lighting; this restatement ray-casts the
  * collision geometry, so rgb is not a parity quantity. */
-typedef struct { real t; v3 n; int shape; } RayHit;
+/* Near plane: a surface the ray ENTERS nearer than `tmin` (= the camera's near distance; t is eye-space depth, the rays
+ * have z = -1) neither shows nor hides anything -- what clipping at the near plane does in a rasteriser.  In particular
+ * the link a camera is mounted on (its eye sits ON a face of that link's hull, at t = +-1 ulp) cannot blank the picture. */
+typedef struct { real t; v3 n; int shape; real tmin; } RayHit;
 static void ray_sphere(v3 o, v3 d, v3 c, real r, RayHit* h, int sh) {
   v3 oc = vsub(o, c); real a = vdot(d, d), b = vdot(oc, d), cc = vdot(oc, oc) - r * r, disc = b * b - a * cc;
   if (disc < 0) return;
   real t = (-b - sqrt(disc)) / a;
-  if (t > 0 && t < h->t) { h->t = t; h->n = vscale(vsub(vadd(o, vscale(d, t)), c), 1.0 / r); h->shape = sh; }
+  if (t >= h->tmin && t < h->t) { h->t = t; h->n = vscale(vsub(vadd(o, vscale(d, t)), c), 1.0 / r); h->shape = sh; }
 }
 static void ray_slabs(v3 o, v3 d, const real* hx, real* tn, real* tf, int* axis, real* sgn) {
   real oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}; *tn = -HUGE_R; *tf = HUGE_R; *axis = 0; *sgn = 1;
@@ -1417,7 +1420,7 @@ static void ray_slabs(v3 o, v3 d, const real* hx, real* tn, real* tf, int* axis,
 static void ray_box(v3 o, v3 d, const m3* R, v3 p, const real* hx, RayHit* h, int sh) {
   v3 ol = mtv(R, vsub(o, p)), dl = mtv(R, d); real tn, tf, sg; int ax;
   ray_slabs(ol, dl, hx, &tn, &tf, &ax, &sg);
-  if (tn > tf || tn <= 0 || tn >= h->t) return;
+  if (tn > tf || tn < h->tmin || tn >= h->t) return;
   v3 nl = V(ax == 0 ? sg : 0, ax == 1 ? sg : 0, ax == 2 ? sg : 0);
   h->t = tn; h->n = mv(R, nl); h->shape = sh;
 }
@@ -1428,7 +1431,7 @@ static void ray_capsule(v3 o, v3 d, v3 e0, v3 e1, real r, RayHit* h, int sh) {
     real a = vdot(d, d) - dax * dax / L2, b = vdot(oc, d) - oax * dax / L2, c = vdot(oc, oc) - oax * oax / L2 - r * r, disc = b * b - a * c;
     if (a > 1e-24 && disc >= 0) {
       real t = (-b - sqrt(disc)) / a, s = (oax + t * dax) / L2;
-      if (t > 0 && t < h->t && s >= 0 && s <= 1) {
+      if (t >= h->tmin && t < h->t && s >= 0 && s <= 1) {
         v3 pt = vadd(o, vscale(d, t)); v3 q = vadd(e0, vscale(ax, s));
         h->t = t; h->n = vscale(vsub(pt, q), 1.0 / r); h->shape = sh;
       }
@@ -1445,7 +1448,7 @@ static void ray_hull(v3 o, v3 d, const m3* Rl, v3 pl, const real* planes, int np
     real t = -dist / den;
     if (den < 0) { if (t > tn) { tn = t; nn = n; } } else if (t < tf) tf = t;
   }
-  if (np == 0 || tn > tf || tn <= 0 || tn >= h->t) return;
+  if (np == 0 || tn > tf || tn < h->tmin || tn >= h->t) return;
   h->t = tn; h->n = mv(Rl, nn); h->shape = sh;
 }
 int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* seg) {
@@ -1473,7 +1476,7 @@ int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* se
     for (int row = 0; row < Hh; row++) for (int col = 0; col < W; col++) {
       const real xn = ((col + 0.5) / W) * 2.0 - 1.0, yn = 1.0 - ((row + 0.5) / Hh) * 2.0;
       v3 d = mv(&Rc, V(xn * tanh2 * aspect, yn * tanh2, -1.0));
-      RayHit h; h.t = zf; h.shape = -1; h.n = V(0, 0, 1);
+      RayHit h; h.t = zf; h.shape = -1; h.n = V(0, 0, 1); h.tmin = zn;
       for (int k = 0; k < s->nsh; k++) {
         const WShape* a = &shp[k]; const int32_t* si = s->SI + k * DG_SI_STRIDE;
         if (a->type == DG_SHAPE_SPHERE) ray_sphere(pc, d, a->p, a->prm[0], &h, k);
@@ -1481,7 +1484,7 @@ int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* se
         else if (a->type == DG_SHAPE_CAPSULE) { v3 e0, e1; seg_ends(a, &e0, &e1); ray_capsule(pc, d, e0, e1, a->prm[0], &h, k); }
         else ray_hull(pc, d, &a->Rl, a->pl, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], &h, k);
       }
-      const int hit = h.shape >= 0 && h.t >= zn; const size_t px = (size_t)e * W * Hh + (size_t)row * W + col;
+      const int hit = h.shape >= 0; const size_t px = (size_t)e * W * Hh + (size_t)row * W + col;
       if (depth) depth[px] = hit ? -h.t : -zf;
       if (seg) {
         if (!hit) seg[px] = -1;

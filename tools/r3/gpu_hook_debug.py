@@ -34,3 +34,38 @@ for step in range(3):
     rows = torch.nonzero(d.max(1).values > 0).flatten().tolist()
     print('step', step, 'rows that differ', rows, 'max', float(d.max()), 'body state off', so, 'ext_h env0', ext_h[:, 0].tolist())
     print('   rotor speeds compiled', c.sim.state[c.layout.addon_off:c.layout.addon_off + 4, 0].tolist(), 'hooked', [float(h.receptors['drone'].addons[m].rotor_speed[0]) for m in motors])
+
+# ---- what the compiled ops applied, made visible: DG_DEBUG_KEEP_EXT leaves the external wrench in the state after a step
+os.environ['DG_DEBUG_KEEP_EXT'] = '1'
+c2, h2 = make('propellor'), make('py_propellor')
+del os.environ['DG_DEBUG_KEEP_EXT']
+st = np.array(c2.sim.get_state()); so = c2.layout.body_state_off[[i for i in range(c2.layout.n_bodies) if not c2.layout.body_fixed[i]][0]]
+rng = np.random.default_rng(0); q = rng.normal(size=(B, 4)) * float(os.environ.get('TILT', '0.2')) + np.array([0, 0, 0, 1.0]); q /= np.linalg.norm(q, axis=1, keepdims=True)
+st[:, so + 3:so + 7] = q; st[:, so:so + 3] += rng.normal(size=(B, 3)) * 0.3
+sh = np.array(h2.sim.get_state()); sh[:, :c2.layout.addon_off] = st[:, :c2.layout.addon_off]
+c2.sim.set_state(st); h2.sim.set_state(sh)
+act = {'drone': {m: torch.rand((B, 1), generator=gen).to('cuda:0') for m in motors}}
+c2.step(act)
+for m in motors: h2.receptors['drone'].addons[m].update(act['drone'][m])
+ec = c2.sim.state[so + 13:so + 19, :B]; eh = h2.sim.state[so + 13:so + 19, :B]
+print('ext wrench rows equal:', [bool(torch.equal(ec[k], eh[k])) for k in range(6)], 'max abs diff', float((ec - eh).abs().max()), 'max', float(ec.abs().max()))
+bad = (ec != eh).any(0).nonzero().flatten()[:3].tolist()
+for e in bad: print('  env', e, 'compiled', ec[:, e].tolist(), 'hooked', eh[:, e].tolist())
+
+# ---- the real rollout with the external wrench left in the state (it accumulates: same for both)
+os.environ['DG_DEBUG_KEEP_EXT'] = '1'
+c3, h3 = make('propellor'), make('py_propellor')
+del os.environ['DG_DEBUG_KEEP_EXT']
+gen = torch.Generator().manual_seed(1)
+for step in range(4):
+    act = {'drone': {m: torch.rand((B, 1), generator=gen).to('cuda:0') for m in motors}}
+    pre_c = c3.sim.state[so:so + 13, :B].clone(); pre_h = h3.sim.state[so:so + 13, :B].clone()
+    c3.step(act)
+    for m in motors: h3.receptors['drone'].addons[m].update(act['drone'][m])
+    eh = h3.sim.state[so + 13:so + 19, :B].clone()
+    h3.sim.step(0)
+    ec = c3.sim.state[so + 13:so + 19, :B]
+    print('rollout step', step, 'pre-state equal', bool(torch.equal(pre_c, pre_h)), 'ext equal', [bool(torch.equal(ec[k], eh[k])) for k in range(6)], 'post-state equal', bool(torch.equal(c3.sim.state[so:so + 13, :B], h3.sim.state[so:so + 13, :B])),
+          'warm caches equal', bool(torch.equal(c3.sim.state[c3.layout.warm_off:, :B], h3.sim.state[h3.layout.warm_off:, :B])))
+    if not torch.equal(ec, eh):
+        e = int((ec != eh).any(0).nonzero()[0]); print('   env', e, 'compiled ext', ec[:, e].tolist(), 'hooked', eh[:, e].tolist(), 'quat', pre_c[3:7, e].tolist())

@@ -2415,6 +2415,14 @@ DGD M3 qmat_x(Q4 q) {
   M3 R = {{1.f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.f - (xx + yy)}};
   return R;
 }
+DGD float spool_up(float w, float a, float k) {  // w + (a - w) k, every operation rounded on its own
+#pragma clang fp contract(off)
+  const float d = a - w; const float p = d * k; return w + p;
+}
+DGD float mul_sep(float a, float b) {  // a product that no later addition may absorb into an FMA
+#pragma clang fp contract(off)
+  const float p = a * b; return p;
+}
 DGD V3 mulx(const M3& R, V3 v) {
 #pragma clang fp contract(off)
   return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
@@ -2532,10 +2540,11 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
       apply_frame_wrench(ln, b, -1, v3(a[0], a[1], a[2]), v3(of[0], of[1], of[2]), v3(0.f, 0.f, 0.f), false);
     } else if (code == DG_OP_PROPELLOR) {  // drone_pilot.py:31-37: thrust along and torque about the motor frame's z, LINK_FRAME
       const int b = oi[DG_OI_BODY], so = sc.addon_off + oi[DG_OI_STATE_OFF];
-      // (separately rounded product and sum: a user addon doing the same two steps with torch gets the same bits)
-      float w = ln.S(so); w = __fadd_rn(w, __fmul_rn(a[0] - w, of[2])); ln.Sset(so, w);
+      // (separately rounded difference, product and sum -- spool_up() -- so that a user addon doing the same three steps with
+      // torch gets the same bits; HIP's __fadd_rn / __fmul_rn are plain operators and contract into an FMA like any other)
+      const float w = spool_up(ln.S(so), a[0], of[2]); ln.Sset(so, w);
       if (ln.fixed(b)) continue;
-      apply_frame_wrench(ln, b, oi[DG_OI_FRAME], v3(0.f, 0.f, __fmul_rn(of[0], w)), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, __fmul_rn(of[1], w)), true);
+      apply_frame_wrench(ln, b, oi[DG_OI_FRAME], v3(0.f, 0.f, mul_sep(of[0], w)), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, mul_sep(of[1], w)), true);
     }
   }
 }

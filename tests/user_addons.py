@@ -30,10 +30,13 @@ class PyPropellor(Addon):
             a = a.expand(sim.num_envs)
         if self.rotor_speed is None:
             self.rotor_speed = torch.zeros(sim.num_envs, dtype=torch.float32, device=sim.device)
-        self.rotor_speed = self.rotor_speed + (a - self.rotor_speed) * self.spool_up_rate
+            # (the constants as fp32 tensors: a Python float operand is a double, and which precision the product with it is
+            # rounded in is the framework's business -- this way it is one fp32 multiply, like the compiled op's)
+            self._k, self._thrust, self._torque = (torch.tensor(v, dtype=torch.float32, device=sim.device) for v in (self.spool_up_rate, self.max_thrust, self.max_torque))
+        self.rotor_speed = self.rotor_speed + (a - self.rotor_speed) * self._k
         zero = torch.zeros_like(self.rotor_speed)
-        force = torch.stack([zero, zero, self.max_thrust * self.rotor_speed], dim=1)
-        torque = torch.stack([zero, zero, self.max_torque * self.rotor_speed], dim=1)
+        force = torch.stack([zero, zero, self._thrust * self.rotor_speed], dim=1)
+        torque = torch.stack([zero, zero, self._torque * self.rotor_speed], dim=1)
         if self.one_call:
             sim.apply_external_wrench(self.uid, self.frame_id, force, [0.0, 0.0, 0.0], torque, sim.LINK_FRAME)
         else:

@@ -69,3 +69,26 @@ for step in range(4):
           'warm caches equal', bool(torch.equal(c3.sim.state[c3.layout.warm_off:, :B], h3.sim.state[h3.layout.warm_off:, :B])))
     if not torch.equal(ec, eh):
         e = int((ec != eh).any(0).nonzero()[0]); print('   env', e, 'compiled ext', ec[:, e].tolist(), 'hooked', eh[:, e].tolist(), 'quat', pre_c[3:7, e].tolist())
+
+# ---- replicate rollout step 1 in fresh worlds and drop motors one at a time
+os.environ['DG_DEBUG_KEEP_EXT'] = '1'
+c4, h4 = make('propellor'), make('py_propellor')
+del os.environ['DG_DEBUG_KEEP_EXT']
+gen = torch.Generator().manual_seed(1)
+acts = [{'drone': {m: torch.rand((B, 1), generator=gen).to('cuda:0') for m in motors}} for _ in range(2)]
+c4.step(acts[0]); h4.step(acts[0])
+base_c = np.array(c4.sim.get_state()); base_h = np.array(h4.sim.get_state()); w_h = [h4.receptors['drone'].addons[m].rotor_speed.clone() for m in motors]
+print('after step 0: drone rows equal', np.array_equal(base_c[:, so:so + 13], base_h[:, so:so + 13]))
+for keep in ([0, 1, 2, 3], [0], [1], [2], [3], [0, 1], [2, 3]):
+    sc_ = base_c.copy(); sh_ = base_h.copy(); sc_[:, so + 13:so + 19] = 0; sh_[:, so + 13:so + 19] = 0
+    c4.sim.set_state(sc_); h4.sim.set_state(sh_)
+    for i, m in enumerate(motors): h4.receptors['drone'].addons[m].rotor_speed = w_h[i].clone()
+    a = {'drone': {m: acts[1]['drone'][m] for i, m in enumerate(motors) if i in keep}}
+    c4.step(a)
+    for i, m in enumerate(motors):
+        if i in keep: h4.receptors['drone'].addons[m].update(a['drone'][m])
+    ec = c4.sim.state[so + 13:so + 19, :B]; eh = h4.sim.state[so + 13:so + 19, :B]
+    nbad = int((ec != eh).any(0).sum())
+    print('motors', keep, 'ext rows equal', [bool(torch.equal(ec[k], eh[k])) for k in range(6)], 'envs that differ', nbad)
+    if nbad:
+        e = int((ec != eh).any(0).nonzero()[0]); print('    env', e, 'compiled', ec[:, e].tolist(), 'hooked', eh[:, e].tolist())

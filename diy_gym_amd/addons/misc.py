@@ -95,20 +95,25 @@ class VisualRandomizer(Addon):
     """A new look for the parent model at every reset (reference: diy_gym/addons/misc/visual_randomizer.py:14-46).
 
     The reference picks a random TEXTURE of the "describable textures" data set for every link (``p.loadTexture`` /
-    ``p.changeVisualShape``) and downloads the 600 MB data set over HTTP when it is missing (:48-77).  Neither the data
-    set nor textured rendering exists here (the camera's ``rgb`` is flat-shaded collision geometry): what this
-    addon randomises is the model's flat colour -- one rgb in [0, 1]^3 per env and episode from the per-env
-    counter-based stream, drawn at construction and at every reset like the reference does, visible in the camera
-    addon's ``rgb`` only.  Depth and segmentation are unaffected."""
+    ``p.changeVisualShape``) and downloads the 600 MB data set over HTTP when it is missing (:48-77).  The data set is
+    out of scope; what is randomised here is a PROCEDURAL texture of the model -- two colours, a frequency and a pattern
+    (checker, stripes or per-cell blends, ``DG_TEX_*`` in diygym_scene.h) per env and episode from the per-env
+    counter-based stream, drawn at construction and at every reset like the reference does, evaluated in the shapes'
+    own frames (the pattern sticks to the object) and visible in the camera addon's ``rgb`` only.  Depth and
+    segmentation are unaffected.  Deviation: one texture per model, not one per link."""
     def __init__(self, parent, config):
         super().__init__(parent, config)
         self.uid = parent.uid
 
     def compile(self, builder):
-        self.op = builder.add_op(K.OP_RANDOMIZE_COLOR, 'reset', body=self.uid, state_dim=3)
+        self.op = builder.add_op(K.OP_RANDOMIZE_COLOR, 'reset', body=self.uid, state_dim=K.TX_STRIDE)
 
-    def colors(self):
-        """[B, 3] current colour of the model in every env (host copy)."""
+    def textures(self):
+        """[B, 8] current texture of the model in every env: colour A, colour B, frequency, kind (host copy)."""
         import torch
         o = self.env.layout.addon_off + self.op.state_off
-        return torch.as_tensor(self.env.sim.get_state()[:, o:o + 3])
+        return torch.as_tensor(self.env.sim.get_state()[:, o:o + K.TX_STRIDE])
+
+    def colors(self):
+        """[B, 3] colour A of the model's texture in every env (host copy)."""
+        return self.textures()[:, :3]

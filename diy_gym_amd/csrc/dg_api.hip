@@ -375,8 +375,10 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   }
   for (int op = 0; op < I[DG_H_N_OPS]; op++) {  // dynamics_randomizer state before its first draw: URDF masses, default damping
     const int32_t* oi = OI + op * DG_OI_STRIDE;
-    if (oi[DG_OI_CODE] == DG_OP_RANDOMIZE_COLOR) {  // visual_randomizer: the configured colour until the first draw
-      for (int k = 0; k < 3; k++) init[sc.addon_off + oi[DG_OI_STATE_OFF] + k] = (float)F[I[DG_H_OFF_BODY_F] + oi[DG_OI_BODY] * DG_BF_STRIDE + DG_BF_COLOR + k];
+    if (oi[DG_OI_CODE] == DG_OP_RANDOMIZE_COLOR) {  // visual_randomizer: the configured colour, flat, until the first draw
+      float* tx = init.data() + sc.addon_off + oi[DG_OI_STATE_OFF];
+      for (int k = 0; k < 3; k++) tx[DG_TX_A + k] = tx[DG_TX_B + k] = (float)F[I[DG_H_OFF_BODY_F] + oi[DG_OI_BODY] * DG_BF_STRIDE + DG_BF_COLOR + k];
+      tx[DG_TX_FREQ] = 1.f; tx[DG_TX_KIND] = (float)DG_TEX_FLAT;
       continue;
     }
     if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;

@@ -14,7 +14,7 @@
 
 namespace dg {
 
-enum { RS_R = 0, RS_P = 9, RS_C = 12, RS_BOUND = 15, RS_COLOR = 16 /* rgb of the owning body in this env */, RS_STRIDE = 20, RC_STRIDE = 12 };
+enum { RS_R = 0, RS_P = 9, RS_C = 12, RS_BOUND = 15, RS_COLOR = 16 /* this env's texture of the shape (DG_TX_*): colour A, colour B, frequency, kind */, RS_STRIDE = 24, RC_STRIDE = 12 };
 
 template <int LANES>
 __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws) {
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, fl
 #pragma unroll
     for (int k = 0; k < 9; k++) o[RS_R + k] = R.m[k];
     o[RS_P] = p.x; o[RS_P + 1] = p.y; o[RS_P + 2] = p.z; o[RS_C] = w.p.x; o[RS_C + 1] = w.p.y; o[RS_C + 2] = w.p.z; o[RS_BOUND] = bound;
-    { const int co = ln.bi(w.body)[DG_BI_COLOR_OFF]; cfp bc = ln.bf(w.body) + DG_BF_COLOR;  // per-env colour of a visual_randomizer, else the configured one
-      _Pragma("unroll") for (int k = 0; k < 3; k++) o[RS_COLOR + k] = co >= 0 ? ln.S(co + k) : bc[k]; }
+    { const int co = ln.bi(w.body)[DG_BI_COLOR_OFF]; cfp sc3 = sc.SF + sh * DG_SF_STRIDE + DG_SF_COLOR;  // per-env texture of a visual_randomizer, else the shape's own colour, flat
+      _Pragma("unroll") for (int k = 0; k < DG_TX_STRIDE; k++) o[RS_COLOR + k] = co >= 0 ? ln.S(co + k) : (k < 6 ? sc3[k % 3] : (k == DG_TX_FREQ ? 1.f : (float)DG_TEX_FLAT)); }
   }
   for (int c = 0; c < ncam; c++) {
     cip ci = CI + c * DG_CI_STRIDE; cfp cf = CF + c * DG_CF_STRIDE;
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       if (sh < sc.nsh) {
         cfp s = tb + sh * RS_STRIDE; v = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; Rb = s[RS_BOUND];
         pass = no_cull || cone_pass(v, Rb, baxis, bcos, bsin);
+        if ((diag & 256) && sc.SI[sh * DG_SI_STRIDE + DG_SI_BODY] == ci[DG_CI_BODY]) pass = false;  // (experiment: the camera's own body left out)
       }
       const unsigned long long m = __ballot(pass);
       if (lane == 0) s_wave_count[wv] = __popcll(m);
@@ -291,13 +292,16 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
         else { n = v3(planes[4 * k], planes[4 * k + 1], planes[4 * k + 2]); d0 = planes[4 * k + 3]; }
         dist = dot(n, ol) + d0;
       };
-      // stable partition: the faces that have the eye on their outer side (dist > 0) first, the others behind them
+      // stable partition: the faces that have the eye on their outer side first, the others behind them.  "Outer side" with
+      // the margin of the eye-inside test below: a camera mounted ON a face of its own link (from_the_readme's gripper
+      // camera) has a signed distance of +-1 ulp there, and which sign comes out must not decide whether that link hides
+      // the whole picture -- within a micrometre of a face the eye counts as behind it (fp64, the oracle, gets -0).
       int nout = 0;
-      for (int k0 = 0; k0 < np; k0 += 64) { V3 n; float dist = -1.f; if (k0 + lane < np) face(k0 + lane, n, dist); nout += __popcll(__ballot(dist > 0.f)); }
+      for (int k0 = 0; k0 < np; k0 += 64) { V3 n; float dist = -1.f; if (k0 + lane < np) face(k0 + lane, n, dist); nout += __popcll(__ballot(dist > 1e-6f)); }
       int at_out = 0, at_in = nout;
       for (int k0 = 0; k0 < np; k0 += 64) {
         const bool have = k0 + lane < np; V3 n = v3(0.f, 0.f, 1.f); float dist = -1.f; if (have) face(k0 + lane, n, dist);
-        const bool out = have && dist > 0.f, in = have && !out;
+        const bool out = have && dist > 1e-6f, in = have && !out;
         const unsigned long long mo = __ballot(out), mi = __ballot(in), below = (1ull << lane) - 1ull;
         if (have) {
           const int at = out ? at_out + __popcll(mo & below) : at_in + __popcll(mi & below); const V3 nw = mul(Rl, n);
@@ -333,10 +337,64 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
   struct Px { V3 d; float idd; RayHit h; int row, col; bool inside; };
   Px px[2];
   const int n_entries = overflow ? sc.nsh : total;
-  // ---------------- phase B: a 16 x 8 tile per wavefront at a time (lane: column lane & 15, rows lane >> 4 and (lane >> 4) + 4)
-  const int ntx = (W + 15) >> 4, ntiles = ntx * ((nrows + 7) >> 3);
-  for (int tile = wv; tile < ntiles; tile += 4) {  // consecutive tiles (row-major) go to the four wavefronts: neighbours in time and in memory
-    const int tyi = tile / ntx, c0 = (tile - tyi * ntx) << 4, q0 = r0 + 8 * tyi, qn = min(8, r0 + nrows - q0);  // tile rows [q0, q0 + qn)
+  // ---------------- phase B: a STRIP of eight full image rows per wavefront at a time, 16 x 8 tiles inside it (lane: column
+  // lane & 15, rows lane >> 4 and (lane >> 4) + 4).  The strip comes first: its list is culled once against the strip's
+  // cone, frustum and separating faces (the tests a tile makes, 13 times less often), the tiles then only look at the
+  // strip's survivors, and a strip without any -- most of a picture of the sky -- is one contiguous piece of each output
+  // image and is filled with 16-byte stores.
+  const bool wide = (W & 3) == 0 && !(diag & 64);  // every 4-pixel piece of a row is 16-byte aligned (diag 64: scalar stores, for tests)
+  const int ntx = (W + 15) >> 4, nstrips = (nrows + 7) >> 3;
+  const size_t img = (size_t)env * W * H;
+  for (int strip = wv; strip < nstrips; strip += 4) {
+    const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
+    unsigned long long smask[2] = {~0ull, ~0ull};  // the strip's candidates among the band's list (entries 0..63, 64..127)
+    if (!overflow && !(diag & 128)) {  // (diag 128: no strip-level culling, every tile looks at the whole list)
+      V3 saxis; float scos, ssin; cone_of(0.f, (float)W, (float)q0, (float)(q0 + qn), saxis, scos, ssin);
+      const V3 eL = rayA, eR = rayA + rayB * (float)W, eT = rayA + rayC * (float)q0, eB = rayA + rayC * (float)(q0 + qn);
+      V3 nL = cross(eL, rayC), nR = cross(eR, rayC), nT = cross(eT, rayB), nB = cross(eB, rayB);
+      if (dot(nL, rayB) > 0.f) nL = -nL;
+      if (dot(nR, rayB) < 0.f) nR = -nR;
+      if (dot(nT, rayC) > 0.f) nT = -nT;
+      if (dot(nB, rayC) < 0.f) nB = -nB;
+      smask[0] = smask[1] = 0ull;
+      for (int base = 0; base < total; base += 64) {
+        const int j = min(base + lane, total - 1);
+        const V3 ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); const float eb = s_f[j][RL_BOUND];
+        const bool boxed = no_cull || (s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
+        const bool cand = base + lane < total && boxed && (no_cull || cone_pass(ev, eb, saxis, scos, ssin)) && s_i[j][RLI_TYPE] >= 0;
+        unsigned long long keep = __ballot(cand);
+        if (!no_cull) for (unsigned long long mm = keep; mm; mm &= mm - 1) {
+          const int bit = __ffsll((long long)mm) - 1, jj = base + bit, type = s_i[jj][RLI_TYPE];  // wave-uniform
+          if (type != DG_SHAPE_BOX && type != DG_SHAPE_POINTS) continue;
+          const int po = s_i[jj][RLI_PLANE_OFF], nout = s_i[jj][RLI_NOUT]; bool sep = false;
+          for (int f0 = 0; f0 < nout; f0 += 64) { const int f = min(f0 + lane, nout - 1); sep = sep || (s_pl[po + f][3] > 0.f && s_pl[po + f][0] * saxis.x + s_pl[po + f][1] * saxis.y + s_pl[po + f][2] * saxis.z >= ssin + 1e-5f); }
+          if (__any(sep)) { keep &= ~(1ull << bit); continue; }
+          const int pto = s_i[jj][RLI_PT_OFF], npt = s_i[jj][RLI_NPT]; bool inL = false, inR = false, inT = false, inB = false;
+          for (int f0 = 0; f0 < npt; f0 += 64) {
+            const bool have = f0 + lane < npt; const int f = min(f0 + lane, npt - 1); const V3 w = v3(s_pt[pto + f][0], s_pt[pto + f][1], s_pt[pto + f][2]);
+            inL = inL || (have && dot(nL, w) <= 0.f); inR = inR || (have && dot(nR, w) <= 0.f); inT = inT || (have && dot(nT, w) <= 0.f); inB = inB || (have && dot(nB, w) <= 0.f);
+          }
+          if (npt > 0 && (!__any(inL) || !__any(inR) || !__any(inT) || !__any(inB))) keep &= ~(1ull << bit);
+        }
+        smask[base >> 6] = keep;
+      }
+      if (!(smask[0] | smask[1]) || (diag & 2)) {  // nothing in sight: the strip's rows are one contiguous piece of every image
+        const size_t o0 = img + (size_t)q0 * W; const int count = qn * W;
+        if (wide) {
+          const float4 dz = make_float4(-zf, -zf, -zf, -zf), bg = make_float4(0.75f, 0.75f, 0.75f, 0.75f); const int4 sgm = make_int4(-1, -1, -1, -1);
+          if (depth) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<float4*>(depth + o0)[i] = dz;
+          if (seg) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<int4*>(seg + o0)[i] = sgm;
+          if (rgb) for (int i = lane; i < 3 * count / 4; i += 64) reinterpret_cast<float4*>(rgb + 3 * o0)[i] = bg;
+        } else {
+          if (depth) for (int i = lane; i < count; i += 64) depth[o0 + i] = -zf;
+          if (seg) for (int i = lane; i < count; i += 64) seg[o0 + i] = -1;
+          if (rgb) for (int i = lane; i < 3 * count; i += 64) rgb[3 * o0 + i] = 0.75f;
+        }
+        continue;
+      }
+    }
+  for (int txi = 0; txi < ntx; txi++) {
+    const int c0 = txi << 4;  // tile: columns [c0, c0 + 16) of the strip
     V3 axis; float cos_t, sin_t;
     cone_of((float)c0, (float)min(c0 + 16, W), (float)q0, (float)(q0 + qn), axis, cos_t, sin_t);
     // the tile's four side planes through the eye, outward normals (rays are A + c B + r C, so the plane of a column
@@ -362,7 +420,7 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       else { cfp s = tb + j * RS_STRIDE; ev = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; eb = s[RS_BOUND]; }
       // the entry's image-space box against the tile's rectangle first (four compares), then the sphere-cone test
       const bool boxed = overflow || no_cull || (s_bb[j][1] >= (float)c0 && s_bb[j][0] <= (float)min(c0 + 16, W) && s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
-      const bool cand = base + lane < n_entries && boxed && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
+      const bool cand = base + lane < n_entries && boxed && (overflow || ((smask[(base >> 6) & 1] >> lane) & 1ull)) && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
       for (unsigned long long mm = (diag & 2) ? 0ull : __ballot(cand); mm; mm &= mm - 1) {
         const int jj = base + __ffsll((long long)mm) - 1;  // wave-uniform
         if (!overflow) {
@@ -420,27 +478,42 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
         }
       }
     }
+    // ---- the tile's pixels out (staging them through LDS into 16-byte stores was measured: no gain, and the 10 KB of LDS cost a
+    // workgroup per CU -- the stores are not what this kernel waits for)
+    float vdepth[2]; int vsegm[2]; float vcol[2][3];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      if (!px[u].inside) continue;
       const RayHit& h = px[u].h;
-      const bool hit = h.shape >= 0 && h.t >= zn; const size_t o = (size_t)env * W * H + (size_t)px[u].row * W + px[u].col;
-      if (depth) depth[o] = hit ? -h.t : -zf;
-      if (seg) {
-        int vseg = -1;
-        if (hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vseg = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
-        seg[o] = vseg;
-      }
-      if (rgb) {
-        float c0r = 0.75f, c1r = 0.75f, c2r = 0.75f;
-        if (hit) {
-          cfp colr = tb + h.shape * RS_STRIDE + RS_COLOR;  // per-lane index: vector loads from the env's table
-          const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
-          c0r = colr[0] * shd; c1r = colr[1] * shd; c2r = colr[2] * shd;
+      const bool hit = h.shape >= 0;
+      vdepth[u] = hit ? -h.t : -zf; vsegm[u] = -1; vcol[u][0] = vcol[u][1] = vcol[u][2] = 0.75f;
+      if (seg && hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vsegm[u] = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
+      if (rgb && hit) {
+        cfp e = tb + h.shape * RS_STRIDE; cfp tx = e + RS_COLOR;  // per-lane index: vector loads from the env's table
+        const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
+        float t = 0.f; const int kind = (int)tx[DG_TX_KIND];
+        if (kind != DG_TEX_FLAT) {  // procedural texture in the shape's reference frame (DG_TX_* in diygym_scene.h)
+          M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[RS_R + q];
+          const V3 pl = tmul(R, (pc + px[u].d * h.t) - v3(e[RS_P], e[RS_P + 1], e[RS_P + 2])); const float fr = tx[DG_TX_FREQ];
+          const int ux = (int)floorf(pl.x * fr), uy = (int)floorf(pl.y * fr), uz = (int)floorf(pl.z * fr);
+          if (kind == DG_TEX_CHECKER) t = ((ux + uy + uz) & 1) ? 1.f : 0.f;
+          else if (kind == DG_TEX_STRIPES) t = (ux & 1) ? 1.f : 0.f;
+          else { uint32_t hh; DG_TEX_HASH(ux, uy, uz, hh); t = (float)hh * (1.0f / 16777216.0f); }
         }
-        rgb[3 * o] = c0r; rgb[3 * o + 1] = c1r; rgb[3 * o + 2] = c2r;
+#pragma unroll
+        for (int k = 0; k < 3; k++) vcol[u][k] = (tx[DG_TX_A + k] + (tx[DG_TX_B + k] - tx[DG_TX_A + k]) * t) * shd;
       }
     }
+    {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!px[u].inside) continue;
+        const size_t o = img + (size_t)px[u].row * W + px[u].col;
+        if (depth) depth[o] = vdepth[u];
+        if (seg) seg[o] = vsegm[u];
+        if (rgb) { rgb[3 * o] = vcol[u][0]; rgb[3 * o + 1] = vcol[u][1]; rgb[3 * o + 2] = vcol[u][2]; }
+      }
+    }
+  }
   }
 }
 

@@ -2575,9 +2575,14 @@ DGD void run_reset_ops(const Lane<LANES>& ln) {
     } else if (code == DG_OP_RESET_JOINTS) {
       cip il = sc.IL + oi[DG_OI_ILIST]; cfp fl = sc.FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { const int lo = ln.li(il[k])[DG_LI_STATE_OFF]; ln.Sset(lo + DG_LS_Q, fl[k]); ln.Sset(lo + DG_LS_QD, 0.f); }
-    } else if (code == DG_OP_RANDOMIZE_COLOR) {  // visual_randomizer.py:40-46: a flat rgb per env and episode instead of a texture
+    } else if (code == DG_OP_RANDOMIZE_COLOR) {  // visual_randomizer.py:40-46: a procedural texture per env and episode (DG_TX_*) instead of an image
       const int so = sc.addon_off + oi[DG_OI_STATE_OFF]; const uint64_t ge = (uint64_t)(sc.env_base + ln.env);
-      for (int k = 0; k < 3; k++) ln.Sset(so + k, rng_uniform(sc.seed, ge, episode + 1ull, (uint64_t)op, (uint64_t)k));
+      float u[DG_TX_STRIDE];
+#pragma unroll
+      for (int k = 0; k < DG_TX_STRIDE; k++) u[k] = rng_uniform(sc.seed, ge, episode + 1ull, (uint64_t)op, (uint64_t)k);
+#pragma unroll
+      for (int k = 0; k < 6; k++) ln.Sset(so + k, u[k]);
+      ln.Sset(so + DG_TX_FREQ, 2.0f + 14.0f * u[6]); ln.Sset(so + DG_TX_KIND, (float)(1 + (int)(3.0f * u[7])));
     } else if (code == DG_OP_RANDOMIZE_DYNAMICS) {
       // dynamics_randomizer.py:24-32 (see DG_OP_RANDOMIZE_DYNAMICS in diygym_scene.h): new mass = log(U) * current mass
       // per joint, angular damping = log(U) * URDF joint damping (body-wide, the last joint's stays); two rounds at an

@@ -218,7 +218,8 @@ class SceneBuilder:
             self.params[k] = v
         self.bodies = []
         self.aliases = {}  # (FlatBody, pos, quat)
-        self.colors = []
+        self.colors = []      # per body: the YAML `color` (reference model.py:82-83), default grey
+        self.color_set = []   # ... whether the config gave one: it then overrides the base link's URDF material, like changeVisualShape(uid, -1)
         self.cameras = []  # (body, frame, width, height, flags, Transform, fov, near, far)
         self.ops = []
         self.ilist = []
@@ -252,12 +253,14 @@ class SceneBuilder:
         p_link = np.asarray(pos, dtype=np.float64) - T_link.R @ flat.T_base_report.p
         self.bodies.append((flat, p_link, q_link))
         self.colors.append([0.8, 0.8, 0.8, 1.0])
+        self.color_set.append(False)
         return len(self.bodies) - 1
 
     def set_color(self, body, rgba):
         if body in self.aliases:
             return  # colours are per body; an attached child keeps its parent's
         self.colors[body] = [float(v) for v in rgba]
+        self.color_set[body] = True
 
     def add_camera(self, body, frame, width, height, flags, T_parent_cam, fov, near, far):
         self.cameras.append((self.resolve(body)[0] if body >= 0 else body, self.global_frame(body, frame) if body >= 0 else -1, int(width), int(height), int(flags),
@@ -425,7 +428,11 @@ class SceneBuilder:
                     ploff, npl = len(planes), len(pl)
                     planes.extend(pl.tolist())
                 shape_i.append([kind, b, -1 if sh.link < 0 else first + sh.link, poff, npts, ploff, npl, wflag])
-                shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction])
+                # colour in camera images: the YAML `color` on the base link's shapes (changeVisualShape(uid, -1, rgbaColor), reference
+                # model.py:82-83), else the link's URDF material, else the body's default grey
+                mat = getattr(sh, 'color', None)
+                rgb3 = self.colors[b][:3] if ((sh.urdf_link < 0 and self.color_set[b]) or mat is None) else mat
+                shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction, *rgb3, 0.0])
                 shape_dyn.append(dynamic)
                 # bounding sphere that holds the shape in EVERY reachable configuration, or None (floating / respawned base)
                 if not anchored:

@@ -96,6 +96,7 @@ class UrdfLink:
         self.has_inertial = False
         self.collisions = []
         self.lateral_friction = None
+        self.color = None  # rgba of the first <visual>'s <material>, if the file has one
         self.child_joints = []
         self.parent_joint = None
 
@@ -152,8 +153,26 @@ class UrdfRobot:
         self.name = root.get('name', os.path.basename(path))
         self.links = {}
         self.link_order = []
+        # <material name=...><color rgba=.../></material> at the top level, referenced by name from the visuals
+        materials = {}
+        for me in root.findall('material'):
+            ce = me.find('color')
+            if ce is not None and me.get('name'):
+                materials[me.get('name')] = _floats(ce.get('rgba'), 4)
         for le in root.findall('link'):
             link = UrdfLink(le.get('name'))
+            for ve in le.findall('visual'):  # the colour of the link's first visual (what pybullet shows for an untextured mesh [R])
+                me = ve.find('material')
+                if me is None:
+                    continue
+                ce = me.find('color')
+                if ce is not None:
+                    link.color = _floats(ce.get('rgba'), 4)
+                    materials.setdefault(me.get('name'), link.color)
+                elif me.get('name') in materials:
+                    link.color = materials[me.get('name')]
+                if link.color is not None:
+                    break
             inertial = le.find('inertial')
             if inertial is not None:
                 link.has_inertial = True
@@ -332,6 +351,7 @@ class FlatFrame:
 
 class FlatShape:
     def __init__(self, kind, link, T, params, points=None, friction=1.0, urdf_link=-1):
+        self.color = None  # rgb of the owning URDF link's material (camera images), None: the body's colour
         self.urdf_link = urdf_link  # pybullet link index of the URDF link that owns the shape (-1 = base)
         self.kind = kind
         self.link = link
@@ -409,6 +429,7 @@ class FlatBody:
                     self.shapes.append(FlatShape(SHAPE_POINTS, anchor, Transform(), np.zeros(3), points=pts, friction=mu))
             for shp in self.shapes[n_before:]:
                 shp.urdf_link = urdf_link
+                shp.color = None if link.color is None else [float(c) for c in link.color[:3]]
 
         # root
         self.base_name = root.name

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 9
+#define DG_VERSION 10
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -120,7 +120,7 @@ enum { DG_BI_FLAGS = 0, DG_BI_FIRST_LINK, DG_BI_N_LINKS, DG_BI_STATE_OFF,
        DG_BI_DYN_OFF /* state offset of the body's per-env angular damping (dynamics_randomizer), or -1: DG_HF_ANG_DAMPING */,
        DG_BI_PREV_OFF /* state offset where the body's generalised velocity at the START of a step's last substep is kept
                          (joint rates in link order, then base linvel3 angvel3 if floating) for force_torque_sensor, or -1 */,
-       DG_BI_COLOR_OFF /* state offset of the body's per-env rgb (visual_randomizer), or -1: DG_BF_COLOR */,
+       DG_BI_COLOR_OFF /* state offset of the body's per-env texture (visual_randomizer, DG_TX_*), or -1: the shapes' own colours */,
        DG_BI_STRIDE };
 /* per-env state of a body at STATE_OFF: pos[3] quat[4] (base link frame, world);
  * then, for a floating base only, linvel[3] (of the base-frame origin, world)
@@ -176,7 +176,26 @@ enum { DG_SI_TYPE = 0, DG_SI_BODY, DG_SI_LINK, DG_SI_POINT_OFF, DG_SI_N_POINTS, 
 #define DG_SHAPE_NO_COLLIDE 2 /* visual only: seen by cameras, ignored by the narrow phase */
 /* flags bits 8..23: (pybullet link index of the owning URDF link) + 1, 0 = base; used by segmentation masks */
 enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3] | capsule r, half_len (axis = local z) */,
-       DG_SF_FRICTION = 15, DG_SF_STRIDE = 16 };
+       DG_SF_FRICTION = 15,
+       DG_SF_COLOR = 16 /* rgb of the shape in camera images: the URDF <material><color> of its link's first <visual>, the
+                           YAML `color` for shapes of the base link (reference model.py:82-83: changeVisualShape(uid, -1, rgbaColor)),
+                           else grey 0.8 */,
+       DG_SF_STRIDE = 20 };
+/* ---- procedural textures (visual_randomizer) ------------------------------------------------------------------------
+ * The per-env addon state of a visual_randomizer op: colour A rgb, colour B rgb, frequency [cells per metre], kind.
+ * With p = the hit point in the shape's reference frame (a hull: its link frame; other shapes: the shape frame) and
+ * u = floor(p * frequency) (three integers):
+ *   DG_TEX_FLAT     colour A
+ *   DG_TEX_CHECKER  (ux + uy + uz) odd ? B : A
+ *   DG_TEX_STRIPES  ux odd ? B : A
+ *   DG_TEX_CELLS    A + (B - A) t,  t = dg_tex_hash(ux, uy, uz) / 2^24  (every cell its own blend)
+ * They stand in for the "describable textures" images the reference swaps in (visual_randomizer.py:33-46; its 600 MB
+ * download :48-77 is out of scope). */
+enum { DG_TX_A = 0, DG_TX_B = 3, DG_TX_FREQ = 6, DG_TX_KIND = 7, DG_TX_STRIDE = 8 };
+enum { DG_TEX_FLAT = 0, DG_TEX_CHECKER = 1, DG_TEX_STRIPES = 2, DG_TEX_CELLS = 3 };
+/* 24-bit hash of a cell (uint32 wrap-around arithmetic; the same in every implementation) */
+#define DG_TEX_HASH(ux, uy, uz, h) do { uint32_t h_ = (uint32_t)(ux) * 73856093u ^ (uint32_t)(uy) * 19349663u ^ (uint32_t)(uz) * 83492791u; \
+    h_ ^= h_ >> 15; h_ *= 0x2C1B3C6Du; h_ ^= h_ >> 12; h_ *= 0x297A2D39u; h_ ^= h_ >> 15; (h) = h_ >> 8; } while (0)
 enum { DG_PI_A = 0, DG_PI_B, DG_PI_STRIDE };
 /* pair groups: the pair list is ordered so that all pairs between one moving body and one shape of the static world
  * (or between two moving bodies) are consecutive; a group is culled as a whole with bounding spheres */
@@ -211,8 +230,9 @@ enum {
                                   Addon state: N mass scales, then the angular damping.  Guards (the reference formula goes
                                   negative for U < 1): |log U| for the mass, scale clamped to [f4, f5]; damping >= 0.  Drawn
                                   twice at an env's first reset (the reference draws at construction and again in reset()) */
-  DG_OP_RANDOMIZE_COLOR = 19,    /* visual_randomizer.py:40-46, without its texture data set: a flat rgb per env and
-                                    episode, U(0,1)^3 from the counter RNG, kept in 3 floats of addon state (camera rgb only) */
+  DG_OP_RANDOMIZE_COLOR = 19,    /* visual_randomizer.py:40-46 with procedural textures instead of its image data set: per env
+                                    and episode colours A, B ~ U(0,1)^3, frequency 2 + 14 U, kind 1 + floor(3 U) from the counter
+                                    RNG (components 0..7), kept in DG_TX_STRIDE floats of addon state (camera rgb only) */
   /* observe phase */
   DG_OP_OBS_JOINT_STATE = 32,  /* joint_state_sensor.py:47-57 */
   DG_OP_OBS_OBJECT_STATE = 33, /* object_state_sensor.py:49-75 */

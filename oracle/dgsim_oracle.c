@@ -347,8 +347,10 @@ dgo_world* dgo_create(const int32_t* idata, int64_t n_i, const double* fdata, in
     }
     for (int op = 0; op < w->sc.nops; op++) { /* dynamics_randomizer state before its first draw: URDF masses, default damping */
       const int32_t* oi = w->sc.OI + op * DG_OI_STRIDE;
-      if (oi[DG_OI_CODE] == DG_OP_RANDOMIZE_COLOR) { /* the configured colour until the first draw */
-        for (int k = 0; k < 3; k++) st[w->sc.addon_off + oi[DG_OI_STATE_OFF] + k] = body_f(&w->sc, oi[DG_OI_BODY])[DG_BF_COLOR + k];
+      if (oi[DG_OI_CODE] == DG_OP_RANDOMIZE_COLOR) { /* the configured colour, flat, until the first draw */
+        real* tx = st + w->sc.addon_off + oi[DG_OI_STATE_OFF];
+        for (int k = 0; k < 3; k++) tx[DG_TX_A + k] = tx[DG_TX_B + k] = body_f(&w->sc, oi[DG_OI_BODY])[DG_BF_COLOR + k];
+        tx[DG_TX_FREQ] = 1.0; tx[DG_TX_KIND] = DG_TEX_FLAT;
         continue;
       }
       if (oi[DG_OI_CODE] != DG_OP_RANDOMIZE_DYNAMICS) continue;
@@ -1171,9 +1173,11 @@ static void run_reset_ops(dgo_world* w, int env) {
     } else if (code == DG_OP_RESET_JOINTS) { /* joint_controller.py:36-38 */
       const int32_t* il = s->IL + oi[DG_OI_ILIST]; const real* fl = s->FL + oi[DG_OI_FLIST];
       for (int k = 0; k < oi[DG_OI_N]; k++) { real* ls = st + link_i(s, il[k])[DG_LI_STATE_OFF]; ls[DG_LS_Q] = fl[k]; ls[DG_LS_QD] = 0.0; }
-    } else if (code == DG_OP_RANDOMIZE_COLOR) { /* visual_randomizer.py:40-46 (flat colour instead of a texture) */
+    } else if (code == DG_OP_RANDOMIZE_COLOR) { /* visual_randomizer.py:40-46 (a procedural texture instead of an image: DG_TX_*) */
       real* ps = st + s->addon_off + oi[DG_OI_STATE_OFF]; const uint64_t ge = (uint64_t)(w->env_base + env);
-      for (int k = 0; k < 3; k++) ps[k] = rng_uniform(w->seed, ge, episode + 1, (uint64_t)op, (uint64_t)k);
+      real u[DG_TX_STRIDE]; for (int k = 0; k < DG_TX_STRIDE; k++) u[k] = rng_uniform(w->seed, ge, episode + 1, (uint64_t)op, (uint64_t)k);
+      for (int k = 0; k < 6; k++) ps[k] = u[k];
+      ps[DG_TX_FREQ] = 2.0 + 14.0 * u[6]; ps[DG_TX_KIND] = (real)(1 + (int)(3.0 * u[7]));
     } else if (code == DG_OP_RANDOMIZE_DYNAMICS) { /* dynamics_randomizer.py:24-32 */
       const real* fl = s->FL + oi[DG_OI_FLIST]; const int n = oi[DG_OI_N]; real* ps = st + s->addon_off + oi[DG_OI_STATE_OFF];
       const uint64_t ge = (uint64_t)(w->env_base + env);
@@ -1494,9 +1498,21 @@ int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* se
         real c[3] = {0.75, 0.75, 0.75};
         if (hit) {
           const int hb_ = s->SI[h.shape * DG_SI_STRIDE + DG_SI_BODY]; const int co_ = body_i(s, hb_)[DG_BI_COLOR_OFF];
-          const real* col4 = co_ >= 0 ? st + co_ : body_f(s, hb_) + DG_BF_COLOR;  /* per-env colour of a visual_randomizer */
+          real col3[3]; for (int k = 0; k < 3; k++) col3[k] = s->SF[h.shape * DG_SF_STRIDE + DG_SF_COLOR + k]; /* URDF material / YAML colour */
+          if (co_ >= 0) { /* per-env texture of a visual_randomizer, evaluated in the shape's reference frame */
+            const real* tx = st + co_; const int kind = (int)tx[DG_TX_KIND]; real t = 0;
+            if (kind != DG_TEX_FLAT) {
+              const WShape* a = &shp[h.shape]; const m3* Rr = a->type == DG_SHAPE_POINTS ? &a->Rl : &a->R; v3 pr = a->type == DG_SHAPE_POINTS ? a->pl : a->p;
+              v3 pl_ = mtv(Rr, vsub(vadd(pc, vscale(d, h.t)), pr));
+              const int32_t ux = (int32_t)floor(pl_.x * tx[DG_TX_FREQ]), uy = (int32_t)floor(pl_.y * tx[DG_TX_FREQ]), uz = (int32_t)floor(pl_.z * tx[DG_TX_FREQ]);
+              if (kind == DG_TEX_CHECKER) t = ((ux + uy + uz) & 1) ? 1 : 0;
+              else if (kind == DG_TEX_STRIPES) t = (ux & 1) ? 1 : 0;
+              else { uint32_t hh; DG_TEX_HASH(ux, uy, uz, hh); t = (real)hh * (1.0 / 16777216.0); }
+            }
+            for (int k = 0; k < 3; k++) col3[k] = tx[DG_TX_A + k] + (tx[DG_TX_B + k] - tx[DG_TX_A + k]) * t;
+          }
           real nl = vdot(h.n, light); real sh = 0.4 + 0.6 * (nl > 0 ? nl : 0);
-          for (int k = 0; k < 3; k++) c[k] = col4[k] * sh;
+          for (int k = 0; k < 3; k++) c[k] = col3[k] * sh;
         }
         for (int k = 0; k < 3; k++) rgb[3 * px + k] = c[k];
       }

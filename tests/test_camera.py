@@ -187,30 +187,62 @@ def test_hip_render_odd_sizes_match_oracle(res):
     assert float((g['depth'].cpu() - c['depth']).abs()[same].max()) < 1e-3
 
 
-def test_visual_randomizer_recolours_the_model_per_env_and_episode(tmp_path):
-    """visual_randomizer (reference visual_randomizer.py:14-46) without its texture data set: a flat colour per env and
-    episode, seen by the camera's rgb only."""
+def test_visual_randomizer_retextures_the_model_per_env_and_episode(tmp_path):
+    """visual_randomizer (reference visual_randomizer.py:14-46) with procedural textures instead of its image data set: two
+    colours, a frequency and a pattern per env and episode (DG_TX_* / DG_TEX_*), seen by the camera's rgb only.  Every
+    pixel of the marble is a blend of the two drawn colours times the shading factor; depth is untouched; a masked reset
+    re-draws for the reset envs only."""
     import yaml
     tree = yaml.safe_load(open(BASIC))
     tree['red_marble']['look'] = {'addon': 'visual_randomizer'}
     from diy_gym_amd.config import Configuration
     env = DIYGym(Configuration.from_dict('basic_env', tree), num_envs=4, seed=3, backend_factory=OracleBackend)
     look = env.models['red_marble'].addons['look']
-    c0 = look.colors().clone()
-    assert c0.shape == (4, 3) and float(c0.min()) >= 0.0 and float(c0.max()) <= 1.0 and len({tuple(r.tolist()) for r in c0}) == 4
+    t0 = look.textures().clone()
+    assert t0.shape == (4, 8) and float(t0[:, :6].min()) >= 0.0 and float(t0[:, :6].max()) <= 1.0 and len({tuple(r.tolist()) for r in t0}) == 4
+    assert float(t0[:, 6].min()) >= 2.0 and float(t0[:, 6].max()) <= 16.0 and set(t0[:, 7].tolist()) <= {1.0, 2.0, 3.0}
     obs = env.observe()['basic_env']['camera']
     rgb, depth = np.asarray(obs['rgb']), np.asarray(obs['depth'])
     ref = DIYGym(BASIC, num_envs=4, seed=3, backend_factory=OracleBackend).observe()['basic_env']['camera']
     assert np.array_equal(depth, np.asarray(ref['depth']))                      # geometry untouched
     changed = np.abs(rgb - np.asarray(ref['rgb'])).max(-1) > 1e-6
     assert changed.any() and changed.mean() < 0.2                                 # only the marble's pixels
-    for e in range(4):   # the marble's pixels carry the drawn colour (times the shading factor)
-        px = rgb[e][changed[e]]
-        ratio = px / np.maximum(c0[e].numpy()[None, :], 1e-6)
-        assert np.allclose(ratio, ratio[:, :1], atol=1e-4)
+    for e in range(4):   # a marble pixel = (A + (B - A) t) x shade with t in [0, 1]: it lies on the segment between the two colours, scaled
+        A, Bc = t0[e, 0:3].numpy().astype(np.float64), t0[e, 3:6].numpy().astype(np.float64)
+        px = rgb[e][changed[e]].astype(np.float64)
+        # solve px = a A + b B (least squares over the three channels): both weights non-negative, residual ~ 0
+        M = np.stack([A, Bc], 1); w, *_ = np.linalg.lstsq(M, px.T, rcond=None)
+        assert np.abs(M @ w - px.T).max() < 1e-4 and w.min() > -1e-4
+        if int(t0[e, 7]) in (1, 2):   # checker / stripes: every pixel is pure A or pure B
+            assert (np.minimum(np.abs(w[0]), np.abs(w[1])) < 1e-4).all()
     env.reset(torch.tensor([1, 0, 0, 1], dtype=torch.uint8))
-    c1 = look.colors()
-    assert [bool((c1[i] != c0[i]).any()) for i in range(4)] == [True, False, False, True]
+    t1 = look.textures()
+    assert [bool((t1[i] != t0[i]).any()) for i in range(4)] == [True, False, False, True]
+
+
+def test_link_materials_and_the_yaml_colour_reach_the_camera():
+    """N4, first slice: the colour of a pixel is the URDF <material><color> of the link that was hit, except that the YAML
+    ``color`` key (reference model.py:82-83, p.changeVisualShape(uid, -1, rgbaColor)) overrides the BASE link's.  Scene:
+    R2D2 (blue body, white legs and head, black wheels: its URDF materials) on the grass plane, a fixed camera."""
+    from diy_gym_amd.config import Configuration
+    tree = {'plane': {'model': 'grass/plane.urdf', 'color': [0.2, 0.6, 0.2, 1.0]},
+            'r2d2': {'model': 'r2d2.urdf', 'xyz': [0, 0, 0.47]},
+            'camera': {'addon': 'camera', 'xyz': [1.8, 0.0, 0.5], 'rpy': [1.5708, 0.0, 1.5708], 'resolution': [64, 64], 'use_segmentation_mask': True}}   # looks along -x, z up
+    env = DIYGym(Configuration.from_dict('look', tree), num_envs=1, backend_factory=OracleBackend)
+    o = env.observe()['look']['camera']
+    rgb, seg = np.asarray(o['rgb'])[0], np.asarray(o['segmentation_mask'])[0]
+    uid = {k: m.uid for k, m in env.models.items()}
+    def hue(mask):   # colour with the shading divided out (largest channel = 1)
+        px = rgb[mask].reshape(-1, 3).astype(np.float64); px = px[px.max(1) > 1e-3]
+        return np.unique(np.round(px / px.max(1, keepdims=True), 2), axis=0)
+    plane = hue((seg & 0xFFFFFF) == uid['plane']) if (seg >= 0).any() else None
+    assert plane is not None and len(plane) == 1 and np.allclose(plane[0], [1 / 3, 1.0, 1 / 3], atol=0.02)       # the YAML colour, not the file's white
+    r2 = (seg >= 0) & ((seg & 0xFFFFFF) == uid['r2d2'])
+    assert r2.mean() > 0.02
+    body = rgb[r2 & ((seg >> 24) == 0)]; assert len(body) and np.allclose(body / body.max(1, keepdims=True), [0.0, 0.0, 1.0], atol=0.02)   # base link: blue
+    others = rgb[r2 & ((seg >> 24) > 0)].reshape(-1, 3)
+    white = others[(others.min(1) > 0.2)]; black = others[(others.max(1) < 1e-3)]
+    assert len(white) > 0 and np.allclose(white / white.max(1, keepdims=True), 1.0, atol=0.02) and len(black) > 0                              # legs / head white, wheels black
 
 
 @pytest.mark.gpu
@@ -225,8 +257,31 @@ def test_visual_randomizer_hip_matches_oracle(tmp_path):
     cpu = DIYGym(Configuration.from_dict('basic_env', copy.deepcopy(tree)), num_envs=6, seed=2, backend_factory=OracleBackend)
     for _ in range(2):
         g = gpu.receptors['basic_env'].addons['camera'].observe(); c = cpu.receptors['basic_env'].addons['camera'].observe()
-        assert np.allclose(gpu.models['plane'].addons['look'].colors().numpy(), cpu.models['plane'].addons['look'].colors().numpy(), atol=1e-6)
+        assert np.allclose(gpu.models['plane'].addons['look'].textures().numpy(), cpu.models['plane'].addons['look'].textures().numpy(), rtol=1e-6, atol=1e-6)
         same = (g['depth'].cpu() - c['depth']).abs() < 1e-3
-        assert same.float().mean() > 0.99 and float((g['rgb'].cpu() - c['rgb']).abs()[same].max()) < 2e-3
+        # (a pixel on the border of a texture cell may fall on the other side in fp32: the picture agrees in > 98 % of the pixels)
+        rgb_same = (g['rgb'].cpu() - c['rgb']).abs().max(-1).values < 2e-3
+        assert same.float().mean() > 0.99 and float((rgb_same & same).float().mean()) > 0.98
         mask = torch.tensor([1, 0, 1, 0, 1, 1], dtype=torch.uint8)
         gpu.reset(mask.to('cuda:0')); cpu.reset(mask)
+
+
+@pytest.mark.gpu
+def test_link_materials_hip_matches_oracle():
+    """The rgb output of the scene of test_link_materials_and_the_yaml_colour_reach_the_camera (URDF materials per link, the
+    YAML colour on the base link) and of basic_env.yaml (the reference's own fixture: three coloured marbles on the plane),
+    HIP against the oracle: the same colour wherever the same surface is seen."""
+    import copy
+    import yaml
+    from diy_gym_amd.config import Configuration
+    scenes = [{'plane': {'model': 'grass/plane.urdf', 'color': [0.2, 0.6, 0.2, 1.0]}, 'r2d2': {'model': 'r2d2.urdf', 'xyz': [0, 0, 0.47]},
+               'camera': {'addon': 'camera', 'xyz': [1.8, 0.0, 0.5], 'rpy': [1.5708, 0.0, 1.5708], 'resolution': [64, 64], 'use_segmentation_mask': True}},
+              yaml.safe_load(open(BASIC))]
+    for tree in scenes:
+        gpu = DIYGym(Configuration.from_dict('look', copy.deepcopy(tree)), num_envs=3, device='cuda:0', seed=2)
+        cpu = DIYGym(Configuration.from_dict('look', copy.deepcopy(tree)), num_envs=3, seed=2, backend_factory=OracleBackend)
+        g = gpu.receptors['look'].addons['camera'].observe(); c = cpu.receptors['look'].addons['camera'].observe()
+        same = (g['depth'].cpu() - c['depth']).abs() < 1e-3
+        assert same.float().mean() > 0.99
+        assert float((g['rgb'].cpu() - c['rgb']).abs()[same].max()) < 2e-3
+        assert len(torch.unique((c['rgb'] * 50).round(), dim=0)) >= 1 and float(c['rgb'].std()) > 0.05   # a picture with several colours in it

@@ -136,6 +136,7 @@ __device__ unsigned long long g_render_count[16];  // diagnostic build-in counte
 #define DG_RL_CAP 96     /* list entries per band */
 #define DG_RP_CAP 1024   /* hull faces per band   */
 #define DG_RT_CAP 1024   /* hull points / box corners per band */
+#define DG_RS_CAP 160    /* strips of eight rows per band (taller bands: their further strips are not culled as a whole) */
 enum { RL_V = 0 /* centre - eye */, RL_BOUND = 3, RL_R = 4, RL_P = 13, RL_PRM = 16, RL_STRIDE = 20 };  // floats per entry; ints alongside
 enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_NOUT /* faces with the eye on their outer side: stored first */, RLI_STRIDE };
 // Two rays (the lane's two pixels) against one convex hull whose faces are (world normal n, s = signed distance of the
@@ -147,27 +148,40 @@ enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_
 // the faces in their original order (the partition is stable).
 DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int np, RayHit (&h)[2], int sh) {
   float tn[2] = {-3.0e38f, -3.0e38f}, tf[2] = {3.0e38f, 3.0e38f}; int kn[2] = {0, 0}; bool miss[2] = {np == 0, np == 0};
-  for (int k = 0; k < nout; k++) {
-    const float nx = pl[k][0], ny = pl[k][1], nz = pl[k][2], dist = pl[k][3];
+  // (four faces per round, their LDS reads issued together: one face at a time the loop waits a whole LDS round trip per face)
+  for (int k0 = 0; k0 < nout; k0 += 4) {
+    float f[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float den = nx * d[u].x + ny * d[u].y + nz * d[u].z, t = -dist * __frcp_rn(den);
-      const bool par = fabsf(den) < 1e-30f, front = den < 0.f && !par;
-      miss[u] = miss[u] || !front;
-      const bool later = front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k : kn[u];
+    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, nout - 1); f[j][0] = pl[k][0]; f[j][1] = pl[k][1]; f[j][2] = pl[k][2]; f[j][3] = pl[k][3]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool ok = k0 + j < nout;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
+        const bool par = fabsf(den) < 1e-30f, front = den < 0.f && !par;
+        miss[u] = miss[u] || (ok && !front);
+        const bool later = ok && front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k0 + j : kn[u];
+      }
     }
   }
   bool alive[2];
 #pragma unroll
   for (int u = 0; u < 2; u++) alive[u] = !miss[u] && tn[u] >= h[u].tmin && tn[u] < h[u].t;
   if (!__any(alive[0] || alive[1])) return;
-  for (int k = nout; k < np; k++) {
-    const float nx = pl[k][0], ny = pl[k][1], nz = pl[k][2], dist = pl[k][3];
+  for (int k0 = nout; k0 < np; k0 += 4) {
+    float f[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float den = nx * d[u].x + ny * d[u].y + nz * d[u].z, t = -dist * __frcp_rn(den);
-      const bool back = den > 0.f && !(fabsf(den) < 1e-30f);
-      tf[u] = back ? fminf(tf[u], t) : tf[u];
+    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, np - 1); f[j][0] = pl[k][0]; f[j][1] = pl[k][1]; f[j][2] = pl[k][2]; f[j][3] = pl[k][3]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool ok = k0 + j < np;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
+        const bool back = ok && den > 0.f && !(fabsf(den) < 1e-30f);
+        tf[u] = back ? fminf(tf[u], t) : tf[u];
+      }
     }
   }
 #pragma unroll
@@ -218,7 +232,9 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       const int sh = chunk + tid; bool pass = false; V3 v = v3(0.f, 0.f, 0.f); float Rb = 0.f;
       if (sh < sc.nsh) {
         cfp s = tb + sh * RS_STRIDE; v = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; Rb = s[RS_BOUND];
-        pass = no_cull || cone_pass(v, Rb, baxis, bcos, bsin);
+        // (a shape wholly nearer than the near plane -- behind the camera, or around it like the link it is mounted on -- is only
+        // ever entered at a depth below the near distance: it neither shows nor hides anything, see RayHit)
+        pass = no_cull || (cone_pass(v, Rb, baxis, bcos, bsin) && -dot(rc2, v) + Rb >= zn);
         if ((diag & 256) && sc.SI[sh * DG_SI_STRIDE + DG_SI_BODY] == ci[DG_CI_BODY]) pass = false;  // (experiment: the camera's own body left out)
       }
       const unsigned long long m = __ballot(pass);
@@ -316,18 +332,19 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       // vertices relative to the eye, for the tile-frustum test of phase B (hull points; the eight corners of a box)
       { const int npt = s_i[e][RLI_NPT], pto = s_i[e][RLI_PT_OFF]; cfp pts = sc.PF + 3 * sc.SI[sh * DG_SI_STRIDE + DG_SI_POINT_OFF];
         const V3 pl = v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]) - pc;
-        float txl = BIG, txh = -BIG, tyl = BIG, tyh = -BIG; bool behind = false;
+        float txl = BIG, txh = -BIG, tyl = BIG, tyh = -BIG, zmax = -BIG; bool behind = false;
         for (int k = lane; k < npt; k += 64) {
           V3 q;
           if (box) q = v3((k & 1) ? s_f[e][RL_PRM] : -s_f[e][RL_PRM], (k & 2) ? s_f[e][RL_PRM + 1] : -s_f[e][RL_PRM + 1], (k & 4) ? s_f[e][RL_PRM + 2] : -s_f[e][RL_PRM + 2]);
           else q = v3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
           const V3 w = pl + mul(Rl, q); s_pt[pto + k][0] = w.x; s_pt[pto + k][1] = w.y; s_pt[pto + k][2] = w.z;
-          const float z = -dot(rc2, w); behind = behind || !(z > 1e-5f);
+          const float z = -dot(rc2, w); behind = behind || !(z > 1e-5f); zmax = fmaxf(zmax, z);
           const float iz = 1.0f / fmaxf(z, 1e-5f), tx = dot(rc0, w) * iz, ty = dot(rc1, w) * iz;
           txl = fminf(txl, tx); txh = fmaxf(txh, tx); tyl = fminf(tyl, ty); tyh = fmaxf(tyh, ty);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { txl = fminf(txl, __shfl_xor(txl, o)); txh = fmaxf(txh, __shfl_xor(txh, o)); tyl = fminf(tyl, __shfl_xor(tyl, o)); tyh = fmaxf(tyh, __shfl_xor(tyh, o)); }
+        for (int o = 32; o > 0; o >>= 1) { txl = fminf(txl, __shfl_xor(txl, o)); txh = fmaxf(txh, __shfl_xor(txh, o)); tyl = fminf(tyl, __shfl_xor(tyl, o)); tyh = fmaxf(tyh, __shfl_xor(tyh, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
+        if (npt > 0 && zmax < zn && !no_cull && lane == 0) s_i[e][RLI_TYPE] = -1;  // every vertex nearer than the near plane: so is the whole convex shape
         const bool unbounded = __any(behind) || npt == 0;
         if (lane == 0) { s_bb[e][0] = unbounded ? -BIG : to_c(txl) - 0.5f; s_bb[e][1] = unbounded ? BIG : to_c(txh) + 0.5f; s_bb[e][2] = unbounded ? -BIG : to_r(tyh) - 0.5f; s_bb[e][3] = unbounded ? BIG : to_r(tyl) + 0.5f; }
       }
@@ -345,6 +362,11 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
   const bool wide = (W & 3) == 0 && !(diag & 64);  // every 4-pixel piece of a row is 16-byte aligned (diag 64: scalar stores, for tests)
   const int ntx = (W + 15) >> 4, nstrips = (nrows + 7) >> 3;
   const size_t img = (size_t)env * W * H;
+  // B1: every wavefront culls the list for its strips (masks into LDS) and fills the strips that come out empty;
+  // B2: the tiles of the other strips go through a queue (an LDS counter): the wavefront that is free takes the next tile, so
+  //     a picture whose content sits in a few strips -- a hand in a corner of the sky -- is spread over all four.
+  __shared__ unsigned long long s_smask[DG_RS_CAP][2]; __shared__ int s_next_tile;
+  if (tid == 0) s_next_tile = 0;
   for (int strip = wv; strip < nstrips; strip += 4) {
     const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
     unsigned long long smask[2] = {~0ull, ~0ull};  // the strip's candidates among the band's list (entries 0..63, 64..127)
@@ -390,10 +412,22 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
           if (seg) for (int i = lane; i < count; i += 64) seg[o0 + i] = -1;
           if (rgb) for (int i = lane; i < 3 * count; i += 64) rgb[3 * o0 + i] = 0.75f;
         }
-        continue;
+        smask[0] = smask[1] = 0ull;
       }
     }
-  for (int txi = 0; txi < ntx; txi++) {
+    if (lane == 0 && strip < DG_RS_CAP) { s_smask[strip][0] = smask[0]; s_smask[strip][1] = smask[1]; }
+  }
+  __syncthreads();
+  for (;;) {
+    int tile = 0; if (lane == 0) tile = atomicAdd(&s_next_tile, 1);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (tile >= nstrips * ntx) break;
+    const int strip = tile / ntx, txi = tile - strip * ntx;
+    const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);
+    unsigned long long smask[2] = {~0ull, ~0ull};
+    if (strip < DG_RS_CAP) { smask[0] = s_smask[strip][0]; smask[1] = s_smask[strip][1]; }
+    if (!overflow && !(diag & 128) && !(smask[0] | smask[1])) continue;  // (an empty strip: filled in B1)
+  {
     const int c0 = txi << 4;  // tile: columns [c0, c0 + 16) of the strip
     V3 axis; float cos_t, sin_t;
     cone_of((float)c0, (float)min(c0 + 16, W), (float)q0, (float)(q0 + qn), axis, cos_t, sin_t);

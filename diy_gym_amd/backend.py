@@ -270,7 +270,12 @@ class HipBackend:
 
     @property
     def envs_per_wave(self):
-        """Envs per wavefront of the workspace mode (``lanes``: 64/32/16 LDS modes, 0 and -16 global-workspace modes)."""
+        """Envs per wavefront of the workspace mode (``lanes``: 64/32/16/8/4/1 LDS modes, 0 and -16 global-workspace modes).
+
+        The mode is chosen per scene AND batch size (and, for one-env-per-wavefront scenes, the GPU's CU count): each
+        mode sums in its own order, so a rollout replays bit for bit only within one mode.  Shards of a job that must
+        equal the whole batch bit for bit pin the mode with the environment variable ``DG_MAX_LANES`` (32 / 16 / 8 / 4 /
+        1) before constructing their worlds; ``sim.lanes`` tells which mode a world got."""
         return self.lanes if self.lanes > 0 else (-self.lanes if self.lanes < 0 else 64)
 
     def enable_stamps(self, on=True):

@@ -232,7 +232,13 @@ class DIYGym(Receptor):
         return walk_dict(ret, self.collapse_terminals_func) if self.collapse_terminals_func is not None else ret
 
     def step(self, action):
-        """Reference diy_gym.py:187-209: only the addons named in ``action`` are updated."""
+        """Reference diy_gym.py:187-209: only the addons named in ``action`` are updated.
+
+        ALIASING CONTRACT (batched use, ``num_envs`` given): the observations, rewards and terminals returned here are
+        zero-copy VIEWS of the backend's output buffers (terminals: a ``bool`` reinterpretation of 0 / 1 bytes).  The
+        next ``step()`` / ``reset()`` overwrites them in place -- a trainer that keeps them in a rollout buffer must
+        ``clone()`` them.  The single-env compatibility mode (no ``num_envs``) returns fresh numpy snapshots, like the
+        reference."""
         if self.flatten_actions:
             if self._flat_fast and isinstance(action, torch.Tensor) and not self.compat:
                 # the flat action tensor already has the kernel's column order: hand it over as is

@@ -493,19 +493,16 @@ DGD void lds_axpy(const Lane<LANES>& ln, int y, int x, float alpha, int n) {  //
 // position-controlled arm (the oracle does the same; Bullet starts from zero [R]).
 // Register form, up to six joints: M row-major 6 x 6 (zero-padded), smax[i] = 0 for a joint without a motor.  acc = the
 // starting impulses, dv += M acc.
-template <int N>
-DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv) {
-  // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
-  // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal.  Packed lower triangle with
-  // the diagonal stored inverted, as chol6: multiply-only.)
-  float P[N * (N + 1) / 2], y[N], x[N], sd[N];
-#pragma unroll
-  for (int i = 0; i < N; i++) sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f;
+// packed Cholesky (lower triangle, diagonal stored INVERTED as in chol6: multiply-only) of the unit-diagonal matrix whose
+// off-diagonal entry (i, j) is off(i, j), with a pivot floor, and the solve P y = rhs
+template <int N, class OFF>
+DGD void chol_unit_solve(OFF off, const float* rhs, float* x) {
+  float P[N * (N + 1) / 2], y[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
 #pragma unroll
     for (int j = 0; j <= i; j++) {
-      float t = i == j ? 1.f : M[i * N + j] * sd[i] * sd[j];
+      float t = i == j ? 1.f : off(i, j);
 #pragma unroll
       for (int k = 0; k < j; k++) t -= P[i * (i + 1) / 2 + k] * P[j * (j + 1) / 2 + k];
       P[i * (i + 1) / 2 + j] = i == j ? __frsqrt_rn(fmaxf(t, 1e-6f)) : t * P[j * (j + 1) / 2 + j];
@@ -513,7 +510,7 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
   }
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    float t = b[i] * sd[i];
+    float t = rhs[i];
 #pragma unroll
     for (int k = 0; k < i; k++) t -= P[i * (i + 1) / 2 + k] * y[k];
     y[i] = t * P[i * (i + 1) / 2 + i];
@@ -524,6 +521,32 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
 #pragma unroll
     for (int k = i + 1; k < N; k++) t -= P[k * (k + 1) / 2 + i] * x[k];
     x[i] = t * P[i * (i + 1) / 2 + i];
+  }
+}
+template <int N>
+DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv) {
+  // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
+  // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal)
+  float rhs[N], x[N], sd[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f; rhs[i] = b[i] * sd[i]; }
+  chol_unit_solve<N>([&](int i, int j) { return M[i * N + j] * sd[i] * sd[j]; }, rhs, x);
+  // one active-set round (DG_MOTOR_GUESS_REFINE): rows beyond their bounds are held there, the others solved again
+  bool held[N], any = false; float val[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { const float imp = x[i] * sd[i]; held[i] = fabsf(imp) > smax[i] && smax[i] > 0.f; any = any || held[i]; val[i] = held[i] ? copysignf(smax[i], imp) * frcp(sd[i]) : 0.f; }
+  if (__any(any)) {
+    float r2[N], x2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float t = held[i] ? val[i] : rhs[i];
+#pragma unroll
+      for (int j = 0; j < N; j++) if (j != i) t -= (!held[i] && held[j]) ? M[i * N + j] * sd[i] * sd[j] * val[j] : 0.f;
+      r2[i] = t;
+    }
+    chol_unit_solve<N>([&](int i, int j) { return (held[i] || held[j]) ? 0.f : M[i * N + j] * sd[i] * sd[j]; }, r2, x2);
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = any ? x2[i] : x[i];
   }
 #pragma unroll
   for (int i = 0; i < N; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i] * sd[i], -smax[i], smax[i]);
@@ -585,16 +608,20 @@ DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
     for (int t = a + 1; t < k; t++) s -= ln.L(at(t, a)) * ln.L(Y + t);
     ln.L(Y + a) = s * ln.L(at(a, a));
   }
+  bool fits = true;  // (a body of this size whose solution does not fit its bounds starts from zero, as without the guess)
   for (int a = 0; a < k; a++) {
     const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * h;
-    ln.L(mo0 + i * MR_STRIDE + MR_ACC) = __builtin_amdgcn_fmed3f(ln.L(Y + a) * ln.L(S + a), -lim, lim);
+    fits = fits && fabsf(ln.L(Y + a) * ln.L(S + a)) <= lim;
   }
+  for (int a = 0; a < k; a++) ln.L(mo0 + nth(a) * MR_STRIDE + MR_ACC) = fits ? ln.L(Y + a) * ln.L(S + a) : 0.f;
 }
 template <int LANES>
 DGD void motor_guess(const Lane<LANES>& ln, int b) {
   if (!(ln.sc.HF[DG_HF_MOTOR_GUESS] > 0.f)) return;
   const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0) return;
-  if (n <= 6) motor_guess_small<LANES, 6>(ln, b); else if (n <= 8) motor_guess_small<LANES, 8>(ln, b); else if (n <= 12) motor_guess_small<LANES, 12>(ln, b); else motor_guess_lds(ln, b);
+  // (registers up to eight joints, with one active-set round; up to ten in LDS, all-or-nothing; none beyond: on a 12-joint
+  // tree under saturating position control the LDS factorisation cost 17 % of the step and the clamped guess two more sweeps)
+  if (n <= 6) motor_guess_small<LANES, 6>(ln, b); else if (n <= DG_MOTOR_GUESS_REFINE) motor_guess_small<LANES, DG_MOTOR_GUESS_REFINE>(ln, b); else if (n <= DG_MOTOR_GUESS_MAX) motor_guess_lds(ln, b);
 }
 
 // one PGS update of contact row at ro; returns the squared velocity residual

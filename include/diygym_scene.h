@@ -97,7 +97,12 @@ enum {
                            impulse it ended the previous substep with (Bullet: m_warmstartingFactor 0.85 [R]); 0 = off */
   DG_HF_WARMSTART_FRICTION, /* the same for its two friction rows (Bullet starts friction rows from zero [R])          */
   DG_HF_MOTOR_GUESS,    /* > 0: the motor rows of a body start from the clamped solution of the body's unclamped motor system
-                           (M^-1 restricted to the motorised joints) lambda = b instead of from zero                      */
+                           (M^-1 restricted to the motorised joints) lambda = b instead of from zero.  By the body's joint
+                           count n (what the factorisation costs on the device decides the cut-offs):
+                             n <= DG_MOTOR_GUESS_REFINE: if a row of the solution exceeds its bound, ONE active-set round --
+                                  those rows are held at their bounds and the others solved again -- then the clamp;
+                             n <= DG_MOTOR_GUESS_MAX:    if a row exceeds its bound the body starts from zero (as without);
+                             beyond:                     no starting guess (zero) */
   DG_HF_FLOAT_COUNT
 };
 
@@ -107,6 +112,9 @@ enum {
  * which end; hull against a box: the hull vertex index & 63).  A reset clears the count. */
 enum { DG_WS_KEY = 0, DG_WS_NORMAL, DG_WS_T1, DG_WS_T2, DG_WS_STRIDE };
 #define DG_CONTACT_KEY(pair, feature) ((pair) * 64 + ((feature) & 63))
+
+#define DG_MOTOR_GUESS_REFINE 8
+#define DG_MOTOR_GUESS_MAX 10
 
 /* ---- per-env state prefix --------------------------------------------- */
 enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_EPISODE /* resets so far (RNG stream) */,

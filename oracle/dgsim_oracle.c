@@ -797,13 +797,23 @@ static void substep(dgo_world* w, int env, int last) {
     for (int b = 0; b < s->nb; b++) {
       BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
       for (int r = r0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
-      if (k == 0) continue;
+      if (k == 0 || ws->n > DG_MOTOR_GUESS_MAX) continue;
       /* (symmetrically scaled to a unit diagonal first: finger joints and shoulder joints differ by 1e5 in M^-1, and the
        * device solves this in fp32) */
       real A[MAXL * MAXL], bb[MAXL], x[MAXL], sc_[MAXL];
       for (int j = 0; j < k; j++) sc_[j] = 1.0 / sqrt(rows[idx[j]].RA[6 + dof[j]]);
       for (int j = 0; j < k; j++) { bb[j] = rows[idx[j]].b * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l]; }
       if (!spd_solve(k, A, bb, x)) continue;
+      int held[MAXL], any = 0; real val[MAXL];
+      for (int j = 0; j < k; j++) { const Row* r = &rows[idx[j]]; const real imp = x[j] * sc_[j]; held[j] = imp < r->lo || imp > r->hi; any |= held[j]; val[j] = (imp < r->lo ? r->lo : r->hi) / sc_[j]; }
+      if (any && ws->n > DG_MOTOR_GUESS_REFINE) continue; /* a bigger body whose solution does not fit its bounds: zero start */
+      if (any) { /* one active-set round: the rows beyond their bounds held there, the others solved again */
+        real A2[MAXL * MAXL], b2[MAXL];
+        for (int j = 0; j < k; j++) { b2[j] = bb[j]; for (int l = 0; l < k; l++) A2[l * k + j] = A[l * k + j]; }
+        for (int j = 0; j < k; j++) if (held[j]) for (int l = 0; l < k; l++) if (!held[l]) b2[l] -= A[l * k + j] * val[j];
+        for (int j = 0; j < k; j++) if (held[j]) { for (int l = 0; l < k; l++) { A2[l * k + j] = 0; A2[j * k + l] = 0; } A2[j * k + j] = 1; b2[j] = val[j]; }
+        if (!spd_solve(k, A2, b2, x)) continue;
+      }
       for (int j = 0; j < k; j++) {
         Row* r = &rows[idx[j]]; real imp = x[j] * sc_[j]; imp = imp < r->lo ? r->lo : (imp > r->hi ? r->hi : imp);
         r->acc = imp; for (int q = 0; q < 6 + ws->n; q++) ws->dv[q] += r->RA[q] * imp;

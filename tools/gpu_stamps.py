@@ -8,7 +8,8 @@ from diy_gym_amd import DIYGym
 import test_parity_gpu as T
 name = sys.argv[1] if len(sys.argv) > 1 else 'ur_ik'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0')
+eng = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in os.environ.get('ENGINE', '').split(',') if kv}  # e.g. ENGINE=motor_guess=0,warmstart=0
+env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0', engine=eng)
 lo, hi = T.action_bounds(env)
 gen = torch.Generator().manual_seed(1)
 ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0') for _ in range(8)]

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Copies the rocprofv3 summaries of tools/profile_r2.sh from gpurun_out/prof_r2 into profiles/ (tracked) and derives the
+"""Copies the rocprofv3 summaries of tools/profile.sh <tag> from gpurun_out/prof_<tag> into profiles/ (tracked) and derives the
 per-launch counter means of the dominant kernels: profiles/<tag>_*_kernel_stats.csv, <tag>_*_pmc_*.json and the bench lines
 of the same commands.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (both counters are in KiB; gfx950's
 FETCH_SIZE counts half of a coalesced read -- MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 src = os.path.join(ROOT, 'gpurun_out', 'prof_%s' % tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
@@ -54,11 +54,12 @@ if cam:
     cam['algorithmic_image_bytes_per_launch'] = 1024 * 200 * 200 * 16
     json.dump({'kernel': 'render_kernel', 'workload': 'from_the_readme x 1024, 200x200 rgb + depth', 'per_launch_means': cam, 'note': note},
               open(os.path.join(dst, '%s_from_the_readme_1024_pmc_render_kernel.json' % tag), 'w'), indent=1)
-b = os.path.join(src, 'bench_ur_high_5_pmc.json')
-if os.path.isfile(b):
-    lines = [l for l in open(b) if l.startswith('{')]
-    if lines:
-        json.dump(json.loads(lines[0]), open(os.path.join(dst, '%s_ur_high_5_16384_bench_line_with_pmc.json' % tag), 'w'), indent=1)
+for src_name, dst_name in (('bench_ur_high_5_default.json', 'ur_high_5_16384_bench_line_default.json'), ('bench_from_the_readme_default.json', 'from_the_readme_1024_bench_line_default.json')):
+    b = os.path.join(src, src_name)
+    if os.path.isfile(b):
+        lines = [l for l in open(b) if l.startswith('{')]
+        if lines:
+            json.dump(json.loads(lines[0]), open(os.path.join(dst, '%s_%s' % (tag, dst_name)), 'w'), indent=1)
 print(json.dumps({'ur': {k: v for k, v in ur.items() if not k.endswith('__launches')}, 'cam': {k: v for k, v in cam.items() if not k.endswith('__launches')}}, indent=1))
 for name, envs in SIZES.items():
     p = os.path.join(dst, '%s_%s_%d_kernel_stats.csv' % (tag, name, envs))

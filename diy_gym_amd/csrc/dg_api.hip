@@ -82,7 +82,8 @@ static const char* check_blob(const int32_t* I, int64_t n_i, int64_t n_f) {
     {DG_H_OFF_FRAME_F, DG_H_N_FRAMES, DG_FF_STRIDE, true, "frame floats"}, {DG_H_OFF_SHAPE_F, DG_H_N_SHAPES, DG_SF_STRIDE, true, "shape floats"},
     {DG_H_OFF_POINT_F, DG_H_N_POINTS, 3, true, "hull points"}, {DG_H_OFF_PLANE_F, DG_H_N_PLANES, 4, true, "hull planes"},
     {DG_H_OFF_CAMERA_F, DG_H_N_CAMERAS, DG_CF_STRIDE, true, "camera floats"}, {DG_H_OFF_OP_F, DG_H_N_OPS, DG_OF_STRIDE, true, "op floats"},
-    {DG_H_OFF_FLIST, DG_H_N_FLIST, 1, true, "float list"}};
+    {DG_H_OFF_FLIST, DG_H_N_FLIST, 1, true, "float list"},
+    {DG_H_OFF_CONS_I, DG_H_N_CONSTRAINTS, DG_KI_STRIDE, false, "constraint ints"}, {DG_H_OFF_CONS_F, DG_H_N_CONSTRAINTS, DG_KF_STRIDE, true, "constraint floats"}};
   for (const T& t : tables) {
     const int64_t off = I[t.off], cnt = I[t.count_idx], lim = t.is_f ? n_f : n_i;
     if (cnt < 0 || off < (t.is_f ? DG_HF_FLOAT_COUNT : DG_H_INT_COUNT) || off + cnt * t.stride > lim) return t.name;
@@ -106,6 +107,16 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   if (n_f < DG_HF_FLOAT_COUNT) return fail(DG_ERR_BAD_SCENE, "float array shorter than its header");
   if (const char* bad = check_blob(I, n_i, n_f)) return fail(DG_ERR_BAD_SCENE, "scene table '%s' does not fit the arrays passed (n_i=%lld, n_f=%lld)", bad, (long long)n_i, (long long)n_f);
   if (I[DG_H_N_SHAPES] > 4096) return fail(DG_ERR_UNSUPPORTED, "%d shapes > 4096 supported", I[DG_H_N_SHAPES]);
+  if (I[DG_H_N_CONSTRAINTS] > DG_MAX_CONSTRAINTS) return fail(DG_ERR_UNSUPPORTED, "%d fixed constraints > %d supported", I[DG_H_N_CONSTRAINTS], DG_MAX_CONSTRAINTS);
+  for (int q = 0; q < I[DG_H_N_CONSTRAINTS]; q++) {
+    const int32_t* ki = I + I[DG_H_OFF_CONS_I] + q * DG_KI_STRIDE;
+    for (int k = 0; k < 2; k++) {
+      const int b = ki[k == 0 ? DG_KI_BODY_A : DG_KI_BODY_B], gl = ki[k == 0 ? DG_KI_LINK_A : DG_KI_LINK_B];
+      if (b < 0 || b >= nb) return fail(DG_ERR_BAD_SCENE, "constraint %d: body %d out of range", q, b);
+      const int32_t* B = I + I[DG_H_OFF_BODY_I] + b * DG_BI_STRIDE;
+      if (gl >= 0 && (gl < B[DG_BI_FIRST_LINK] || gl >= B[DG_BI_FIRST_LINK] + B[DG_BI_N_LINKS])) return fail(DG_ERR_BAD_SCENE, "constraint %d: link %d is not a link of body %d", q, gl, b);
+    }
+  }
   if (I[DG_H_N_TERM_GROUPS] > 64) return fail(DG_ERR_UNSUPPORTED, "%d receptors with terminal addons > 64 supported", I[DG_H_N_TERM_GROUPS]);
   { int ndev = 0; HIP_TRY(hipGetDeviceCount(&ndev)); if (device < 0 || device >= ndev) return fail(DG_ERR_ARG, "device %d out of range (%d visible)", device, ndev); }
   DG_ON_DEVICE(device);
@@ -135,8 +146,9 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   slot += nvmax + 8;  // chunked helpers read up to 7 slots past a vector
   for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_POSE] = slot; slot += 9; PLL[l * PLL_STRIDE + PLL_IAACC] = -1; }
   for (int l = 0; l < nl; l++) { PLL[l * PLL_STRIDE + PLL_MROW] = slot; slot += MR_STRIDE; }  // contiguous: pgs_rows_small strides through them
-  const int maxc = I[DG_H_MAX_CONTACTS];
-  const int cont_off = slot; slot += 1 + maxc * CL_STRIDE;
+  const int maxc = I[DG_H_MAX_CONTACTS], ncons = I[DG_H_N_CONSTRAINTS];
+  // (a fixed constraint keeps two pseudo contact slots behind the real ones: its linear and its angular rows, build_constraint_rows)
+  const int cont_off = slot; slot += 1 + (maxc + 2 * ncons) * CL_STRIDE;
   const int ab_stride = any_float ? AB_FLOAT_STRIDE : AB_FIXED_STRIDE;
   // transient region: ABA workspace (+ inertia accumulators for links with a child that is not link+1),
   // contact rows, IK scratch -- never live at the same time
@@ -153,14 +165,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     if (n > 6) tr = std::max(tr, n * (n + 1) / 2 + 2 * n + 24);  // motor_guess_lds: packed factor + y + scaling, padded
   }
   // contact rows carry a second body's Jacobian / response only if some candidate pair has two moving bodies
-  bool two_sided = false;
+  bool two_sided = ncons > 0;
   { const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
     auto moving = [&](int sh) { const int32_t* B = BI + SIh[sh * DG_SI_STRIDE + DG_SI_BODY] * DG_BI_STRIDE; return !((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0); };
     for (int p = 0; p < I[DG_H_N_PAIRS]; p++) if (moving(PIh[p * DG_PI_STRIDE + DG_PI_A]) && moving(PIh[p * DG_PI_STRIDE + DG_PI_B])) two_sided = true; }
   int nt = 0; for (int b = 0; b < nb; b++) nt += PLB[b * PLB_STRIDE + PLB_NV];
-  const bool dense = nt <= 32;  // contact rows indexed by global DoF, swept with the velocity change in registers
+  const bool dense = nt <= 32 && ncons == 0;  // contact rows indexed by global DoF, swept with the velocity change in registers (fixed-constraint rows: generic sweeps only)
   const int crow_tail = dense ? 2 * nt : (two_sided ? 4 : 2) * nvmax;
-  tr = std::max(tr, 3 * maxc * (crow_tail + 3));
+  tr = std::max(tr, 3 * (maxc + 2 * ncons) * (crow_tail + 3));
   if (I[DG_H_N_PAIRS] > 0) tr = std::max(tr, (int)SC_STRIDE * I[DG_H_N_SHAPES]);  // narrow-phase shape cache
   for (int op = 0; op < I[DG_H_N_OPS]; op++)
     if (OI[op * DG_OI_STRIDE + DG_OI_CODE] == DG_OP_IK_CONTROL) {
@@ -291,7 +303,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];
-  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.warm_off = I[DG_H_WARM_OFF]; sc.debug_keep_ext = getenv("DG_DEBUG_KEEP_EXT") ? 1 : 0; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
+  sc.state_dim = I[DG_H_STATE_DIM]; sc.addon_off = I[DG_H_ADDON_STATE_OFF]; sc.max_contacts = maxc; sc.warm_off = I[DG_H_WARM_OFF]; sc.ncons = ncons; sc.KI = dI + I[DG_H_OFF_CONS_I]; sc.KF = dF + I[DG_H_OFF_CONS_F]; sc.debug_keep_ext = getenv("DG_DEBUG_KEEP_EXT") ? 1 : 0; sc.term_mode = I[DG_H_TERM_MODE]; sc.n_term_groups = I[DG_H_N_TERM_GROUPS];
   sc.tr_off = tr_off; sc.tr_slots = tr; sc.cont_off = cont_off; sc.nv_max = nvmax; sc.total_slots = total; sc.ab_stride = ab_stride; sc.crow_tail = crow_tail; sc.nt = nt; sc.dense = dense ? 1 : 0; sc.dv_base = nb > 0 ? PLB[PLB_DV] : 0;
   sc.num_envs = num_envs; sc.stride = env_stride; sc.seed = seed; sc.env_base = env_index_base;
   // bodies whose solver rows are held in registers by the step kernel
@@ -303,7 +315,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   // helper wave: the LAST fixed-base chain body (so that wave 0 keeps the first arm), provided the scene has other
   // work to overlap with and every inverse-kinematics op on that body has the register-resident form
   sc.helper_body = -1;
-  if (lanes == 64 && !getenv("DG_NO_HELPER_WAVE")) {
+  if (lanes == 64 && ncons == 0 && !getenv("DG_NO_HELPER_WAVE")) {
     int n_dyn = 0; for (int b = 0; b < nb; b++) { const int32_t* B = BI + b * DG_BI_STRIDE; if (!((B[DG_BI_FLAGS] & DG_BODY_FIXED) && B[DG_BI_N_LINKS] == 0)) n_dyn++; }
     for (int b = nb - 1; b >= 0 && n_dyn >= 2; b--) {
       if (!PLB[b * PLB_STRIDE + PLB_CHAIN]) continue;

@@ -58,6 +58,7 @@ struct DevScene {
   int32_t nsha; // 1 + the last shape that is not an analytic box (the narrow phase caches a segment per round shape)
   int32_t debug_keep_ext;  // DG_DEBUG_KEEP_EXT: external wrenches and joint torques are NOT cleared at the end of a step (diagnostic: lets a test read what the update ops applied)
   int32_t warm_off;  // state offset of the contact impulse cache (DG_WS_*), -1: no warm starting
+  int32_t ncons; cip KI; cfp KF;  // fixed constraints between two bodies (DG_KI_*, DG_KF_*): six solver rows each, generic sweeps only
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;
   int32_t tr_off, tr_slots, cont_off, nv_max, total_slots, ab_stride;  // LDS plan
@@ -648,19 +649,21 @@ struct Lane {
   }
 
   // Jacobian (into jo) and response M^-1 J^T (into ro) of body b for a unit force along world direction
-  // dir at world point p on link gl (-1 base).  Returns J M^-1 J^T.
+  // dir at world point p on link gl (-1 base) -- TORQUE: for a unit torque about dir on that link.  Returns J M^-1 J^T.
+  template <bool TORQUE = false>
   DGD float point_row(int b, int gl, V3 p, V3 dir, int jo, int ro) const {
     cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     const int nv = plb(b)[PLB_NV], mo = plb(b)[PLB_MINV]; int k0 = 0;
     for (int k = 0; k < nv; k++) L(jo + k) = 0.f;
     if (!fixed(b)) {
-      M3 R0 = LR(plb(b)[PLB_R0]); V3 ja = tmul(R0, cross(p - base_pos(b), dir)), jl = tmul(R0, dir);
+      M3 R0 = LR(plb(b)[PLB_R0]); V3 ja = TORQUE ? tmul(R0, dir) : tmul(R0, cross(p - base_pos(b), dir)), jl = TORQUE ? v3(0.f, 0.f, 0.f) : tmul(R0, dir);
       L3set(jo, ja); L3set(jo + 3, jl); k0 = 6;
     }
     for (int k = gl; k >= 0; k = li(k)[DG_LI_PARENT]) {
       int po = pll(k)[PLL_POSE]; M3 Rk = LR(po); V3 pk = L3(po + 6); cfp f = lf(k);
       V3 axw = mul(Rk, v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]));
-      L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
+      if (TORQUE) L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, dir) : 0.f;
+      else L(jo + k0 + (k - first)) = li(k)[DG_LI_TYPE] == 0 ? dot(axw, cross(p - pk, dir)) : dot(axw, dir);
     }
     (void)n;
     // Response M^-1 J^T, eight entries at a time: J is sparse (base + the chain above link gl) and M^-1 symmetric,

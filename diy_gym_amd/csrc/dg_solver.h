@@ -393,6 +393,50 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
   }
 }
 
+// ---- fixed constraints (DG_KI_* / DG_KF_*; reference model.py:74-75 createConstraint(JOINT_FIXED)) as solver rows ------
+// Constraint q keeps two pseudo contact slots behind the real ones -- max_contacts + 2 q (linear rows x y z) and + 1 (angular
+// rows) -- so that solve_crow sweeps its rows like any two-sided contact row.  Scenes with constraints take the generic
+// sweeps only (dg_world_create: not dense, no helper wavefronts, rows two-sided).  Every table read is wave-uniform.
+template <int LANES>
+DGD void build_constraint_rows(const Lane<LANES>& ln) {
+  const DevScene& sc = ln.sc; const int nvm = sc.nv_max, tl = sc.crow_tail, rs = crow_stride(tl); const float h = sc.h, erp = sc.HF[DG_HF_CONTACT_ERP];
+  for (int q = 0; q < sc.ncons; q++) {
+    cip ki = sc.KI + q * DG_KI_STRIDE; cfp kf = sc.KF + q * DG_KF_STRIDE;
+    const int ba = ki[DG_KI_BODY_A], la = ki[DG_KI_LINK_A], bb = ki[DG_KI_BODY_B], lb = ki[DG_KI_LINK_B];
+    const bool a_dyn = !(ln.fixed(ba) && ln.bi(ba)[DG_BI_N_LINKS] == 0), b_dyn = !(ln.fixed(bb) && ln.bi(bb)[DG_BI_N_LINKS] == 0);
+    V3 P[2]; Q4 Q[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int b = k == 0 ? ba : bb, gl = k == 0 ? la : lb; M3 R; V3 o; ln.link_world(b, gl, R, o);
+      cfp pp = kf + (k == 0 ? DG_KF_POS_A : DG_KF_POS_B); cfp qq = kf + (k == 0 ? DG_KF_QUAT_A : DG_KF_QUAT_B);
+      P[k] = o + mul(R, v3(pp[0], pp[1], pp[2]));
+      const Q4 ql = gl < 0 ? ln.base_quat(b) : qfrom_mat(R); const Q4 qo = {qq[0], qq[1], qq[2], qq[3]}; Q[k] = qnormalize(qmul(ql, qo));
+    }
+    const V3 perr = P[1] - P[0];
+    const Q4 qe = qmul(Q[1], qconj(Q[0])); const float sg = qe.w < 0.f ? -2.f : 2.f; const V3 aerr = v3(sg * qe.x, sg * qe.y, sg * qe.z);
+    const int b1 = a_dyn ? ba : bb, l1 = a_dyn ? la : lb;
+#pragma unroll 1
+    for (int d = 0; d < 6; d++) {
+      const bool tq = d >= 3; const int c = sc.max_contacts + 2 * q + (tq ? 1 : 0), co = sc.cont_off + 1 + c * CL_STRIDE, ro = sc.tr_off + (3 * c + d % 3) * rs;
+      const V3 dir = v3(d % 3 == 0 ? 1.f : 0.f, d % 3 == 1 ? 1.f : 0.f, d % 3 == 2 ? 1.f : 0.f);
+      for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f;
+      float diag = 0.f, jv = 0.f;
+      if (a_dyn || b_dyn) {
+        const V3 d1 = a_dyn ? dir : -dir, p1 = a_dyn ? P[0] : P[1];
+        diag += tq ? ln.template point_row<true>(b1, l1, p1, d1, ro, ro + nvm) : ln.point_row(b1, l1, p1, d1, ro, ro + nvm);
+        jv += ln.gen_vel_dot(b1, ro);
+        ln.L(co + CL_DVA) = (float)ln.plb(b1)[PLB_DV]; ln.L(co + CL_NVA) = (float)ln.plb(b1)[PLB_NV];
+        if (a_dyn && b_dyn) {
+          diag += tq ? ln.template point_row<true>(bb, lb, P[1], -dir, ro + 2 * nvm, ro + 3 * nvm) : ln.point_row(bb, lb, P[1], -dir, ro + 2 * nvm, ro + 3 * nvm);
+          jv += ln.gen_vel_dot(bb, ro + 2 * nvm);
+          ln.L(co + CL_DVB) = (float)ln.plb(bb)[PLB_DV]; ln.L(co + CL_NVB) = (float)ln.plb(bb)[PLB_NV];
+        } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
+      }
+      ln.L(ro + tl) = -jv + erp * dot(tq ? aerr : perr, dir) / h; ln.L(ro + tl + 1) = 0.f; ln.L(ro + tl + 2) = diag;
+    }
+  }
+}
+
 // The same rows for the lanes whose contact joins two BASE shapes (no link on either side: marbles, a drone on the
 // ground, a free body on a table) in an all-dense scene, without the pair-by-pair serialisation: every table entry is
 // fetched per lane, so ONE pass serves all lanes whatever pairs they hold.  Returns whether this lane's contact was
@@ -1884,6 +1928,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
     if (ln.bi(b)[DG_BI_N_LINKS] == 0 || b == sc.reg_body[0] || b == sc.reg_body[1] || (helper_rows && b == hb)) continue;
     motor_guess(ln, b);
   }
+  if (sc.ncons > 0) build_constraint_rows(ln);
   // ---- contact rows: lanes are grouped by pair id so that every table lookup stays wave-uniform
   // all-dense scenes: the sweeps start from a zero velocity change held in registers, so until they finish the LDS
   // velocity-change blocks are free -- park the generalised velocities there for the row right-hand sides
@@ -2067,7 +2112,14 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       }
     }
     prof.stamp(PS_PGS_LIMIT);
-    if (wave_max_cont > 0) { regs_to_lds(0); regs_to_lds(1); }
+    if (wave_max_cont > 0 || sc.ncons > 0) { regs_to_lds(0); regs_to_lds(1); }
+    for (int q = 0; q < sc.ncons; q++) {  // fixed constraints: behind the limit rows, before the contacts (oracle order)
+      const float lim = sc.KF[q * DG_KF_STRIDE + DG_KF_MAX_FORCE] * h;
+      for (int d = 0; d < 6; d++) {
+        const int c = sc.max_contacts + 2 * q + d / 3;
+        maxres = fmaxf(maxres, solve_crow(ln, sc.tr_off + (3 * c + d % 3) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, true));
+      }
+    }
     {  // (dense scenes with contacts never get here: they take pgs_dense above)
     for (int c = 0; c < wave_max_cont; c++) {  // contact normals
       const bool has = c < ncont;
@@ -2083,7 +2135,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       for (int d = 1; d < 3; d++) { float r = solve_crow(ln, sc.tr_off + (3 * c + d) * rs, sc.cont_off + 1 + c * CL_STRIDE, -lim, lim, live, act); if (act) maxres = fmaxf(maxres, r); }
     }
     }
-    if (wave_max_cont > 0) { lds_to_regs(0); lds_to_regs(1); }
+    if (wave_max_cont > 0 || sc.ncons > 0) { lds_to_regs(0); lds_to_regs(1); }
     prof.stamp(PS_PGS_CONTACT);
     if (live) iters_done = it + 1;
     live = live && !(maxres <= thr && maxabs <= thr_abs);

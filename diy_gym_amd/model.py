@@ -72,8 +72,17 @@ class Model(Receptor):
             # parent with a fixed constraint whose pivot is this model's xyz / rpy in the parent frame.  Here the
             # coupling is rigid -- the child is merged into the parent's body (FlatBody.attach) and ``uid`` is an
             # alias the scene builder resolves to (parent body, link / frame offsets).
+            # ``attach: constraint`` keeps the reference's arrangement instead: the child is a body of its own and the
+            # fixed constraint becomes six solver rows (``constraint_max_force``: createConstraint's default 500 N [R]).
             parent_frame_id = parent.get_frame_id(config.get('parent_frame')) if 'parent_frame' in config else -1
-            self.uid = self.env.builder.attach_child(parent.uid, parent_frame_id, self.flat, self.position, self.orientation)
+            how = config.get('attach', 'merge')
+            if how not in ('merge', 'constraint'):
+                raise ValueError("attach: 'merge' or 'constraint', not %r" % (how, ))
+            if how == 'constraint':
+                self.uid = self.env.builder.add_constrained_child(parent.uid, parent_frame_id, self.flat, self.position, self.orientation,
+                                                                  config.get('constraint_max_force', 500.0))
+            else:
+                self.uid = self.env.builder.attach_child(parent.uid, parent_frame_id, self.flat, self.position, self.orientation)
         self.color = config.get('color') if 'color' in config else None  # visual only (camera rgb)
         if self.color is not None:
             self.env.builder.set_color(self.uid, list(self.color) + [1.0] * (4 - len(self.color)))

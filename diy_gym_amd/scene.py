@@ -220,6 +220,7 @@ class SceneBuilder:
         self.aliases = {}  # (FlatBody, pos, quat)
         self.colors = []      # per body: the YAML `color` (reference model.py:82-83), default grey
         self.color_set = []   # ... whether the config gave one: it then overrides the base link's URDF material, like changeVisualShape(uid, -1)
+        self.constraints = []  # ([body_a, local link_a, body_b, local link_b], [pivot_a pos quat, pivot_b pos quat, max force, 0])
         self.cameras = []  # (body, frame, width, height, flags, Transform, fov, near, far)
         self.ops = []
         self.ilist = []
@@ -244,6 +245,30 @@ class SceneBuilder:
         uid = self.ALIAS_BASE + len(self.aliases)
         self.aliases[uid] = (body, link_off, frame_off, base_frame)
         return uid
+
+    def add_constrained_child(self, parent_uid, parent_frame, child_flat, pos, quat, max_force):
+        """Child model coupled to its parent the way the reference does it (model.py:69-77): a body of its own, held by
+        ``createConstraint(JOINT_FIXED)`` -- here six solver rows (``DG_KI_*`` / ``DG_KF_*``).  ``pos`` / ``quat``: the pivot in
+        the parent link's INERTIAL frame; the pivot on the child is its base inertial frame [RECOLLECTION: the frames
+        createConstraint takes its pivots in].  [decision] The child is loaded AT the pivot for the parent's load
+        configuration (all joints at zero); the reference loads it at the parent frame and lets the constraint pull it
+        over.  The two bodies do not collide with each other."""
+        body, _, foff, basef = self.resolve(parent_uid)
+        flat, p_link, q_link = self.bodies[body]
+        pf = basef if parent_frame < 0 else foff + parent_frame
+        anchor, T_anchor_pf = (flat.frames[pf].link, flat.frames[pf].T_com) if pf >= 0 else (-1, flat.T_base_report)
+        T = Transform()  # anchor link frame in the base link frame, joints at zero
+        k = anchor
+        while k >= 0:
+            T = flat.links[k].origin * T
+            k = flat.links[k].parent
+        T_rel = Transform.from_xyz_quat(pos, quat)
+        T_world = Transform.from_xyz_quat(p_link, q_link) * T * T_anchor_pf * T_rel
+        child = self.add_body(child_flat, T_world.p, T_world.quat)
+        T_a = T_anchor_pf * T_rel  # pivot in the anchor's link frame
+        T_b = child_flat.T_base_report  # the child's base inertial frame in its base link frame
+        self.constraints.append(([body, -1 if anchor < 0 else anchor, child, -1], [*T_a.p, *T_a.quat, *T_b.p, *T_b.quat, float(max_force), 0.0]))
+        return child
 
     def add_body(self, flat, pos, quat):
         """``pos``/``quat``: pose of the root inertial frame, as passed to
@@ -467,10 +492,13 @@ class SceneBuilder:
         # candidate collision pairs: different bodies, at least one of them able to move,
         # and a narrow-phase routine exists for the pair (no box-box)
         cand, max_contacts, static_pairs = [], 0, 0
+        coupled = {(k[0][0], k[0][2]) for k in self.constraints}
         for a in range(len(shape_i)):
             for c in range(a + 1, len(shape_i)):
                 if shape_i[a][1] == shape_i[c][1] or not (shape_dyn[a] or shape_dyn[c]):
                     continue
+                if (shape_i[a][1], shape_i[c][1]) in coupled or (shape_i[c][1], shape_i[a][1]) in coupled:
+                    continue  # two bodies held together by a fixed constraint
                 if (shape_i[a][7] | shape_i[c][7]) & K.SHAPE_NO_COLLIDE:
                     continue
                 ta, tc = shape_i[a][0], shape_i[c][0]
@@ -525,6 +553,8 @@ class SceneBuilder:
             ('OFF_CAMERA_I', arr([[c[0], c[1], c[2], c[3], c[4]] for c in self.cameras], K.CI_STRIDE, np.int32)),
             ('OFF_OP_I', arr([o[0] for o in self.ops], K.OI_STRIDE, np.int32)),
             ('OFF_ILIST', np.asarray(self.ilist, dtype=np.int32).reshape(-1, 1)),
+            ('OFF_CONS_I', arr([[k[0][0], -1 if k[0][1] < 0 else body_i[k[0][0]][1] + k[0][1], k[0][2], -1 if k[0][3] < 0 else body_i[k[0][2]][1] + k[0][3]]
+                                for k in self.constraints], K.KI_STRIDE, np.int32)),
         ]
         tables_f = [
             ('OFF_BODY_F', arr(body_f, K.BF_STRIDE, np.float64)),
@@ -536,6 +566,7 @@ class SceneBuilder:
             ('OFF_CAMERA_F', arr([[*c[5].p, *c[5].quat, c[6], c[7], c[8], float(np.tan(np.radians(0.5 * c[6]))), 0.0] for c in self.cameras], K.CF_STRIDE, np.float64)),
             ('OFF_OP_F', arr([o[1] for o in self.ops], K.OF_STRIDE, np.float64)),
             ('OFF_FLIST', np.asarray(self.flist, dtype=np.float64).reshape(-1, 1)),
+            ('OFF_CONS_F', arr([k[1] for k in self.constraints], K.KF_STRIDE, np.float64)),
         ]
         H = np.zeros(K.H_INT_COUNT, dtype=np.int32)
         H[K.H_MAGIC] = K.MAGIC
@@ -552,6 +583,7 @@ class SceneBuilder:
         H[K.H_N_OPS] = len(self.ops)
         H[K.H_N_ILIST] = len(self.ilist)
         H[K.H_N_FLIST] = len(self.flist)
+        H[K.H_N_CONSTRAINTS] = len(self.constraints)
         H[K.H_ACT_DIM] = self.dims['act']
         H[K.H_OBS_DIM] = self.dims['obs']
         H[K.H_REW_DIM] = self.dims['rew']

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 10
+#define DG_VERSION 11
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -71,6 +71,9 @@ enum {
   DG_H_OFF_OP_F,
   DG_H_OFF_FLIST,
   DG_H_WARM_OFF,     /* state offset of the contact impulse cache (DG_WS_*), or -1: no warm starting */
+  DG_H_N_CONSTRAINTS,/* fixed constraints between two bodies (child models attached with `attach: constraint`) */
+  DG_H_OFF_CONS_I,
+  DG_H_OFF_CONS_F,
   DG_H_INT_COUNT /* header length in I[] */
 };
 
@@ -112,6 +115,15 @@ enum {
  * which end; hull against a box: the hull vertex index & 63).  A reset clears the count. */
 enum { DG_WS_KEY = 0, DG_WS_NORMAL, DG_WS_T1, DG_WS_T2, DG_WS_STRIDE };
 #define DG_CONTACT_KEY(pair, feature) ((pair) * 64 + ((feature) & 63))
+
+/* ---- fixed constraints (reference model.py:74-75: p.createConstraint(parent, parent_frame, child, child_frame,
+ * JOINT_FIXED, ...)) as SOLVER ROWS: three linear rows along the world axes at the pivot (pulling the pivot on side B onto
+ * the pivot on side A) and three angular rows, bilateral, each bounded by MAX_FORCE x substep; position and orientation
+ * errors are fed back with DG_HF_CONTACT_ERP.  Swept after the joint-limit rows and before the contact rows.  Pivots are
+ * given in the LINK frame of their side (link < 0: the body's base link frame). */
+enum { DG_KI_BODY_A = 0, DG_KI_LINK_A /* global link index or -1 */, DG_KI_BODY_B, DG_KI_LINK_B, DG_KI_STRIDE };
+enum { DG_KF_POS_A = 0, DG_KF_QUAT_A = 3, DG_KF_POS_B = 7, DG_KF_QUAT_B = 10, DG_KF_MAX_FORCE = 14, DG_KF_STRIDE = 16 };
+#define DG_MAX_CONSTRAINTS 4
 
 #define DG_MOTOR_GUESS_REFINE 8
 #define DG_MOTOR_GUESS_MAX 10

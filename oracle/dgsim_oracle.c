@@ -238,7 +238,8 @@ typedef struct {
   int32_t* I; real* F; int64_t ni, nf;
   int nb, nl, nfr, nsh, npairs, nops;
   int act_dim, obs_dim, rew_dim, term_dim, substeps, iters, max_steps, hot_start, ik_iters, state_dim;
-  int addon_off, max_contacts, rew_mode, term_mode, n_term_groups, warm_off;
+  int addon_off, max_contacts, rew_mode, term_mode, n_term_groups, warm_off, ncons;
+  const int32_t* KI; const real* KF; /* fixed constraints (DG_KI_*, DG_KF_*) */
   const int32_t *BI, *LI, *FI, *SI, *PI, *OI, *IL;
   const real *BF, *LF, *FF, *SF, *PF, *OF, *FL;
   real h; v3 g;
@@ -279,6 +280,13 @@ typedef struct {
   real dv[MAXV]; /* solver velocity change: base(6, base coords) + joints */
 } BodyWS;
 
+/* per-thread scratch that outlives the call (the solver rows of one substep are ~0.7 MB: a malloc of that size is an mmap /
+ * munmap pair plus page faults per substep, serialised between the OpenMP threads by the kernel).  Never freed. */
+static void* scratch(int slot, size_t bytes) {
+  static _Thread_local void* buf[4]; static _Thread_local size_t cap[4];
+  if (cap[slot] < bytes) { free(buf[slot]); buf[slot] = malloc(bytes); cap[slot] = bytes; }
+  return buf[slot];
+}
 static real* env_state(dgo_world* w, int e) { return w->state + (size_t)e * w->sc.state_dim; }
 static const int32_t* body_i(const Scene* s, int b) { return s->BI + b * DG_BI_STRIDE; }
 static const real* body_f(const Scene* s, int b) { return s->BF + b * DG_BF_STRIDE; }
@@ -302,6 +310,8 @@ static int parse_scene(Scene* s, const int32_t* I, int64_t ni, const double* F64
   s->hot_start = I[DG_H_HOT_START]; s->ik_iters = I[DG_H_IK_ITERS]; s->state_dim = I[DG_H_STATE_DIM];
   s->addon_off = I[DG_H_ADDON_STATE_OFF]; s->max_contacts = I[DG_H_MAX_CONTACTS];
   s->warm_off = I[DG_H_WARM_OFF];
+  s->ncons = I[DG_H_N_CONSTRAINTS]; s->KI = I + I[DG_H_OFF_CONS_I]; s->KF = F + I[DG_H_OFF_CONS_F];
+  if (s->ncons > DG_MAX_CONSTRAINTS) { set_err("%d fixed constraints > %d", s->ncons, DG_MAX_CONSTRAINTS); return 0; }
   s->rew_mode = I[DG_H_REW_MODE]; s->term_mode = I[DG_H_TERM_MODE]; s->n_term_groups = I[DG_H_N_TERM_GROUPS];
   s->BI = I + I[DG_H_OFF_BODY_I]; s->LI = I + I[DG_H_OFF_LINK_I]; s->FI = I + I[DG_H_OFF_FRAME_I];
   s->SI = I + I[DG_H_OFF_SHAPE_I]; s->PI = I + I[DG_H_OFF_PAIR_I]; s->OI = I + I[DG_H_OFF_OP_I]; s->IL = I + I[DG_H_OFF_ILIST];
@@ -737,6 +747,35 @@ static int make_contact_row(const Scene* s, const real* st, BodyWS* wsb, const C
   return diag > 1e-18;
 }
 
+/* One row of a fixed constraint (reference model.py:74-75, createConstraint(JOINT_FIXED); Bullet btMultiBodyFixedConstraint
+ * [R]): a unit force along world direction `dir` at world point pa on side A and the opposite one at pb on side B
+ * (torque = 0), or a unit torque about `dir` on A and the opposite on B (torque = 1).  Like make_contact_row, the row's
+ * first side is the dynamic one of (A, B). */
+static int make_constraint_row(const Scene* s, const real* st, BodyWS* wsb, const int32_t* ki, v3 pa, v3 pb, v3 dir, int torque, Row* r) {
+  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1; r->body_b = -1;
+  const int ba = ki[DG_KI_BODY_A], bb = ki[DG_KI_BODY_B];
+  BodyWS *A = &wsb[ba], *Bw = &wsb[bb];
+  const int la = ki[DG_KI_LINK_A] < 0 ? -1 : ki[DG_KI_LINK_A] - A->first, lb = ki[DG_KI_LINK_B] < 0 ? -1 : ki[DG_KI_LINK_B] - Bw->first;
+  int a_dyn = !(A->fixed && A->n == 0), b_dyn = !(Bw->fixed && Bw->n == 0);
+  if (!a_dyn && !b_dyn) return 0;
+  real diag = 0, jv = 0; int side = 0;
+  for (int k = 0; k < 2; k++) {
+    BodyWS* W = k == 0 ? A : Bw; if (!(k == 0 ? a_dyn : b_dyn)) continue;
+    const int lk = k == 0 ? la : lb; const v3 d = k == 0 ? dir : vscale(dir, -1.0);
+    s6 f;
+    if (torque) { m3 R; v3 o; link_world(W, lk, &R, &o); f = mk6(mtv(&R, d), V(0, 0, 0)); }
+    else f = point_force(W, lk, k == 0 ? pa : pb, d);
+    real* J = side == 0 ? r->JA : r->JB; real* Rr = side == 0 ? r->RA : r->RB;
+    if (side == 0) r->body_a = k == 0 ? ba : bb; else r->body_b = bb;
+    body_response(W, lk, &f, -1, J, Rr);
+    for (int q = 0; q < 6 + W->n; q++) diag += J[q] * Rr[q];
+    jv += gen_vel_dot(s, st, W, J);
+    side++;
+  }
+  r->diag = diag; r->b = -jv;
+  return diag > 1e-18;
+}
+
 /* one substep of length h for env state st (Bullet btMultiBodyDynamicsWorld::
  * internalSingleStepSimulation order [R]: collide at the current poses, forward
  * dynamics, velocity update, constraint solve, position update) */
@@ -748,8 +787,8 @@ static void substep(dgo_world* w, int env, int last) {
       for (int i = 0; i < bi[DG_BI_N_LINKS]; i++) st[po + i] = st[link_i(s, bi[DG_BI_FIRST_LINK] + i)[DG_LI_STATE_OFF] + DG_LS_QD];
       if (!body_fixed(s, b)) for (int k = 0; k < 6; k++) st[po + bi[DG_BI_N_LINKS] + k] = st[bi[DG_BI_STATE_OFF] + DG_BS_LINVEL + k];
     }
-  BodyWS* wsb = (BodyWS*)malloc(sizeof(BodyWS) * (size_t)s->nb);
-  Row* rows = (Row*)malloc(sizeof(Row) * MAXROWS); int nr = 0;
+  BodyWS* wsb = (BodyWS*)scratch(0, sizeof(BodyWS) * (size_t)s->nb);
+  Row* rows = (Row*)scratch(1, sizeof(Row) * MAXROWS); int nr = 0;
   Contact cs[MAXC];
   for (int b = 0; b < s->nb; b++) { body_kinematics(s, st, b, &wsb[b], NULL); body_velocities(s, st, b, &wsb[b]); }
   int nc = collide(s, wsb, cs); w->last_contacts[env] = nc;
@@ -837,6 +876,29 @@ static void substep(dgo_world* w, int env, int last) {
         r->b = -relv + (dist > 0 ? -dist / h : -dist * erp / h);
         r->lo = 0; r->hi = HUGE_R;
       }
+    }
+  }
+  /* fixed constraints: behind the motor / limit rows (the non-contact rows of btMultiBodyConstraintSolver [R]), before the
+   * contacts.  Errors: the pivot of side B minus the pivot of side A, and the rotation vector that takes A's pivot frame
+   * onto B's (2 x the vector part of qB qA^-1, shorter arc); a fraction DG_HF_CONTACT_ERP of each is corrected per
+   * substep.  Impulses bounded by max_force x h.  Started from zero every substep. */
+  for (int q = 0; q < s->ncons; q++) {
+    const int32_t* ki = s->KI + q * DG_KI_STRIDE; const real* kf = s->KF + q * DG_KF_STRIDE;
+    const real kerp = s->F[DG_HF_CONTACT_ERP], maximp = kf[DG_KF_MAX_FORCE] * h;
+    v3 P[2]; qt Q[2];
+    for (int k = 0; k < 2; k++) {
+      const BodyWS* W = &wsb[ki[k == 0 ? DG_KI_BODY_A : DG_KI_BODY_B]]; const int gl = ki[k == 0 ? DG_KI_LINK_A : DG_KI_LINK_B];
+      m3 R; v3 o; link_world(W, gl < 0 ? -1 : gl - W->first, &R, &o);
+      const real* pp = kf + (k == 0 ? DG_KF_POS_A : DG_KF_POS_B); const real* qq = kf + (k == 0 ? DG_KF_QUAT_A : DG_KF_QUAT_B);
+      P[k] = vadd(o, mv(&R, V(pp[0], pp[1], pp[2])));
+      qt ql = gl < 0 ? W->q0 : qfrom_mat(&R); qt qo = {qq[0], qq[1], qq[2], qq[3]}; Q[k] = qnormalize(qmul(ql, qo));
+    }
+    const v3 perr = vsub(P[1], P[0]);
+    qt qe = qmul(Q[1], qconj(Q[0])); const real sg = qe.w < 0 ? -2.0 : 2.0; const v3 aerr = V(sg * qe.x, sg * qe.y, sg * qe.z);
+    for (int d = 0; d < 6; d++) {
+      const v3 dir = V(d % 3 == 0, d % 3 == 1, d % 3 == 2); Row* r = &rows[nr];
+      if (!make_constraint_row(s, st, wsb, ki, P[0], P[1], dir, d >= 3, r)) continue;
+      r->b += kerp * vdot(d < 3 ? perr : aerr, dir) / h; r->lo = -maximp; r->hi = maximp; nr++;
     }
   }
   /* contacts: all normal rows first, then the friction rows (btMultiBodyConstraintSolver order [R]) */
@@ -936,7 +998,6 @@ static void substep(dgo_world* w, int env, int last) {
       ls[DG_LS_QD] = qd; ls[DG_LS_Q] += h * qd;
     }
   }
-  free(rows); free(wsb);
 }
 
 /* -------------------------------------------------- frames and queries */
@@ -1359,6 +1420,9 @@ static void sim_step(dgo_world* w, int env) {
 
 static int observe_all(dgo_world* w, real* obs, real* rew, uint8_t* term, real* rew_sum, uint8_t* term_flag, int ft_mode, const uint8_t* fresh) {
   Scene* s = &w->sc;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int e = 0; e < w->B; e++)
     run_output_ops(w, e, obs ? obs + (size_t)e * s->obs_dim : NULL, rew ? rew + (size_t)e * s->rew_dim : NULL,
                    term ? term + (size_t)e * s->term_dim : NULL, rew_sum ? rew_sum + e : NULL, term_flag ? term_flag + e : NULL,
@@ -1394,7 +1458,7 @@ int dgo_step(dgo_world* w, const real* actions, uint64_t update_mask, real* obs,
     st[DG_ST_STEP] += 1.0; sim_step(w, 0); e0 = 1;
   }
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 4)
 #endif
   for (int e = e0; e < w->B; e++) {
     real* st = env_state(w, e);

@@ -188,6 +188,38 @@ def test_child_model_is_bolted_to_the_parent_frame():
     assert xyz.shape == (2, 3) and torch.isfinite(xyz).all() and torch.isfinite(quat).all()
 
 
+def test_child_model_held_by_a_fixed_constraint(tmp_path):
+    """``attach: constraint`` -- the reference's own arrangement (model.py:69-77): the child stays a body of its own and
+    createConstraint(JOINT_FIXED) becomes six solver rows.  Holding the rest pose, the gripper is pulled onto the pivot
+    (xyz / rpy in the inertial frame of the parent link) and ends up where the rigidly merged child sits."""
+    from diy_gym_amd.mathx import Transform, mat_from_quat
+    from diy_gym_amd.scene import K
+    env = DIYGym(os.path.join(ROOT, 'tests', 'golden', 'ur5_constrained_gripper.yaml'), num_envs=2, backend_factory=OracleBackend)
+    ref = DIYGym(os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'), num_envs=2, backend_factory=OracleBackend)
+    arm = env.models['arm']; grip = arm.models['gripper']
+    assert env.layout.n_bodies == 2 and env.layout.n_links == 6 + 6 and grip.uid == 1     # a body of its own
+    assert int(env.layout.I[K.H_N_CONSTRAINTS]) == 1 and int(env.layout.I[K.H_N_PAIRS]) == 0   # the two do not collide with each other
+    assert env.action_space['arm']['controller'].shape == (6, )
+    hold = {'arm': {'controller': torch.tensor([[0.3, -1.2, 1.4, -0.6, 0.4, 0.1]] * 2)}}
+    for _ in range(160):
+        env.step(hold); ref.step(hold)
+    pe = env.sim.frame_state64(arm.uid, arm.get_frame_id('ee_fixed_joint'), com=True)
+    pg = env.sim.frame_state64(grip.uid, -1, com=True)
+    rb, _, _, basef = ref.builder.resolve(ref.models['arm'].models['gripper'].uid)
+    pr = ref.sim.frame_state64(rb, basef, com=True)
+    for e in range(2):
+        Te = Transform(mat_from_quat(pe[e][3:7]), pe[e][:3]); Tg = Transform(mat_from_quat(pg[e][3:7]), pg[e][:3])
+        rel = Te.inverse() * Tg
+        assert np.allclose(rel.p, [0.0, 0.0, 0.02], atol=1e-6)
+        assert np.allclose(rel.R, [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-5)
+        assert np.allclose(pg[e][:3], pr[e][:3], atol=2e-5) and abs(abs(np.dot(pg[e][3:7], pr[e][3:7])) - 1.0) < 1e-9 and np.abs(pg[e][7:]).max() < 1e-5
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'tests', 'golden', 'ur5_constrained_gripper.yaml'))); cfg['arm']['gripper']['attach'] = 'glue'
+    yaml.safe_dump(cfg, open(tmp_path / 'glue.yaml', 'w'))
+    with pytest.raises(ValueError):
+        DIYGym(str(tmp_path / 'glue.yaml'), num_envs=1, backend_factory=OracleBackend)
+
+
 def test_child_frame_attaches_the_child_by_that_link(tmp_path):
     """``child_frame`` (reference model.py:71-77): the CHILD LINK of that joint is what gets pinned to the parent frame;
     the rest of the child -- including its URDF root -- hangs from it (the child is re-rooted at that link)."""

@@ -20,6 +20,7 @@ CONFIGS = {
     'admittance': os.path.join(ROOT, 'tests', 'golden', 'ur_admittance.yaml'),
     'gripper': os.path.join(ROOT, 'tests', 'golden', 'ur5_gripper.yaml'),
     'child': os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml'),
+    'constrained': os.path.join(ROOT, 'tests', 'golden', 'ur5_constrained_gripper.yaml'),
     'touching': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching.yaml'),
     'touching_ik': os.path.join(ROOT, 'tests', 'golden', 'ur_arms_touching_ik.yaml'),
     'randomized': os.path.join(ROOT, 'tests', 'golden', 'ur_randomized.yaml'),
@@ -173,6 +174,39 @@ def test_child_model_attached_by_one_of_its_links_40_steps(tmp_path):
     w = rollout(gpu, cpu, 40)
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
     assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
+
+
+def test_child_model_held_by_a_fixed_constraint_40_steps():
+    """``attach: constraint`` (reference model.py:69-77 as written: the child is its own body, p.createConstraint(JOINT_FIXED)
+    couples it to the parent frame): six bilateral solver rows between the UR5's flange and the floating gripper, swept
+    between the limit rows and the contacts.  The constructor's reset teleports the arm to its rest pose and leaves the
+    gripper behind (as resetJointState would), so the rollout starts with the constraint pulling it over at its force limit.
+    Blind to: Bullet's own error feedback / force limit of that constraint (recollection), the child loaded at the pivot."""
+    gpu, cpu = make_pair('constrained', 5)
+    assert gpu.layout.n_bodies == 2
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, 40)
+    assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
+    assert d[:, 1].tolist() == [cpu.sim.iterations(e) for e in range(5)] or abs(int(d[:, 1].max()) - max(cpu.sim.iterations(e) for e in range(5))) <= 150
+
+
+def test_constrained_child_settles_where_the_merged_child_sits():
+    """The stiff limit of the fixed-constraint rows: holding the rest pose, the constrained gripper ends up where the rigidly
+    merged one (tests/golden/ur5_child_gripper.yaml) is, and the arm's joints with it."""
+    from diy_gym_amd import DIYGym
+    soft = DIYGym(CONFIGS['constrained'], num_envs=3, device='cuda:0', seed=5); hard = DIYGym(CONFIGS['child'], num_envs=3, device='cuda:0', seed=5)
+    hold = torch.tensor([[0.3, -1.2, 1.4, -0.6, 0.4, 0.1]] * 3, device='cuda:0')
+    for _ in range(200):
+        soft.sim.step(soft._all_slots, hold); hard.sim.step(hard._all_slots, hold)
+    grip = soft.models['arm'].models['gripper']
+    body, _, _, basef = hard.builder.resolve(hard.models['arm'].models['gripper'].uid)
+    ps = soft.sim.frame_state(grip.uid, -1, com=True).cpu().numpy(); ph = hard.sim.frame_state(body, basef, com=True).cpu().numpy()
+    assert np.abs(ps[:, :3] - ph[:, :3]).max() < 2e-4, np.abs(ps[:, :3] - ph[:, :3]).max()
+    assert np.abs(np.abs((ps[:, 3:7] * ph[:, 3:7]).sum(1)) - 1.0).max() < 1e-6      # same orientation (q and -q are)
+    assert np.abs(ps[:, 7:]).max() < 1e-3      # at rest
+    qs = [soft.sim.get_state()[:, o].copy() for o in soft.layout.link_state_off[:6]]; qh = [hard.sim.get_state()[:, o].copy() for o in hard.layout.link_state_off[:6]]
+    assert np.abs(np.array(qs) - np.array(qh)).max() < 2e-4
 
 
 def test_arms_in_contact_30_steps():

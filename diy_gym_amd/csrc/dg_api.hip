@@ -503,9 +503,11 @@ int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* 
   // so a workgroup should render as many rows as the machine's occupancy allows: about four workgroups per CU over the
   // whole launch -- with >= 1024 envs one workgroup renders a whole image.
   const int W = ci[DG_CI_WIDTH], H = ci[DG_CI_HEIGHT];
+  if (W > 16 * 512) return fail(DG_ERR_UNSUPPORTED, "render: pictures wider than %d pixels are not supported (%d)", 16 * 512, W);  // DG_RTILE_CAP tiles per strip
   int band_rows;
   { const int want_blocks = 4 * std::max(w->cu_count, 1), bands_per_env = std::max(1, (want_blocks + w->num_envs - 1) / w->num_envs);
     band_rows = std::max(8, ((H + bands_per_env - 1) / bands_per_env + 7) / 8 * 8); }
+  if (w->render_diag & 512) band_rows = H;  // (diag 512: one band per picture whatever the batch -- what a batch >= 4 x CUs gets; for tests)
   band_rows = std::min(band_rows, H);
   const int nbands = (H + band_rows - 1) / band_rows;
   const long long blocks = (long long)nbands * w->num_envs;  // the env index is folded into grid.x (grid.y stops at 65535)

@@ -20,12 +20,15 @@ template <int LANES>
 __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, float* state, int ncam, cip CI, cfp CF, float* table, float* gws) {
   extern __shared__ float smem[];
   constexpr int ACTIVE = envs_per_wave(LANES);
-  const int lane = threadIdx.x; if (lane >= ACTIVE) return;
+  // the 64 / ACTIVE lanes that a narrow mode leaves idle per env share the env's shapes: each of them runs the (cheap, serial)
+  // kinematics of the env into the same workspace -- same values, same addresses -- and then takes every (64 / ACTIVE)-th shape
+  constexpr int GROUP = 64 / ACTIVE;
+  const int lane = threadIdx.x % ACTIVE, sub = threadIdx.x / ACTIVE;
   const int env = blockIdx.x * ACTIVE + lane; if (env >= sc.num_envs) return;
   Lane<LANES> ln(sc, mt, workspace_of<LANES>(sc, smem, gws, lane), state + env, env, false);
   for (int b = 0; b < sc.nba; b++) ln.kinematics(b);
   float* out = table + (size_t)env * (sc.nsh * RS_STRIDE + ncam * RC_STRIDE);
-  for (int sh = 0; sh < sc.nsh; sh++) {
+  for (int sh = sub; sh < sc.nsh; sh += GROUP) {
     WShape w; shape_world(ln, sh, w); cip si = sc.SI + sh * DG_SI_STRIDE; float* o = out + sh * RS_STRIDE;
     M3 R = w.R; V3 p = w.p; float bound;
     if (w.type == DG_SHAPE_POINTS) {  // hull planes live in the link frame (or the world for a frozen body)
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(64) void pose_kernel(DevScene sc, MotorTable mt, fl
     { const int co = ln.bi(w.body)[DG_BI_COLOR_OFF]; cfp sc3 = sc.SF + sh * DG_SF_STRIDE + DG_SF_COLOR;  // per-env texture of a visual_randomizer, else the shape's own colour, flat
       _Pragma("unroll") for (int k = 0; k < DG_TX_STRIDE; k++) o[RS_COLOR + k] = co >= 0 ? ln.S(co + k) : (k < 6 ? sc3[k % 3] : (k == DG_TX_FREQ ? 1.f : (float)DG_TEX_FLAT)); }
   }
-  for (int c = 0; c < ncam; c++) {
+  for (int c = sub; c < ncam; c += GROUP) {
     cip ci = CI + c * DG_CI_STRIDE; cfp cf = CF + c * DG_CF_STRIDE;
     M3 Rp = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; V3 pp = v3(0.f, 0.f, 0.f);
     if (ci[DG_CI_BODY] >= 0) { V3 v, w; Q4 q; ln.frame_state(ci[DG_CI_BODY], ci[DG_CI_FRAME], ci[DG_CI_FRAME] < 0, pp, q, v, w, false); Rp = qmat(q); }
@@ -130,15 +133,20 @@ DGD void ray_hull(V3 o, V3 d, const M3& Rl, V3 pl, cfp planes, int np, RayHit& h
 __device__ unsigned long long g_render_count[16];  // diagnostic build-in counters (DG_RENDER_DIAG & 16), read by dg_debug_render_counters
 #ifdef DG_RENDER_COUNTERS  /* make CXXFLAGS+=-DDG_RENDER_COUNTERS: per-stage candidate counts for tools/gpu_cam_bench.py */
 #define DG_RCOUNT(k) do { if ((diag & 16) && lane == 0) atomicAdd(&g_render_count[k], 1ull); } while (0)
+#define DG_RTIME(k, t0) do { if ((diag & 16) && lane == 0) atomicAdd(&g_render_count[k], (unsigned long long)(__builtin_amdgcn_s_memtime() - (t0))); } while (0)
+#define DG_RNOW() __builtin_amdgcn_s_memtime()
 #else
 #define DG_RCOUNT(k) do { } while (0)
+#define DG_RTIME(k, t0) do { } while (0)
+#define DG_RNOW() 0ull
 #endif
 #define DG_RL_CAP 96     /* list entries per band */
 #define DG_RP_CAP 1024   /* hull faces per band   */
 #define DG_RT_CAP 1024   /* hull points / box corners per band */
-#define DG_RS_CAP 160    /* strips of eight rows per band (taller bands: their further strips are not culled as a whole) */
-enum { RL_V = 0 /* centre - eye */, RL_BOUND = 3, RL_R = 4, RL_P = 13, RL_PRM = 16, RL_STRIDE = 20 };  // floats per entry; ints alongside
-enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_NOUT /* faces with the eye on their outer side: stored first */, RLI_STRIDE };
+#define DG_RS_CAP 64     /* strips of eight rows per chunk */
+#define DG_RTILE_CAP 512  /* 16 x 8 tiles per chunk of strips */
+enum { RL_V = 0 /* centre - eye */, RL_BOUND = 3, RL_R = 4, RL_P = 13, RL_PRM = 16, RL_TEX = 20 /* DG_TX_*: the shape's colours / texture in this env */, RL_STRIDE = 28 };  // floats per entry; ints alongside
+enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_OFF, RLI_NPT, RLI_NOUT /* faces with the eye on their outer side: stored first */, RLI_SEG /* the shape's segmentation value */, RLI_STRIDE };
 // Two rays (the lane's two pixels) against one convex hull whose faces are (world normal n, s = signed distance of the
 // eye), the `nout` faces with the eye on their OUTER side (s > 0) first.  The ray eye + t d crosses a face at
 // t = -s / (n . d).  A ray can only ENTER through an outer-side face it approaches (n . d < 0); an outer-side face it
@@ -146,6 +154,9 @@ enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_
 // and most misses, and the second pass (the other faces: exit = the earliest crossing with n . d > 0) is skipped by
 // the whole wavefront when no ray is still in play.  Same arithmetic and the same entry face as a single loop over
 // the faces in their original order (the partition is stable).
+// The first pass ends as soon as every ray of the wavefront has missed.  (Seeding `miss` with the per-ray bounding-sphere test
+// was tried: the face planes of a thinned hull reach a hair beyond the sphere around its points, and single silhouette pixels
+// then differ from the brute-force picture.)
 DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int np, RayHit (&h)[2], int sh) {
   float tn[2] = {-3.0e38f, -3.0e38f}, tf[2] = {3.0e38f, 3.0e38f}; int kn[2] = {0, 0}; bool miss[2] = {np == 0, np == 0};
   // (four faces per round, their LDS reads issued together: one face at a time the loop waits a whole LDS round trip per face)
@@ -164,6 +175,7 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
         const bool later = ok && front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k0 + j : kn[u];
       }
     }
+    if (!__any(!miss[0] || !miss[1])) return;
   }
   bool alive[2];
 #pragma unroll
@@ -187,6 +199,54 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
 #pragma unroll
   for (int u = 0; u < 2; u++) if (alive[u] && !(tn[u] > tf[u])) { h[u].t = tn[u]; h[u].n = v3(pl[kn[u]][0], pl[kn[u]][1], pl[kn[u]][2]); h[u].shape = sh; }
 }
+// colour of a pixel whose ray (direction d) hit at h: Lambert factor x the shape's colour / procedural texture; e = rotation (9),
+// position (3) and texture (DG_TX_*) of the shape that was hit
+DGD void shade_pixel(V3 pc, const RayHit& h, V3 d, const float* e, float (&col)[3]) {
+  const float* tx = e + 12;
+  const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
+  float t = 0.f; const int kind = (int)tx[DG_TX_KIND];
+  if (kind != DG_TEX_FLAT) {  // procedural texture in the shape's reference frame (DG_TX_* in diygym_scene.h)
+    M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[q];
+    const V3 pl = tmul(R, (pc + d * h.t) - v3(e[9], e[10], e[11])); const float fr = tx[DG_TX_FREQ];
+    const int ux = (int)floorf(pl.x * fr), uy = (int)floorf(pl.y * fr), uz = (int)floorf(pl.z * fr);
+    if (kind == DG_TEX_CHECKER) t = ((ux + uy + uz) & 1) ? 1.f : 0.f;
+    else if (kind == DG_TEX_STRIPES) t = (ux & 1) ? 1.f : 0.f;
+    else { uint32_t hh; DG_TEX_HASH(ux, uy, uz, hh); t = (float)hh * (1.0f / 16777216.0f); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) col[k] = (tx[DG_TX_A + k] + (tx[DG_TX_B + k] - tx[DG_TX_A + k]) * t) * shd;
+}
+
+// More survivors than the band's list holds (a maze seen from above: 130 shapes in view): every pixel of the band against
+// every shape, straight from the tables -- as slow as it is general.  A function of its own, not inlined: inside the kernel its
+// registers counted against the tile loop (19 spilled registers there, whose scratch reloads cost a third of the kernel's time).
+__device__ __noinline__ void render_band_slow(cip SI, cfp SF, int nsh, cfp tb, cfp PLN, V3 pc, V3 rayA, V3 rayB, V3 rayC, int W, int H, int r0, int npx, float zn, float zf,
+                                              int env, int diag, int tid, float* rgb, float* depth, int32_t* seg) {
+  const float inv_w = 1.0f / (float)W;
+  for (int p = tid; p < npx; p += 256) {
+    int row = (int)(((float)p + 0.5f) * inv_w), col = p - row * W; if (col < 0) { row--; col += W; } else if (col >= W) { row++; col -= W; } row += r0;
+    const V3 d = rayA + rayB * (col + 0.5f) + rayC * (row + 0.5f);
+    RayHit h; h.t = zf; h.shape = -1; h.n = v3(0.f, 0.f, 1.f); h.tmin = (diag & 32) ? 1e-30f : zn;
+    if (!(diag & 2)) for (int k = 0; k < nsh; k++) {
+      cfp s = tb + k * RS_STRIDE; cip si = SI + k * DG_SI_STRIDE; cfp sf = SF + k * DG_SF_STRIDE; const int type = si[DG_SI_TYPE];
+      M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = s[RS_R + q];
+      const V3 pp = v3(s[RS_P], s[RS_P + 1], s[RS_P + 2]);
+      if (type == DG_SHAPE_SPHERE) ray_sphere(pc, d, pp, sf[DG_SF_PARAMS], h, k);
+      else if (type == DG_SHAPE_BOX) ray_box(pc, d, R, pp, sf[DG_SF_PARAMS], sf[DG_SF_PARAMS + 1], sf[DG_SF_PARAMS + 2], h, k);
+      else if (type == DG_SHAPE_CAPSULE) { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * sf[DG_SF_PARAMS + 1]; ray_capsule(pc, d, pp - ax, pp + ax, sf[DG_SF_PARAMS], h, k); }
+      else if (!(diag & 4)) ray_hull(pc, d, R, pp, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], h, k);
+    }
+    const bool hit = h.shape >= 0; const size_t o = (size_t)env * W * H + (size_t)row * W + col;
+    if (depth) depth[o] = hit ? -h.t : -zf;
+    if (seg) { int v = -1; if (hit) { cip si = SI + h.shape * DG_SI_STRIDE; v = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); } seg[o] = v; }
+    if (rgb) {
+      float colr[3] = {0.75f, 0.75f, 0.75f};
+      if (hit) { float eb[12 + DG_TX_STRIDE]; cfp e = tb + h.shape * RS_STRIDE; _Pragma("unroll") for (int q = 0; q < 12; q++) eb[q] = e[RS_R + q]; _Pragma("unroll") for (int q = 0; q < DG_TX_STRIDE; q++) eb[12 + q] = e[RS_COLOR + q]; shade_pixel(pc, h, d, eb, colr); }
+      rgb[3 * o] = colr[0]; rgb[3 * o + 1] = colr[1]; rgb[3 * o + 2] = colr[2];
+    }
+  }
+}
+
 // WPE: wavefronts per SIMD the register allocation is held to (216 registers fit 2; 3 spills 41 of them -- measured)
 template <int WPE>
 __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, cfp CF, cfp PLN, int cam, int ncam, cfp table, float* rgb, float* depth, int32_t* seg,
@@ -224,6 +284,7 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
   };
   const float inv_w = 1.0f / (float)W;
   auto row_col = [&](int p, int& row, int& col) { row = (int)(((float)p + 0.5f) * inv_w); col = p - row * W; if (col < 0) { row--; col += W; } else if (col >= W) { row++; col -= W; } };
+  const unsigned long long t_start = DG_RNOW(); (void)t_start;
   // ---------------- phase A: the band's list
   int total = 0, total_planes = 0, total_points = 0;
   {
@@ -249,6 +310,8 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
           _Pragma("unroll") for (int q = 0; q < 9; q++) o[RL_R + q] = s[RS_R + q];
           o[RL_P] = s[RS_P]; o[RL_P + 1] = s[RS_P + 1]; o[RL_P + 2] = s[RS_P + 2];
           o[RL_PRM] = sf[DG_SF_PARAMS]; o[RL_PRM + 1] = sf[DG_SF_PARAMS + 1]; o[RL_PRM + 2] = sf[DG_SF_PARAMS + 2];
+          _Pragma("unroll") for (int q = 0; q < DG_TX_STRIDE; q++) o[RL_TEX + q] = s[RS_COLOR + q];
+          s_i[idx][RLI_SEG] = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24);
           s_i[idx][RLI_TYPE] = si[DG_SI_TYPE]; s_i[idx][RLI_SHAPE] = sh; s_i[idx][RLI_NP] = si[DG_SI_TYPE] == DG_SHAPE_POINTS ? si[DG_SI_N_PLANES] : (si[DG_SI_TYPE] == DG_SHAPE_BOX ? 6 : 0); s_i[idx][RLI_PLANE_OFF] = 0;
           s_i[idx][RLI_NPT] = si[DG_SI_TYPE] == DG_SHAPE_POINTS ? si[DG_SI_N_POINTS] : (si[DG_SI_TYPE] == DG_SHAPE_BOX ? 8 : 0); s_i[idx][RLI_PT_OFF] = 0;
         }
@@ -270,7 +333,8 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
     }
   }
   const bool overflow = total > DG_RL_CAP || total_planes > DG_RP_CAP || total_points > DG_RT_CAP;  // (then: the slow path below, straight from the tables)
-  if (!overflow) {
+  if (overflow) { render_band_slow(sc.SI, sc.SF, sc.nsh, tb, PLN, pc, rayA, rayB, rayC, W, H, r0, npx, zn, zf, env, diag, tid, rgb, depth, seg); return; }
+  {
     // faces of the surviving hulls and boxes -> (world normal, signed distance of the eye); one wavefront per entry at a time
     // A point w (relative to the eye) at depth z = -rc2 . w > 0 is seen by the ray of pixel coordinates
     // c = (x / z + kx) / sx, r = (y / z - th) / sy; a convex shape wholly in front of the eye projects inside the box of
@@ -351,9 +415,10 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
     }
     __syncthreads();
   }
+  if (wv == 0) DG_RTIME(4, t_start);  // [4] phase A, wavefront 0
   struct Px { V3 d; float idd; RayHit h; int row, col; bool inside; };
   Px px[2];
-  const int n_entries = overflow ? sc.nsh : total;
+  const int n_entries = total;
   // ---------------- phase B: a STRIP of eight full image rows per wavefront at a time, 16 x 8 tiles inside it (lane: column
   // lane & 15, rows lane >> 4 and (lane >> 4) + 4).  The strip comes first: its list is culled once against the strip's
   // cone, frustum and separating faces (the tests a tile makes, 13 times less often), the tiles then only look at the
@@ -362,15 +427,26 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
   const bool wide = (W & 3) == 0 && !(diag & 64);  // every 4-pixel piece of a row is 16-byte aligned (diag 64: scalar stores, for tests)
   const int ntx = (W + 15) >> 4, nstrips = (nrows + 7) >> 3;
   const size_t img = (size_t)env * W * H;
-  // B1: every wavefront culls the list for its strips (masks into LDS) and fills the strips that come out empty;
-  // B2: the tiles of the other strips go through a queue (an LDS counter): the wavefront that is free takes the next tile, so
-  //     a picture whose content sits in a few strips -- a hand in a corner of the sky -- is spread over all four.
-  __shared__ unsigned long long s_smask[DG_RS_CAP][2]; __shared__ int s_next_tile;
-  if (tid == 0) s_next_tile = 0;
-  for (int strip = wv; strip < nstrips; strip += 4) {
-    const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
+  // The strips are taken DG_RTILE_CAP tiles at a time (whole strips; a 200 x 200 picture is one such chunk).  Per chunk:
+  // B1a: a wavefront per strip culls the band's list against the strip (cone, image-space boxes, separating faces, frustum);
+  // B1b: a THREAD per 16 x 8 tile narrows its strip's mask with the tile's own cone and rectangle -- the tile's candidates;
+  // B1c: a wavefront per strip writes the background of every tile that has none: a strip without any -- most of a picture of
+  //      the sky -- is one contiguous piece of each output image; in the others the empty tiles' pieces of each row, as
+  //      16-byte stores either way;
+  // B2:  the tiles that do have candidates go through a queue (an LDS counter): the wavefront that is free takes the next one,
+  //      so a picture whose content sits in a few tiles -- a hand in a corner of the sky -- is spread over all four.
+  __shared__ unsigned long long s_smask[DG_RS_CAP][2]; __shared__ unsigned long long s_tmask[DG_RTILE_CAP][2];
+  __shared__ int s_queue[DG_RTILE_CAP]; __shared__ int s_nq, s_next_tile;
+  const int spc = max(1, min((int)DG_RS_CAP, (int)DG_RTILE_CAP / ntx));  // strips per chunk (dg_world_render refuses pictures wider than 16 DG_RTILE_CAP)
+  const bool tile_cull = !no_cull && !(diag & 128);  // (diag 128: no strip / tile level culling, every tile looks at the whole list)
+  const float4 bg_d = make_float4(-zf, -zf, -zf, -zf), bg_c = make_float4(0.75f, 0.75f, 0.75f, 0.75f); const int4 bg_s = make_int4(-1, -1, -1, -1);
+  for (int s0 = 0; s0 < nstrips; s0 += spc) {
+  const int ns = min(spc, nstrips - s0), ntl = ns * ntx;
+  if (tid == 0) { s_nq = 0; s_next_tile = 0; }
+  for (int ls = wv; ls < ns; ls += 4) {
+    const int q0 = r0 + 8 * (s0 + ls), qn = min(8, r0 + nrows - q0);  // rows [q0, q0 + qn)
     unsigned long long smask[2] = {~0ull, ~0ull};  // the strip's candidates among the band's list (entries 0..63, 64..127)
-    if (!overflow && !(diag & 128)) {  // (diag 128: no strip-level culling, every tile looks at the whole list)
+    if (tile_cull) {
       V3 saxis; float scos, ssin; cone_of(0.f, (float)W, (float)q0, (float)(q0 + qn), saxis, scos, ssin);
       const V3 eL = rayA, eR = rayA + rayB * (float)W, eT = rayA + rayC * (float)q0, eB = rayA + rayC * (float)(q0 + qn);
       V3 nL = cross(eL, rayC), nR = cross(eR, rayC), nT = cross(eT, rayB), nB = cross(eB, rayB);
@@ -382,10 +458,10 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       for (int base = 0; base < total; base += 64) {
         const int j = min(base + lane, total - 1);
         const V3 ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); const float eb = s_f[j][RL_BOUND];
-        const bool boxed = no_cull || (s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
-        const bool cand = base + lane < total && boxed && (no_cull || cone_pass(ev, eb, saxis, scos, ssin)) && s_i[j][RLI_TYPE] >= 0;
+        const bool boxed = s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn);
+        const bool cand = base + lane < total && boxed && cone_pass(ev, eb, saxis, scos, ssin) && s_i[j][RLI_TYPE] >= 0;
         unsigned long long keep = __ballot(cand);
-        if (!no_cull) for (unsigned long long mm = keep; mm; mm &= mm - 1) {
+        for (unsigned long long mm = keep; mm; mm &= mm - 1) {
           const int bit = __ffsll((long long)mm) - 1, jj = base + bit, type = s_i[jj][RLI_TYPE];  // wave-uniform
           if (type != DG_SHAPE_BOX && type != DG_SHAPE_POINTS) continue;
           const int po = s_i[jj][RLI_PLANE_OFF], nout = s_i[jj][RLI_NOUT]; bool sep = false;
@@ -400,33 +476,76 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
         }
         smask[base >> 6] = keep;
       }
-      if (!(smask[0] | smask[1]) || (diag & 2)) {  // nothing in sight: the strip's rows are one contiguous piece of every image
-        const size_t o0 = img + (size_t)q0 * W; const int count = qn * W;
-        if (wide) {
-          const float4 dz = make_float4(-zf, -zf, -zf, -zf), bg = make_float4(0.75f, 0.75f, 0.75f, 0.75f); const int4 sgm = make_int4(-1, -1, -1, -1);
-          if (depth) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<float4*>(depth + o0)[i] = dz;
-          if (seg) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<int4*>(seg + o0)[i] = sgm;
-          if (rgb) for (int i = lane; i < 3 * count / 4; i += 64) reinterpret_cast<float4*>(rgb + 3 * o0)[i] = bg;
-        } else {
-          if (depth) for (int i = lane; i < count; i += 64) depth[o0 + i] = -zf;
-          if (seg) for (int i = lane; i < count; i += 64) seg[o0 + i] = -1;
-          if (rgb) for (int i = lane; i < 3 * count; i += 64) rgb[3 * o0 + i] = 0.75f;
-        }
-        smask[0] = smask[1] = 0ull;
-      }
     }
-    if (lane == 0 && strip < DG_RS_CAP) { s_smask[strip][0] = smask[0]; s_smask[strip][1] = smask[1]; }
+    if (lane == 0) { s_smask[ls][0] = smask[0]; s_smask[ls][1] = smask[1]; }
   }
   __syncthreads();
+  for (int t = tid; t < ntl; t += 256) {  // B1b
+    const int ls = t / ntx, txi = t - ls * ntx, q0 = r0 + 8 * (s0 + ls), qn = min(8, r0 + nrows - q0), c0 = txi << 4, c1 = min(c0 + 16, W);
+    unsigned long long m[2] = {s_smask[ls][0], s_smask[ls][1]};
+    if (tile_cull && (m[0] | m[1])) {
+      V3 axis; float cos_t, sin_t; cone_of((float)c0, (float)c1, (float)q0, (float)(q0 + qn), axis, cos_t, sin_t);
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) for (unsigned long long mm = m[hf]; mm; mm &= mm - 1) {
+        const int bit = __ffsll((long long)mm) - 1, j = 64 * hf + bit;
+        const bool boxed = s_bb[j][1] >= (float)c0 && s_bb[j][0] <= (float)c1 && s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn);
+        if (!(boxed && cone_pass(v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]), s_f[j][RL_BOUND], axis, cos_t, sin_t))) m[hf] &= ~(1ull << bit);
+      }
+    }
+    if (diag & 2) m[0] = m[1] = 0ull;  // (diag 2: no intersections at all, every tile is background)
+    s_tmask[t][0] = m[0]; s_tmask[t][1] = m[1];
+    if (m[0] | m[1]) s_queue[atomicAdd(&s_nq, 1)] = t;
+  }
+  __syncthreads();
+  for (int ls = wv; ls < ns; ls += 4) {  // B1c
+    const int q0 = r0 + 8 * (s0 + ls), qn = min(8, r0 + nrows - q0); const size_t o0 = img + (size_t)q0 * W;
+    bool some = false; for (int x = lane; x < ntx; x += 64) some = some || (s_tmask[ls * ntx + x][0] | s_tmask[ls * ntx + x][1]) != 0ull;
+    if (!__any(some)) {  // nothing in sight: the strip's rows are one contiguous piece of every image
+      const int count = qn * W;
+      if (wide) {
+        if (depth) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<float4*>(depth + o0)[i] = bg_d;
+        if (seg) for (int i = lane; i < count / 4; i += 64) reinterpret_cast<int4*>(seg + o0)[i] = bg_s;
+        if (rgb) for (int i = lane; i < 3 * count / 4; i += 64) reinterpret_cast<float4*>(rgb + 3 * o0)[i] = bg_c;
+      } else {
+        if (depth) for (int i = lane; i < count; i += 64) depth[o0 + i] = -zf;
+        if (seg) for (int i = lane; i < count; i += 64) seg[o0 + i] = -1;
+        if (rgb) for (int i = lane; i < 3 * count; i += 64) rgb[3 * o0 + i] = 0.75f;
+      }
+    } else if (wide) {  // the empty tiles' pieces of each row (a tile is 16 pixels wide: 4 pieces of a depth row, 12 of an rgb row)
+      for (int pc4 = lane; pc4 < W / 4; pc4 += 64) {
+        const int x = pc4 >> 2; if (s_tmask[ls * ntx + x][0] | s_tmask[ls * ntx + x][1]) continue;
+        for (int r = 0; r < qn; r++) {
+          if (depth) reinterpret_cast<float4*>(depth + o0 + (size_t)r * W)[pc4] = bg_d;
+          if (seg) reinterpret_cast<int4*>(seg + o0 + (size_t)r * W)[pc4] = bg_s;
+        }
+      }
+      if (rgb) for (int pc4 = lane; pc4 < 3 * W / 4; pc4 += 64) {
+        const int x = (pc4 * 43691) >> 19;  // pc4 / 12 (exact below 10 922)
+        if (s_tmask[ls * ntx + x][0] | s_tmask[ls * ntx + x][1]) continue;
+        for (int r = 0; r < qn; r++) reinterpret_cast<float4*>(rgb + 3 * (o0 + (size_t)r * W))[pc4] = bg_c;
+      }
+    } else {
+      for (int c = lane; c < W; c += 64) {
+        const int x = c >> 4; if (s_tmask[ls * ntx + x][0] | s_tmask[ls * ntx + x][1]) continue;
+        for (int r = 0; r < qn; r++) {
+          const size_t o = o0 + (size_t)r * W + c;
+          if (depth) depth[o] = -zf;
+          if (seg) seg[o] = -1;
+          if (rgb) { rgb[3 * o] = 0.75f; rgb[3 * o + 1] = 0.75f; rgb[3 * o + 2] = 0.75f; }
+        }
+      }
+    }
+  }
+  const int nq = s_nq;
+  if (wv == 0) { DG_RTIME(6, t_start); if ((diag & 16) && lane == 0) atomicAdd(&g_render_count[8], (unsigned long long)nq); }  // [6] up to the end of B1 (cumulative), [8] queued tiles
+  const unsigned long long t_b2 = DG_RNOW(); (void)t_b2;
   for (;;) {
-    int tile = 0; if (lane == 0) tile = atomicAdd(&s_next_tile, 1);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    if (tile >= nstrips * ntx) break;
-    const int strip = tile / ntx, txi = tile - strip * ntx;
-    const int q0 = r0 + 8 * strip, qn = min(8, r0 + nrows - q0);
-    unsigned long long smask[2] = {~0ull, ~0ull};
-    if (strip < DG_RS_CAP) { smask[0] = s_smask[strip][0]; smask[1] = s_smask[strip][1]; }
-    if (!overflow && !(diag & 128) && !(smask[0] | smask[1])) continue;  // (an empty strip: filled in B1)
+    int qi = 0; if (lane == 0) qi = atomicAdd(&s_next_tile, 1);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+    if (qi >= nq) break;
+    const int tile = s_queue[qi], ls = tile / ntx, txi = tile - ls * ntx;
+    const int q0 = r0 + 8 * (s0 + ls), qn = min(8, r0 + nrows - q0);
+    const unsigned long long tm[2] = {s_tmask[tile][0], s_tmask[tile][1]};
   {
     const int c0 = txi << 4;  // tile: columns [c0, c0 + 16) of the strip
     V3 axis; float cos_t, sin_t;
@@ -449,16 +568,11 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
     }
     for (int base = 0; base < n_entries; base += 64) {
       const int j = min(base + lane, n_entries - 1);
-      V3 ev; float eb;  // culling data of entry j: from the band's list, or (overflow) straight from the table
-      if (!overflow) { ev = v3(s_f[j][RL_V], s_f[j][RL_V + 1], s_f[j][RL_V + 2]); eb = s_f[j][RL_BOUND]; }
-      else { cfp s = tb + j * RS_STRIDE; ev = v3(s[RS_C], s[RS_C + 1], s[RS_C + 2]) - pc; eb = s[RS_BOUND]; }
-      // the entry's image-space box against the tile's rectangle first (four compares), then the sphere-cone test
-      const bool boxed = overflow || no_cull || (s_bb[j][1] >= (float)c0 && s_bb[j][0] <= (float)min(c0 + 16, W) && s_bb[j][3] >= (float)q0 && s_bb[j][2] <= (float)(q0 + qn));
-      const bool cand = base + lane < n_entries && boxed && (overflow || ((smask[(base >> 6) & 1] >> lane) & 1ull)) && (no_cull || cone_pass(ev, eb, axis, cos_t, sin_t)) && (overflow || s_i[j][RLI_TYPE] >= 0);
-      for (unsigned long long mm = (diag & 2) ? 0ull : __ballot(cand); mm; mm &= mm - 1) {
+      const bool cand = base + lane < n_entries && ((tm[(base >> 6) & 1] >> lane) & 1ull) && s_i[j][RLI_TYPE] >= 0;  // the tile's candidates: its mask of B1b
+      for (unsigned long long mm = __ballot(cand); mm; mm &= mm - 1) {
         const int jj = base + __ffsll((long long)mm) - 1;  // wave-uniform
-        if (!overflow) {
-          const float* e = s_f[jj]; const int type = s_i[jj][RLI_TYPE], k = s_i[jj][RLI_SHAPE];
+        {
+          const float* e = s_f[jj]; const int type = s_i[jj][RLI_TYPE], k = jj;  // (a hit remembers the LIST entry: what the pixel's colour needs is in LDS too)
           DG_RCOUNT(type);  // 0..3: candidates after the sphere-cone test, by type
           const V3 oc = v3(e[RL_V], e[RL_V + 1], e[RL_V + 2]); const float bound = e[RL_BOUND];
           if ((type == DG_SHAPE_BOX || type == DG_SHAPE_POINTS) && !no_cull) {
@@ -477,17 +591,17 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
             if (npt > 0 && (!__any(inL) || !__any(inR) || !__any(inT) || !__any(inB))) continue;
             DG_RCOUNT(8 + type);  // after the frustum test
           }
+          bool far[2] = {false, false};  // the ray passes the entry's bounding sphere by
           if (type != DG_SHAPE_BOX && !no_cull) {  // per-pixel bounding-sphere test before anything else
-            bool nr = false;
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const float tc = dot(oc, px[u].d) * px[u].idd; const V3 qv = oc - px[u].d * tc; nr = nr || dot(qv, qv) <= bound * bound; }
-            if (!__any(nr)) continue;
+            for (int u = 0; u < 2; u++) { const float tc = dot(oc, px[u].d) * px[u].idd; const V3 qv = oc - px[u].d * tc; far[u] = !(dot(qv, qv) <= bound * bound); }
+            if (!__any(!far[0] || !far[1])) continue;
           }
           DG_RCOUNT(12 + type);  // intersected
           if (type == DG_SHAPE_POINTS) {
             if (!(diag & 4)) { const int po = s_i[jj][RLI_PLANE_OFF], np = s_i[jj][RLI_NP], nout = s_i[jj][RLI_NOUT];
               const V3 dd[2] = {px[0].d, px[1].d}; RayHit hh[2] = {px[0].h, px[1].h};
-              ray_hull_world2(dd, &s_pl[po], nout, np, hh, k); px[0].h = hh[0]; px[1].h = hh[1]; }
+              ray_hull_world2(dd, &s_pl[po], nout, np, hh, k); if (!(diag & 1024)) { px[0].h = hh[0]; px[1].h = hh[1]; } }  // (diag 1024: intersected, result dropped -- timing)
             continue;
           }
           M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[RL_R + q];
@@ -498,43 +612,35 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
             else if (type == DG_SHAPE_BOX) ray_box(pc, px[u].d, R, pp, p0, p1, p2, px[u].h, k);
             else { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * p1; ray_capsule(pc, px[u].d, pp - ax, pp + ax, p0, px[u].h, k); }
           }
-        } else {  // more survivors than the list holds (never seen): everything from the tables, as slow as it is general
-          const int k = jj; cfp s = tb + k * RS_STRIDE; cip si = sc.SI + k * DG_SI_STRIDE; cfp sf = sc.SF + k * DG_SF_STRIDE; const int type = si[DG_SI_TYPE];
-          M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = s[RS_R + q];
-          const V3 pp = v3(s[RS_P], s[RS_P + 1], s[RS_P + 2]);
-#pragma unroll
-          for (int u = 0; u < 2; u++) {
-            if (type == DG_SHAPE_SPHERE) ray_sphere(pc, px[u].d, pp, sf[DG_SF_PARAMS], px[u].h, k);
-            else if (type == DG_SHAPE_BOX) ray_box(pc, px[u].d, R, pp, sf[DG_SF_PARAMS], sf[DG_SF_PARAMS + 1], sf[DG_SF_PARAMS + 2], px[u].h, k);
-            else if (type == DG_SHAPE_CAPSULE) { const V3 ax = v3(R.m[2], R.m[5], R.m[8]) * sf[DG_SF_PARAMS + 1]; ray_capsule(pc, px[u].d, pp - ax, pp + ax, sf[DG_SF_PARAMS], px[u].h, k); }
-            else ray_hull(pc, px[u].d, R, pp, PLN + 4 * si[DG_SI_PLANE_OFF], si[DG_SI_N_PLANES], px[u].h, k);
-          }
         }
       }
     }
-    // ---- the tile's pixels out (staging them through LDS into 16-byte stores was measured: no gain, and the 10 KB of LDS cost a
-    // workgroup per CU -- the stores are not what this kernel waits for)
+    if (wide && !__any(px[0].h.shape >= 0 || px[1].h.shape >= 0)) {  // every ray missed after all: the tile's background as 16-byte stores
+      const int np4 = (min(c0 + 16, W) - c0) >> 2;
+      { const int r = lane >> 2, pcx = lane & 3;
+        if (r < qn && pcx < np4) {
+          const size_t o = img + (size_t)(q0 + r) * W + c0;
+          if (depth) reinterpret_cast<float4*>(depth + o)[pcx] = bg_d;
+          if (seg) reinterpret_cast<int4*>(seg + o)[pcx] = bg_s;
+        } }
+      if (rgb) { const int sr = (lane * 43691) >> 19, pcx = lane - 12 * sr;  // lane / 12: four rows at a time, 12 pieces each
+        if (sr < 4 && pcx < 3 * np4) for (int r = sr; r < qn; r += 4) reinterpret_cast<float4*>(rgb + 3 * (img + (size_t)(q0 + r) * W + c0))[pcx] = bg_c; }
+      continue;
+    }
     float vdepth[2]; int vsegm[2]; float vcol[2][3];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const RayHit& h = px[u].h;
       const bool hit = h.shape >= 0;
       vdepth[u] = hit ? -h.t : -zf; vsegm[u] = -1; vcol[u][0] = vcol[u][1] = vcol[u][2] = 0.75f;
-      if (seg && hit) { cip si = sc.SI + h.shape * DG_SI_STRIDE; vsegm[u] = si[DG_SI_BODY] + (((si[DG_SI_FLAGS] >> 8) & 0xFFFF) << 24); }
+      // (no global LOAD in this phase -- the first one would wait for every background store the wavefront issued in B1c: the
+      // colours of the shape that was hit come from its list entry)
+      if (seg && hit) vsegm[u] = s_i[h.shape][RLI_SEG];
       if (rgb && hit) {
-        cfp e = tb + h.shape * RS_STRIDE; cfp tx = e + RS_COLOR;  // per-lane index: vector loads from the env's table
-        const float nl = h.n.x * 0.30151134457776363f + h.n.y * 0.30151134457776363f + h.n.z * 0.9045340337332909f, shd = 0.4f + 0.6f * fmaxf(nl, 0.f);
-        float t = 0.f; const int kind = (int)tx[DG_TX_KIND];
-        if (kind != DG_TEX_FLAT) {  // procedural texture in the shape's reference frame (DG_TX_* in diygym_scene.h)
-          M3 R; _Pragma("unroll") for (int q = 0; q < 9; q++) R.m[q] = e[RS_R + q];
-          const V3 pl = tmul(R, (pc + px[u].d * h.t) - v3(e[RS_P], e[RS_P + 1], e[RS_P + 2])); const float fr = tx[DG_TX_FREQ];
-          const int ux = (int)floorf(pl.x * fr), uy = (int)floorf(pl.y * fr), uz = (int)floorf(pl.z * fr);
-          if (kind == DG_TEX_CHECKER) t = ((ux + uy + uz) & 1) ? 1.f : 0.f;
-          else if (kind == DG_TEX_STRIPES) t = (ux & 1) ? 1.f : 0.f;
-          else { uint32_t hh; DG_TEX_HASH(ux, uy, uz, hh); t = (float)hh * (1.0f / 16777216.0f); }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) vcol[u][k] = (tx[DG_TX_A + k] + (tx[DG_TX_B + k] - tx[DG_TX_A + k]) * t) * shd;
+        float eb[12 + DG_TX_STRIDE]; const float* e = s_f[h.shape];
+        _Pragma("unroll") for (int q = 0; q < 12; q++) eb[q] = e[RL_R + q];
+        _Pragma("unroll") for (int q = 0; q < DG_TX_STRIDE; q++) eb[12 + q] = e[RL_TEX + q];
+        shade_pixel(pc, h, px[u].d, eb, vcol[u]);
       }
     }
     {
@@ -548,6 +654,10 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       }
     }
   }
+  }
+  DG_RTIME(10, t_b2);  // [10] B2, summed over the four wavefronts
+  __syncthreads();  // (the next chunk of strips reuses the masks and the queue)
+  if (wv == 0) DG_RTIME(5, t_b2);  // [5] B2 until the slowest wavefront is done
   }
 }
 

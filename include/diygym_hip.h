@@ -123,8 +123,9 @@ int32_t dg_world_apply_wrench(dg_world* w, float* state, int32_t body, int32_t f
 int32_t dg_world_render(dg_world* w, const float* state, int32_t camera, float* rgb, float* depth, int32_t* seg, void* stream);
 
 /* Diagnostic switches of dg_world_render (bit 0: test every shape for every pixel group -- the brute-force picture the
- * culled one must equal bit for bit; other bits: tools/gpu_cam_bench.py).  The environment variables DG_RENDER_NO_CULL /
- * DG_RENDER_DIAG give the initial value, read once at dg_world_create. */
+ * culled one must equal bit for bit; 2: no intersections, background only; 4: hulls skipped; 128: no strip / tile level culling;
+ * 512: one band per picture whatever the batch size; 16: stage counters of a -DDG_RENDER_COUNTERS build, tools/gpu_cam_bench.py).
+ * The environment variables DG_RENDER_NO_CULL / DG_RENDER_DIAG give the initial value, read once at dg_world_create. */
 int32_t dg_world_set_render_diag(dg_world* w, int32_t flags);
 
 /* Per-env diagnostics of the last step: diag[num_envs][DG_DIAG_STRIDE] (int32), columns DG_DIAG_*: contact count and

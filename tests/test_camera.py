@@ -170,6 +170,35 @@ def test_gripper_camera_at_the_baseline_batch_1024_envs_200x200():
 
 
 @pytest.mark.gpu
+def test_more_shapes_in_view_than_the_render_list_holds():
+    """r2d2_maze seen from above: 119 walls + R2D2's shapes + the ground pass the picture's cone -- more than the 96 entries of the
+    render kernel's per-band list, so the band is rendered by the general path (every pixel against every shape, from the
+    tables).  Same picture as the oracle's renderer; a camera that sees only a corner of the maze (the list holds what it sees)
+    agrees with it too."""
+    import copy
+    import yaml
+    from diy_gym_amd.config import Configuration
+    tree = yaml.safe_load(open(os.path.join(ROOT, 'examples', 'r2d2_maze', 'r2d2_maze.yaml')))
+    tree['above'] = {'addon': 'camera', 'xyz': [0.0, 0.0, 14.0], 'rpy': [0.0, 0.0, 0.0], 'resolution': [72, 60], 'use_segmentation_mask': True}
+    tree['corner'] = {'addon': 'camera', 'xyz': [3.0, 3.0, 2.5], 'rpy': [0.0, 0.0, 0.3], 'resolution': [72, 60], 'use_segmentation_mask': True}
+    B = 3
+    gpu = DIYGym(Configuration.from_dict('r2d2_maze', tree), num_envs=B, device='cuda:0', seed=2)
+    cpu = DIYGym(Configuration.from_dict('r2d2_maze', copy.deepcopy(tree)), num_envs=B, seed=2, backend_factory=OracleBackend)
+    assert gpu.layout.n_bodies > 120
+    gpu.sim.set_render_diag(512)    # one band per picture, as at the batch sizes that matter (a band of 8 rows sees fewer shapes)
+    gpu._tick += 1; cpu._tick += 1
+    for name in ('above', 'corner'):
+        g = gpu.receptors['r2d2_maze'].addons[name].observe(); c = cpu.receptors['r2d2_maze'].addons[name].observe()
+        sg, sc = g['segmentation_mask'].cpu(), c['segmentation_mask']
+        same = sg == sc
+        assert same.float().mean() > 0.99, (name, float(same.float().mean()))
+        assert float((g['depth'].cpu() - c['depth']).abs()[same].max()) < 2e-3, name
+        assert float((g['rgb'].cpu() - c['rgb']).abs()[same].max()) < 2e-3, name
+        if name == 'above':
+            assert len(torch.unique(sc)) > 3 and float((c['depth'] > -13.9).float().mean()) > 0.05     # walls (and R2D2) are in the picture, not just the ground
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('res', [[50, 50], [33, 33], [7, 7], [130, 130]])
 def test_hip_render_odd_sizes_match_oracle(res):
     # rows that are not a whole number of cache lines, bands cut short by the image edge, images smaller than a pixel group

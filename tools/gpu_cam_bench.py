@@ -41,4 +41,5 @@ for rec, name in (('r2d2', 'arm_camera'), ('from_the_readme', 'overview')):
     c = list(buf); tiles = 13 * 25 * B
     print(name, 'per tile: after sphere-cone [sphere box capsule hull] %s | band-0 list length %.1f | after separating face [box hull] %s | after frustum [box hull] %s | intersected [sphere box capsule hull] %s' % (
         [round(x / tiles, 2) for x in c[0:4]], c[4] / B, [round(c[5] / tiles, 2), round(c[7] / tiles, 2)], [round(c[9] / tiles, 2), round(c[11] / tiles, 2)], [round(x / tiles, 2) for x in c[12:16]]))
+    print('   cycles per workgroup (100 MHz s_memtime ticks): phase A %.0f | to the end of B1 %.0f | B2 makespan %.0f, mean over wavefronts %.0f | queued tiles %.1f' % (c[4] / B, c[6] / B, c[5] / B, c[10] / B / 4, c[8] / B))
     print('   depth background fraction %.4f' % float((depth <= -99.9).float().mean()))

@@ -163,16 +163,17 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
   for (int k0 = 0; k0 < nout; k0 += 4) {
     float f[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, nout - 1); f[j][0] = pl[k][0]; f[j][1] = pl[k][1]; f[j][2] = pl[k][2]; f[j][3] = pl[k][3]; }
+    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, nout - 1); const float4 v = *reinterpret_cast<const float4*>(pl[k]); f[j][0] = v.x; f[j][1] = v.y; f[j][2] = v.z; f[j][3] = v.w; }
+    // (a round's spare slots repeat the last face: the same crossing again changes neither the latest entry -- the comparison is
+    // strict -- nor the verdict)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const bool ok = k0 + j < nout;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
-        const bool par = fabsf(den) < 1e-30f, front = den < 0.f && !par;
-        miss[u] = miss[u] || (ok && !front);
-        const bool later = ok && front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k0 + j : kn[u];
+        const bool front = den <= -1e-30f;  // approached from outside, and not (numerically) parallel
+        miss[u] = miss[u] || !front;
+        const bool later = front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k0 + j : kn[u];  // (a repeated face never is `later`: kn < nout)
       }
     }
     if (!__any(!miss[0] || !miss[1])) return;
@@ -184,15 +185,13 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
   for (int k0 = nout; k0 < np; k0 += 4) {
     float f[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, np - 1); f[j][0] = pl[k][0]; f[j][1] = pl[k][1]; f[j][2] = pl[k][2]; f[j][3] = pl[k][3]; }
+    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, np - 1); const float4 v = *reinterpret_cast<const float4*>(pl[k]); f[j][0] = v.x; f[j][1] = v.y; f[j][2] = v.z; f[j][3] = v.w; }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const bool ok = k0 + j < np;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
-        const bool back = ok && den > 0.f && !(fabsf(den) < 1e-30f);
-        tf[u] = back ? fminf(tf[u], t) : tf[u];
+        tf[u] = den >= 1e-30f ? fminf(tf[u], t) : tf[u];
       }
     }
   }
@@ -252,7 +251,7 @@ template <int WPE>
 __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, cfp CF, cfp PLN, int cam, int ncam, cfp table, float* rgb, float* depth, int32_t* seg,
                                                       int band_rows, int nbands, int diag) {
   const int no_cull = diag & 1;  // diagnostics (DG_RENDER_DIAG): 1 test every shape for every pixel group, 2 skip every intersection, 4 skip hulls
-  __shared__ float s_f[DG_RL_CAP][RL_STRIDE]; __shared__ int s_i[DG_RL_CAP][RLI_STRIDE]; __shared__ float s_pl[DG_RP_CAP][4]; __shared__ float s_pt[DG_RT_CAP][3];
+  __shared__ float s_f[DG_RL_CAP][RL_STRIDE]; __shared__ int s_i[DG_RL_CAP][RLI_STRIDE]; __shared__ __align__(16) float s_pl[DG_RP_CAP][4] /* 16-byte aligned: a face is one ds_read_b128 */; __shared__ float s_pt[DG_RT_CAP][3];
   __shared__ float s_bb[DG_RL_CAP][4];  // image-space bounds of each entry, in pixel coordinates: [c min, c max, r min, r max]
   __shared__ int s_wave_count[4]; __shared__ int s_scan[4], s_scan2[4];
   const int env = blockIdx.x / nbands, band = blockIdx.x - env * nbands, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

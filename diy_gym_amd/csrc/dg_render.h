@@ -340,6 +340,15 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
     // its projected vertices.  Anything that reaches behind the eye keeps an unbounded box (the tests of phase B deal
     // with it).  Half a pixel of padding covers the rounding of the projection.
     const float isx = 1.0f / sx, isy = 1.0f / sy, BIG = 3.0e38f;
+    // the band's four side planes through the eye, outward normals: a hull / box with every vertex outside one of them is not in
+    // the band at all and leaves the list here, once, instead of failing the same test strip by strip
+    V3 bnL, bnR, bnT, bnB;
+    { const V3 eL = rayA, eR = rayA + rayB * (float)W, eT = rayA + rayC * (float)r0, eB = rayA + rayC * (float)(r0 + nrows);
+      bnL = cross(eL, rayC); bnR = cross(eR, rayC); bnT = cross(eT, rayB); bnB = cross(eB, rayB);
+      if (dot(bnL, rayB) > 0.f) bnL = -bnL;
+      if (dot(bnR, rayB) < 0.f) bnR = -bnR;
+      if (dot(bnT, rayC) > 0.f) bnT = -bnT;
+      if (dot(bnB, rayC) < 0.f) bnB = -bnB; }
     auto to_c = [&](float tx) { return (tx + kx) * isx; };
     auto to_r = [&](float ty) { return (ty - th) * isy; };  // (sy < 0: r decreases with ty)
     for (int e = wv; e < total; e += 4) {
@@ -395,12 +404,13 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
       // vertices relative to the eye, for the tile-frustum test of phase B (hull points; the eight corners of a box)
       { const int npt = s_i[e][RLI_NPT], pto = s_i[e][RLI_PT_OFF]; cfp pts = sc.PF + 3 * sc.SI[sh * DG_SI_STRIDE + DG_SI_POINT_OFF];
         const V3 pl = v3(s_f[e][RL_P], s_f[e][RL_P + 1], s_f[e][RL_P + 2]) - pc;
-        float txl = BIG, txh = -BIG, tyl = BIG, tyh = -BIG, zmax = -BIG; bool behind = false;
+        float txl = BIG, txh = -BIG, tyl = BIG, tyh = -BIG, zmax = -BIG; bool behind = false, inL = false, inR = false, inT = false, inB = false;
         for (int k = lane; k < npt; k += 64) {
           V3 q;
           if (box) q = v3((k & 1) ? s_f[e][RL_PRM] : -s_f[e][RL_PRM], (k & 2) ? s_f[e][RL_PRM + 1] : -s_f[e][RL_PRM + 1], (k & 4) ? s_f[e][RL_PRM + 2] : -s_f[e][RL_PRM + 2]);
           else q = v3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
           const V3 w = pl + mul(Rl, q); s_pt[pto + k][0] = w.x; s_pt[pto + k][1] = w.y; s_pt[pto + k][2] = w.z;
+          inL = inL || dot(bnL, w) <= 0.f; inR = inR || dot(bnR, w) <= 0.f; inT = inT || dot(bnT, w) <= 0.f; inB = inB || dot(bnB, w) <= 0.f;
           const float z = -dot(rc2, w); behind = behind || !(z > 1e-5f); zmax = fmaxf(zmax, z);
           const float iz = 1.0f / fmaxf(z, 1e-5f), tx = dot(rc0, w) * iz, ty = dot(rc1, w) * iz;
           txl = fminf(txl, tx); txh = fmaxf(txh, tx); tyl = fminf(tyl, ty); tyh = fmaxf(tyh, ty);
@@ -408,6 +418,7 @@ __global__ __launch_bounds__(256, WPE) void render_kernel(DevScene sc, cip CI, c
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { txl = fminf(txl, __shfl_xor(txl, o)); txh = fmaxf(txh, __shfl_xor(txh, o)); tyl = fminf(tyl, __shfl_xor(tyl, o)); tyh = fmaxf(tyh, __shfl_xor(tyh, o)); zmax = fmaxf(zmax, __shfl_xor(zmax, o)); }
         if (npt > 0 && zmax < zn && !no_cull && lane == 0) s_i[e][RLI_TYPE] = -1;  // every vertex nearer than the near plane: so is the whole convex shape
+        if (npt > 0 && !no_cull && (!__any(inL) || !__any(inR) || !__any(inT) || !__any(inB)) && lane == 0) s_i[e][RLI_TYPE] = -1;  // wholly outside the band's frustum
         const bool unbounded = __any(behind) || npt == 0;
         if (lane == 0) { s_bb[e][0] = unbounded ? -BIG : to_c(txl) - 0.5f; s_bb[e][1] = unbounded ? BIG : to_c(txh) + 0.5f; s_bb[e][2] = unbounded ? -BIG : to_r(tyh) - 0.5f; s_bb[e][3] = unbounded ? BIG : to_r(tyl) + 0.5f; }
       }

@@ -1,6 +1,6 @@
-"""Step time of a scene per engine setting: python tools/r3/gpu_time_scene.py <config name> <envs> [key=value ...]"""
+"""Step time of a scene per engine setting: python tools/gpu_time_scene.py <config name> <envs> [key=value ...]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import diy_gym_amd.examples

@@ -2060,6 +2060,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   }
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
     const int nvm = sc.nv_max; const bool two = sc.crow_tail > 2 * nvm;
+    regs_to_lds(0); regs_to_lds(1);  // (the motor guess of a register-chain body is in registers only: without this the reload below dropped it)
     for (int c = 0; c < wave_max_cont; c++) {
       const bool has = c < ncont; const int co = sc.cont_off + 1 + c * CL_STRIDE;
 #pragma unroll

@@ -191,6 +191,31 @@ def test_child_model_held_by_a_fixed_constraint_40_steps():
     assert d[:, 1].tolist() == [cpu.sim.iterations(e) for e in range(5)] or abs(int(d[:, 1].max()) - max(cpu.sim.iterations(e) for e in range(5))) <= 150
 
 
+def test_constrained_child_pressed_onto_the_floor():
+    """The constrained gripper in contact: the arm lowers its shoulder and presses the gripper (a floating body held by the six
+    constraint rows) onto the plane -- motor rows of the parent, constraint rows, normal and friction rows of the child's
+    hull-point contacts in one sweep, two-sided rows throughout.  Contact counts equal step by step; state to 3e-2 after 80
+    steps, joint angles to 2e-3.  (This test found the round's one solver bug: with a register-chain body, a contact and warm
+    starting in the generic sweeps, the reload of the velocity change after the warm-start prologue dropped the motor guess's
+    share of it.)  Blind to: as test_child_model_held_by_a_fixed_constraint_40_steps, plus hull thinning."""
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    path = os.path.join(ROOT, 'tests', 'golden', 'ur5_constrained_gripper_floor.yaml')   # (not in CONFIGS: the gripper is loaded at the pivot
+    # of the arm's zero configuration, inside the floor -- 32 capped contacts in the constructor's hot-start step, nothing to compare tightly)
+    gpu = DIYGym(path, num_envs=5, device='cuda:0', seed=5); cpu = DIYGym(path, num_envs=5, seed=5, backend_factory=OracleBackend)
+    d = gpu.sim.enable_diagnostics()
+    press = torch.tensor([[0.3, -0.50, 1.22, -1.51, 0.84, 0.1]] * 5)
+    gen = torch.Generator().manual_seed(4)
+    for i in range(80):
+        act = press + 0.01 * (torch.rand((5, 6), generator=gen) - 0.5)
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act)
+        if i > 10:
+            assert d[:, 0].tolist() == [cpu.sim.contacts(e) for e in range(5)], i
+    assert int(d[:, 0].min()) >= 8                     # the arm's base and the gripper's pads are on the floor
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 3e-2, np.abs(phys_state(gpu) - phys_state(cpu)).max()   # measured 1.1e-2 (a velocity; some steps' sweeps stop at the cap)
+    assert float((gpu.sim.obs.cpu() - cpu.sim.obs).abs()[:, :6].max()) < 2e-3      # the arm's joint angles
+
+
 def test_constrained_child_settles_where_the_merged_child_sits():
     """The stiff limit of the fixed-constraint rows: holding the rest pose, the constrained gripper ends up where the rigidly
     merged one (tests/golden/ur5_child_gripper.yaml) is, and the arm's joints with it."""
@@ -473,6 +498,8 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('maze', {'DG_MAX_LANES': '8'}, 8, 25, 5e-3),           # the mode dg_world_create picks for r2d2_maze at BASELINE's 4 096 envs
     ('drone', {'DG_MAX_LANES': '32'}, 32, 40, 2e-3),        # ... and for drone_pilot at 16 384 envs
     ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
+    ('constrained', {'DG_MAX_LANES': '32'}, 32, 30, 2e-3),   # fixed-constraint rows (generic sweeps) with the idle lanes of the narrow modes around them
+    ('constrained', {'DG_MAX_LANES': '16'}, 16, 30, 2e-3),
     ('maze', {'DG_MAX_LANES': '4', 'DG_NO_MINV_SLICES': '1'}, 4, 25, 5e-3),   # M^-1 columns by one lane per env (they are shared by the group's lanes otherwise)
     ('maze', {'DG_MAX_LANES': '1'}, 1, 25, 5e-3),           # one env per wavefront: every row in registers, scalars in owner lanes
     ('readme', {'DG_MAX_LANES': '1'}, 1, 30, 2e-3),

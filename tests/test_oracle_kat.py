@@ -382,6 +382,44 @@ def test_head_on_collision_is_inelastic_and_conserves_momentum(tmp_path):
     assert vb >= va - 1e-6                                  # separating or together, never interpenetrating further
 
 
+def test_fixed_constraint_rows_make_two_free_bodies_move_as_one(tmp_path):
+    """``attach: constraint`` (reference model.py:74-75, createConstraint(JOINT_FIXED) as six solver rows), no gravity, no
+    plane: a 10 kg sphere carries a second one on a 0.5 m offset.  Pushed through the pair's common centre of mass with
+    100 N for 24 steps, the two end up at F t / (m_a + m_b) = 0.5 m/s, without rotation, the offset kept; pushed through the
+    PARENT's own centre the pair also turns -- angular momentum about the common centre = lever x impulse, with the pair's
+    inertia 2 (2/5 m r^2) + 2 m (d/2)^2 -- and the child stays 0.5 m from the parent."""
+    import yaml
+    def build(push_at):
+        cfg = {'render': False, 'gravity': [0.0, 0.0, 0.0],
+               'a': {'model': 'sphere2.urdf', 'xyz': [0.0, 0.0, 0.0], 'push': {'addon': 'external_force', 'xyz': push_at},
+                     'state': {'addon': 'object_state_sensor', 'include_velocity': True},
+                     'b': {'model': 'sphere2.urdf', 'attach': 'constraint', 'xyz': [0.0, 0.5, 0.0], 'constraint_max_force': 1e5}}}
+        path = tmp_path / ('pair_%s.yaml' % abs(hash(str(push_at))))
+        yaml.safe_dump(cfg, open(path, 'w'))
+        return make(str(path), **NODAMP)
+    env = build([0.0, 0.25, 0.0])          # through the common centre of mass
+    assert env.layout.n_bodies == 2
+    for _ in range(24):
+        o, _, _, _ = env.step({'a': {'push': torch.tensor([[100.0, 0.0, 0.0]])}})
+    for _ in range(60):
+        o, _, _, _ = env.step({'a': {'push': torch.zeros(1, 3)}})
+    b = env.sim.frame_state64(env.models['a'].models['b'].uid, -1, com=True)[0]; a = env.sim.frame_state64(env.models['a'].uid, -1, com=True)[0]
+    assert abs(a[7] - 0.5) < 1e-4 and abs(b[7] - 0.5) < 1e-4 and np.abs(a[10:13]).max() < 1e-4      # 100 N x 0.1 s / 20 kg, no spin
+    assert np.allclose(b[:3] - a[:3], [0.0, 0.5, 0.0], atol=1e-5)
+    env = build([0.0, 0.0, 0.0])           # through the parent's centre: 0.25 m beside the common one
+    for _ in range(24):
+        o, _, _, _ = env.step({'a': {'push': torch.tensor([[100.0, 0.0, 0.0]])}})
+    for _ in range(60):
+        o, _, _, _ = env.step({'a': {'push': torch.zeros(1, 3)}})
+    b = env.sim.frame_state64(env.models['a'].models['b'].uid, -1, com=True)[0]; a = env.sim.frame_state64(env.models['a'].uid, -1, com=True)[0]
+    m, r = 10.0, 0.5                        # sphere2.urdf: 10 kg, radius 0.5 (inertia as in the file)
+    I_pair = 2 * float(env.builder.bodies[0][0].base_inertia[2, 2]) + 2 * m * 0.25 ** 2
+    assert abs(0.5 * (a[7] + b[7]) - 0.5) < 1e-3                                   # linear momentum / 20 kg
+    assert abs(np.linalg.norm(b[:3] - a[:3]) - 0.5) < 1e-4                           # rigid
+    wz = a[12]
+    assert abs(wz - b[12]) < 1e-4 and abs(abs(wz) - 0.25 * 10.0 / I_pair) < 0.03 * 0.25 * 10.0 / I_pair    # |L| = lever x impulse (the lever turns with the pair: 3 %)
+
+
 # ---------------------------------------------------------------- dynamics_randomizer (reference dynamics_randomizer.py:24-32)
 def _pendulum_with_randomizer(tmp_path, body, B=1, seed=0):
     cfg = tmp_path / 'pend_rand.yaml'

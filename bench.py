@@ -313,14 +313,19 @@ def run_rank(args, argv):
         if auto_reset:
             sim.reset(sim.term_flag)
 
-    for i in range(args.warmup):
+    # Warm-up: --warmup untimed steps in all.  The last ones are the FIRST replay of each graph the timed region uses (below):
+    # the first launch of a freshly instantiated hipGraph can pay a one-off upload of tens of milliseconds, which in a timed
+    # region of ~30 ms in all showed up once as 0.26 ms per step instead of 0.108 (profiles/, round 3).
+    R = len(ring)
+    n_graph_warm = 0 if args.eager else R + (args.steps % R)
+    if args.warmup < n_graph_warm:
+        n_graph_warm = 0  # (too few warm-up steps asked for to spend them on the graphs: the first replay is timed)
+    for i in range(args.warmup - n_graph_warm):
         one_step(i)
     torch.cuda.synchronize()
     # The timed region replays hipGraphs of consecutive steps (step [+ render] + masked auto-reset each): the work is
     # identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.1 ms kernels.  EXACTLY --steps
     # steps, all of them replayed: whole segments of len(ring) steps plus one shorter segment for the remainder.
-    R = len(ring)
-
     def capture(n_steps, body):
         cap = torch.cuda.Stream(device=device)
         cap.wait_stream(torch.cuda.current_stream(device))
@@ -343,6 +348,15 @@ def run_rank(args, argv):
         except Exception as exc:  # pragma: no cover
             print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
             graph = graph_rest = graph_kernel = None
+    if graph is not None and n_graph_warm:  # the remaining warm-up steps, as the graphs' first replays
+        graph.replay()
+        if graph_rest is not None:
+            graph_rest.replay()
+        torch.cuda.synchronize()
+    elif graph is None:
+        for i in range(n_graph_warm):
+            one_step(i)
+        torch.cuda.synchronize()
 
     def timed(steps):
         torch.cuda.synchronize()

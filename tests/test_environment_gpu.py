@@ -80,6 +80,26 @@ def test_shards_equal_whole_batch():
     assert np.array_equal(np.concatenate(parts, axis=0), whole)
 
 
+def test_a_shard_in_another_workspace_mode_agrees_with_the_whole_batch():
+    """dg_world_create picks the workspace mode from the scene AND the batch (from_the_readme: one env per wavefront up to four
+    wavefronts per CU, four envs per wavefront above), so a shard can run another solver path -- another summation order --
+    than the whole batch it is cut from: bit-for-bit replay holds within one mode (test_shards_equal_whole_batch; pin it with
+    DG_MAX_LANES), ACROSS modes the shard agrees to rounding.  25 steps of the settling scene: 2e-3 on the observations."""
+    import diy_gym_amd.examples  # noqa: F401
+    from diy_gym_amd import DIYGym
+    from test_parity_gpu import action_bounds
+    readme = os.path.join(ROOT, 'examples', 'from_the_readme', 'from_the_readme.yaml')
+    whole = DIYGym(readme, num_envs=2048, device='cuda:0', seed=3)
+    shard = DIYGym(readme, num_envs=512, device='cuda:0', seed=3, env_index_base=1024)
+    assert whole.sim.lanes != shard.sim.lanes, (whole.sim.lanes, shard.sim.lanes)
+    lo, hi = action_bounds(whole); gen = torch.Generator().manual_seed(9)
+    for _ in range(25):
+        act = lo + (hi - lo) * torch.rand((2048, lo.numel()), generator=gen)
+        whole.sim.step(whole._all_slots, act.to('cuda:0')); shard.sim.step(shard._all_slots, act[1024:1536].to('cuda:0').contiguous())
+    assert bool(torch.isfinite(whole.sim.obs).all())
+    assert float((whole.sim.obs[1024:1536] - shard.sim.obs).abs().max()) < 2e-3
+
+
 def test_ragged_batch_sizes():
     # batch sizes that do not fill the last wavefront, and a single env
     for B in (1, 63, 65, 130):

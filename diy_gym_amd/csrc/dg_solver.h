@@ -874,9 +874,9 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
   };
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
     for (int r = 0; r < 3 * wave_max_cont; r++) {
-      DenseRow<NTB> W; load_row(W, sc.tr_off + r * rs); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+      DenseRow<NTB> W; load_row(W, sc.tr_off + r * rs); const bool on = r < 3 * ncont;  // (a slot beyond THIS env's contacts holds whatever was there: select, never multiply by zero)
 #pragma unroll
-      for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * a0;
+      for (int k = 0; k < NTB; k++) dv[k] += on ? W.R[k] * W.acc : 0.f;
     }
   }
   for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
@@ -1033,9 +1033,9 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
   };
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
     for (int r = 0; r < 3 * wave_max_cont; r++) {
-      Row W; load_row(W, sc.tr_off + r * rs); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+      Row W; load_row(W, sc.tr_off + r * rs); const bool on = r < 3 * ncont;  // (a slot beyond THIS env's contacts holds whatever was there -- NaN patterns included: select, never multiply by zero)
 #pragma unroll
-      for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
+      for (int i = 0; i < NS; i++) dv[i] += on ? W.R[i] * W.acc : 0.f;
     }
   }
   for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
@@ -1489,9 +1489,9 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   const int r0 = sc.tr_off, c0 = sc.cont_off + 1;
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to
     for (int r = 0; r < 3 * wave_max_cont; r++) {
-      Row W; load_row(W, r0 + r * rs, c0 + (r / 3) * CL_STRIDE, r); const float a0 = r < 3 * ncont ? W.acc : 0.f;
+      Row W; load_row(W, r0 + r * rs, c0 + (r / 3) * CL_STRIDE, r); const bool on = r < 3 * ncont;
 #pragma unroll
-      for (int i = 0; i < NS; i++) dv[i] += W.R[i] * a0;
+      for (int i = 0; i < NS; i++) dv[i] += on ? W.R[i] * W.acc : 0.f;
     }
   }
   for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)

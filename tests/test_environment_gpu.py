@@ -290,7 +290,8 @@ def test_unindexed_device_string_is_accepted():
     assert out['depth'].shape[0] == 4 and bool(torch.isfinite(out['depth']).all())
 
 
-def test_python_hook_addon_equals_the_compiled_propellor():
+@pytest.mark.parametrize('max_lanes', [None, '32', '8'])
+def test_python_hook_addon_equals_the_compiled_propellor(max_lanes):
     """A user addon that acts on the world from Python: the reference's Propellor (examples/drone_pilot/drone_pilot.py:10-40;
     registry diy_gym/addons/addon.py:80-81, hooks :91-186) written as a plain hook addon on ``env.sim.apply_external_*``
     (dg_world_apply_wrench) against the compiled DG_OP_PROPELLOR, same dict actions, 40 steps incl. terminal resets.
@@ -316,7 +317,13 @@ def test_python_hook_addon_equals_the_compiled_propellor():
             t['drone'][m]['addon'] = addon_name
         return DIYGym(Configuration.from_dict('drone_pilot', t), num_envs=B, device='cuda:0', seed=4)
 
-    compiled, hooked, hooked2 = make('propellor'), make('py_propellor'), make('py_propellor2')
+    if max_lanes:   # (the wrench entry point in the narrow workspace modes -- drone_pilot takes 32 envs per wavefront at 16 384 envs)
+        os.environ['DG_MAX_LANES'] = max_lanes
+    try:
+        compiled, hooked, hooked2 = make('propellor'), make('py_propellor'), make('py_propellor2')
+    finally:
+        os.environ.pop('DG_MAX_LANES', None)
+    assert max_lanes is None or compiled.sim.lanes == int(max_lanes) == hooked.sim.lanes
     assert not compiled._hook_addons and len(hooked._hook_addons) == 4 and compiled.layout.addon_off == hooked.layout.addon_off
     L = compiled.layout
     so = L.body_state_off[[i for i in range(L.n_bodies) if not L.body_fixed[i]][0]]   # the drone (the target's respawn jitter is keyed by op index)

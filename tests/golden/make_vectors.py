@@ -40,11 +40,21 @@ def actions_for(env, steps, scale, seed=123):
     return (lo + (hi - lo) * torch.rand((steps, env.num_envs, lo.numel()), generator=gen)) * scale
 
 
-def run(name, backend_factory=None, device=None):
+# Second set ("ref/<scene>/..."): the solver settings the reference is believed to run with (diy_gym/diy_gym.py:76-82 sets
+# nothing but the iteration count and the substeps, so Bullet's own defaults apply [R]): motor rows started from ZERO and
+# contact normal rows warm started with Bullet's factor 0.85 -- instead of this build's production defaults (motor_guess 1,
+# warmstart 1).  Scenes with motors and / or contacts.
+REFERENCE_SETTINGS = dict(motor_guess=0.0, warmstart=0.85)
+REF_SCENES = ('ur_ik', 'ur_joint', 'cart_tree', 'maze', 'readme', 'touching', 'gripper', 'marbles')
+
+
+def run(name, backend_factory=None, device=None, engine=None):
     import diy_gym_amd.examples  # noqa: F401
     from diy_gym_amd import DIYGym
     cfg, B, steps, scale = SCENES[name]
     kw = dict(backend_factory=backend_factory) if backend_factory else dict(device=device)
+    if engine:
+        kw['engine'] = dict(engine)
     env = DIYGym(os.path.join(ROOT, cfg), num_envs=B, seed=11, **kw)
     acts = actions_for(env, steps, scale)
     obs = []
@@ -63,6 +73,12 @@ def main():
         for k, v in r.items():
             out['%s/%s' % (name, k)] = v.astype(np.float32) if v.dtype == np.float64 and k != 'state' else v
         print(name, 'obs', r['obs'].shape, 'state', r['state'].shape)
+    for name in REF_SCENES:
+        r = run(name, backend_factory=OracleBackend, engine=REFERENCE_SETTINGS)
+        for k, v in r.items():
+            if k != 'actions':   # (the same seeded actions as the first set)
+                out['ref/%s/%s' % (name, k)] = v.astype(np.float32) if v.dtype == np.float64 and k != 'state' else v
+        print('ref/' + name, 'obs', r['obs'].shape, 'max |obs - production settings| = %.3g' % float(np.abs(r['obs'] - out[name + '/obs']).max()) if r['obs'].size else '')
     np.savez_compressed(os.path.join(HERE, 'vectors.npz'), **out)
     print('wrote', os.path.join(HERE, 'vectors.npz'), os.path.getsize(os.path.join(HERE, 'vectors.npz')), 'bytes')
 

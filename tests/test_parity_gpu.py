@@ -188,7 +188,9 @@ def test_child_model_held_by_a_fixed_constraint_40_steps():
     w = rollout(gpu, cpu, 40)
     assert w['obs'] < 2e-3 and w['term_mismatch'] == 0, w
     assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5e-3
-    assert d[:, 1].tolist() == [cpu.sim.iterations(e) for e in range(5)] or abs(int(d[:, 1].max()) - max(cpu.sim.iterations(e) for e in range(5))) <= 150
+    # the constraint-row sweeps end where the oracle's do (fp32 against fp64: the residual crosses 1e-7 within a few sweeps of each other)
+    it_c = [cpu.sim.iterations(e) for e in range(5)]
+    assert max(abs(int(g) - c) for g, c in zip(d[:, 1].tolist(), it_c)) <= max(3, max(it_c) // 10), (d[:, 1].tolist(), it_c)
 
 
 def test_constrained_child_pressed_onto_the_floor():
@@ -864,6 +866,93 @@ def test_spawn_multiple_scene_100_steps():
     # the clones got different respawn draws
     o = cpu.sim.obs
     assert float((o[:, 0:2] - o[:, 3:5]).abs().max()) > 1e-2 and float((o[:, 3:5] - o[:, 6:8]).abs().max()) > 1e-2
+
+
+# ---- the reference's (recollected) solver settings: zero-started motor rows ---------------------------------------------------
+REF = dict(motor_guess=0.0, warmstart=0.85)
+COLD = dict(motor_guess=0.0)
+
+
+@pytest.mark.parametrize('name,env_vars,lanes,steps,tol,scale,engine', [
+    # the arm-per-half-wavefront register sweeps of step_kernel_par (two register-chain arms), IK and joint control
+    ('ur_ik', {}, 64, 60, 5e-4, 1.0, COLD), ('ur_ik', {}, 64, 60, 5e-4, 1.0, REF), ('ur_joint', {}, 64, 60, 5e-4, 1.0, COLD),
+    # ... the main wavefront sweeping both arms, and the single-wavefront step kernel
+    ('ur_ik', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-4, 1.0, COLD), ('ur_ik', {'DG_NO_HELPER_WAVE': '1'}, 64, 30, 5e-4, 1.0, REF),
+    # register chains with dense arm-arm contact rows (crossed forearms), single-wave and streamed
+    ('touching', {}, 64, 30, 5e-3, 0.3, COLD), ('touching', {}, 64, 30, 5e-3, 0.3, REF), ('touching', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-3, 0.3, REF),
+    ('touching', {'DG_NO_HELPER_WAVE': '1'}, 64, 30, 5e-3, 0.3, COLD), ('touching_ik', {}, 64, 30, 5e-3, 1.0, REF),
+    # pgs_wave_env (one env per wavefront), pgs_dense_sliced (LDS), pgs_dense_sliced_global, pgs_dense over the global workspace
+    ('readme', {}, 1, 30, 2e-3, 0.2, REF), ('readme', {'DG_NO_WAVE_ENV': '1'}, 4, 30, 2e-3, 0.2, REF), ('readme', {'DG_NO_NARROW_MODES': '1'}, -16, 30, 2e-3, 0.2, REF),
+    ('readme', {'DG_NO_NARROW_MODES': '1', 'DG_NO_SLICED_GLOBAL': '1'}, 0, 30, 2e-3, 0.2, COLD),
+    # pgs_dense_sliced_regs (r2d2_maze's production mode: 8 lanes per env, rows in registers), and the same scene streamed
+    ('maze', {'DG_MAX_LANES': '8'}, 8, 25, 5e-3, 10.0, REF), ('maze', {'DG_MAX_LANES': '8', 'DG_NO_REG_ROWS': '1'}, 8, 25, 5e-3, 10.0, COLD),
+    ('maze', {'DG_MAX_LANES': '16'}, 16, 25, 5e-3, 10.0, COLD), ('maze', {'DG_MAX_LANES': '1'}, 1, 25, 5e-3, 10.0, REF),
+    # pgs_dense, 64 envs per wavefront from LDS (12-DoF tree with hull-vs-plane contacts; 9-10 joint bodies take motor_guess_lds otherwise)
+    ('gripper', {}, None, 40, 3e-3, 0.5, REF), ('child', {}, None, 40, 2e-3, 1.0, COLD),
+    # generic rows (floating tree with two jointed bodies; fixed-constraint rows)
+    ('cart_tree', {}, 64, 20, 2e-2, 1.0, REF), ('constrained', {}, None, 40, 2e-3, 1.0, REF),
+    ('admittance', {}, None, 40, 3e-3, 1.0, COLD),
+])
+def test_zero_started_motor_rows_in_every_sweep_form(name, env_vars, lanes, steps, tol, scale, engine):
+    """``motor_guess = 0`` -- the zero start Bullet's solver gives the motor rows [R], i.e. what the reference's own settings
+    (diy_gym/diy_gym.py:76-82: iteration count and substeps only) run -- alone and together with Bullet's warm-start factor 0.85,
+    through every form of the sweeps, against the oracle at the same settings.  The production default (motor_guess = 1) starts
+    those rows from the direct solution of their system: same fixed point, but where sweeps end at the iteration cap the result
+    depends on the start, so this is the setting that corresponds to the reference and it must not be dead code."""
+    os.environ.update(env_vars)
+    try:
+        gpu, cpu = make_pair(name, 9, **engine)
+    finally:
+        for k in env_vars:
+            del os.environ[k]
+    if lanes is not None:
+        assert gpu.sim.lanes == lanes
+    d = gpu.sim.enable_diagnostics()
+    w = rollout(gpu, cpu, steps, scale=scale)
+    assert w['obs'] < tol and w['term_mismatch'] == 0, w
+    a, b = phys_state(gpu), phys_state(cpu)
+    assert np.isfinite(a).all()
+    if name == 'maze':   # (no sensors: the base pose is what there is to compare; velocities at the iteration cap are loose)
+        so = gpu.layout.body_state_off[[i for i in range(gpu.layout.n_bodies) if gpu.layout.body_n_links[i] > 0][0]]
+        assert np.abs(a[:, so:so + 7] - b[:, so:so + 7]).max() < tol
+    else:   # poses, joint angles and rates (the applied-torque columns of the state are O(100) N m and relative like every effort)
+        L = gpu.layout
+        cols = [o + k for o in L.link_state_off for k in (0, 1)] + [o + k for i, o in enumerate(L.body_state_off) if o >= 0 for k in range(7 if L.body_fixed[i] else 13)]
+        assert np.abs(a[:, cols] - b[:, cols]).max() < 20 * tol, np.abs(a[:, cols] - b[:, cols]).max()
+    # a cold start needs MORE sweeps than the guess: the setting took effect (ur_ik: ~35 against ~3), and both sides agree on how many
+    it_g, it_c = int(d[:, 1].max()), max(cpu.sim.iterations(e) for e in range(9))
+    assert abs(it_g - it_c) <= max(3, it_c // 5), (it_g, it_c)
+    if name == 'ur_ik':   # (a joint-controlled arm near its target converges in a few sweeps either way)
+        assert it_c >= 12, it_c
+
+
+def test_arms_touching_under_ik_control_at_the_size_the_bench_ships():
+    """ur_arms_touching_ik at 16 384 envs (BASELINE.json's ur_high_5 batch): the contact path of the headline scene -- dense
+    arm-arm contact rows in the register sweeps of step_kernel_par -- at the size it ships at, 256 workgroups.  Asserted:
+    every env has contacts after the first step, the state stays finite over 40 random-action steps, a second world built
+    from the same seed reproduces it BIT FOR BIT (no dependence on scheduling), and the first 64 envs follow the oracle."""
+    from diy_gym_amd import DIYGym
+    from oracle_backend import OracleBackend
+    B = 16384
+    a = DIYGym(CONFIGS['touching_ik'], num_envs=B, device='cuda:0', seed=5)
+    b = DIYGym(CONFIGS['touching_ik'], num_envs=B, device='cuda:0', seed=5)
+    cpu = DIYGym(CONFIGS['touching_ik'], num_envs=64, seed=5, backend_factory=OracleBackend)
+    assert a.sim.lanes == 64 and a.sim.par
+    d = a.sim.enable_diagnostics()
+    lo, hi = action_bounds(a)
+    gen = torch.Generator().manual_seed(0)
+    worst, touching = 0.0, []
+    for i in range(40):
+        act = lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)
+        a.sim.step(a._all_slots, act.to(a.device)); b.sim.step(b._all_slots, act.to(b.device)); cpu.sim.step(cpu._all_slots, act[:64])
+        touching.append(float((d[:, 0] > 0).float().mean()))
+        worst = max(worst, float((a.sim.obs[:64].cpu() - cpu.sim.obs).abs().max()))
+        if i == 0:
+            assert d[:64, 0].tolist() == [cpu.sim.contacts(e) for e in range(64)]
+    sa, sb = a.sim.state.cpu(), b.sim.state.cpu()
+    assert torch.isfinite(sa).all() and torch.equal(sa, sb) and torch.equal(a.sim.obs.cpu(), b.sim.obs.cpu())
+    assert touching[0] == 1.0 and min(touching) > 0.5, touching   # crossed forearms: every env starts in contact, most stay
+    assert worst < 5e-3, worst
 
 
 # ---- warm starting ---------------------------------------------------------------------------------------------------------

@@ -369,7 +369,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     }
     sc.early_dyn = (ok && long_update) ? 1 : 0;
   }
-  sc.h = (float)F[DG_HF_DT]; sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
+  sc.h = (float)F[DG_HF_DT]; sc.hm = (float)(F[DG_HF_DT] * F[DG_HF_MOTOR_IMPULSE_SCALE]); sc.gx = (float)F[DG_HF_GRAV_X]; sc.gy = (float)F[DG_HF_GRAV_Y]; sc.gz = (float)F[DG_HF_GRAV_Z];
   // ---- default velocity motors on every joint
   memset(&w->mt, 0, sizeof w->mt);
   for (int l = 0; l < nl; l++) { w->mt.v[3 * l] = 0.f; w->mt.v[3 * l + 1] = 1.f; w->mt.v[3 * l + 2] = -(float)F[DG_HF_DEFAULT_MOTOR_IMPULSE]; }

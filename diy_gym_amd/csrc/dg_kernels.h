@@ -69,6 +69,7 @@ struct DevScene {
   int32_t num_envs, stride;
   uint64_t seed; int64_t env_base;
   float h, gx, gy, gz;
+  float hm;  // time base of a motor row's impulse bound: h x DG_HF_MOTOR_IMPULSE_SCALE (the substep, or the full step)
 };
 struct MotorTable { float v[DG_MAX_LINKS * 3]; };  // kp, kd, max_force (<0 raw impulse)
 

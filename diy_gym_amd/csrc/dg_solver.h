@@ -567,18 +567,33 @@ DGD void chol_unit_solve(OFF off, const float* rhs, float* x) {
     x[i] = t * P[i * (i + 1) / 2 + i];
   }
 }
+// DG_HF_LIMIT_GUESS (pinning): lb0 / la0 and lb1 / la1 are the right-hand sides and impulses of the joints' lower / upper limit
+// rows (la < 0: the row is not active).  A joint whose motor target lies beyond an active limit row enters the system as ONE
+// unknown -- the joint's total impulse, with the limit row's velocity as right-hand side -- and starts with the motor saturated
+// into the limit and the limit row holding the balance (written to la0 / la1); if the motor alone is too weak to reach the limit
+// velocity it is held at its bound like any row that leaves its bounds.  dv += M x (total impulse per joint).  Same steps as
+// the CPU checker (its comment "Starting impulses of the motor rows").
 template <int N>
-DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv) {
+DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv, bool pinning, const float* lb0, float* la0, const float* lb1, float* la1) {
   // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
   // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal)
-  float rhs[N], x[N], sd[N];
+  float rhs[N], x[N], sd[N], pin[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) { sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f; rhs[i] = b[i] * sd[i]; }
+  for (int i = 0; i < N; i++) {
+    sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f;
+    const bool plo = pinning && smax[i] > 0.f && la0[i] >= 0.f && b[i] < lb0[i], phi = pinning && smax[i] > 0.f && la1[i] >= 0.f && b[i] > -lb1[i];
+    pin[i] = plo ? -1.f : (phi ? 1.f : 0.f);
+    rhs[i] = (plo ? lb0[i] : (phi ? -lb1[i] : b[i])) * sd[i];
+  }
   chol_unit_solve<N>([&](int i, int j) { return M[i * N + j] * sd[i] * sd[j]; }, rhs, x);
   // one active-set round (DG_MOTOR_GUESS_REFINE): rows beyond their bounds are held there, the others solved again
   bool held[N], any = false; float val[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) { const float imp = x[i] * sd[i]; held[i] = fabsf(imp) > smax[i] && smax[i] > 0.f; any = any || held[i]; val[i] = held[i] ? copysignf(smax[i], imp) * frcp(sd[i]) : 0.f; }
+  for (int i = 0; i < N; i++) {
+    const float imp = x[i] * sd[i];
+    held[i] = smax[i] > 0.f && (pin[i] != 0.f ? pin[i] * imp > smax[i] : fabsf(imp) > smax[i]); any = any || held[i];
+    val[i] = held[i] ? (pin[i] != 0.f ? pin[i] * smax[i] : copysignf(smax[i], imp)) * frcp(sd[i]) : 0.f;
+  }
   if (__any(any)) {
     float r2[N], x2[N];
 #pragma unroll
@@ -592,14 +607,21 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
 #pragma unroll
     for (int i = 0; i < N; i++) x[i] = any ? x2[i] : x[i];
   }
+  float tot[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) acc[i] = __builtin_amdgcn_fmed3f(x[i] * sd[i], -smax[i], smax[i]);
+  for (int i = 0; i < N; i++) {
+    const float t = x[i] * sd[i], clamped = __builtin_amdgcn_fmed3f(t, -smax[i], smax[i]);
+    const bool pinned = pin[i] != 0.f && !held[i];
+    const float lim = pinned ? fmaxf(smax[i] - pin[i] * t, 0.f) : 0.f;  // what the limit row holds (it pushes along -pin)
+    acc[i] = pinned ? pin[i] * smax[i] : clamped; tot[i] = acc[i] - pin[i] * lim;
+    if (pinning) { if (pinned && pin[i] < 0.f) la0[i] = lim; if (pinned && pin[i] > 0.f) la1[i] = lim; }
+  }
 #pragma unroll
   for (int i = 0; i < N; i++)
 #pragma unroll
-    for (int c = 0; c < N; c++) dv[c] += M[i * N + c] * acc[i];
+    for (int c = 0; c < N; c++) dv[c] += M[i * N + c] * tot[i];
 }
-DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv) { chain_motor_guess_n<6>(M, b, smax, acc, dv); }
+DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv, bool pinning, const float* lb0, float* la0, const float* lb1, float* la1) { chain_motor_guess_n<6>(M, b, smax, acc, dv, pinning, lb0, la0, lb1, la1); }
 // LDS form for a body with at most N joints (fixed or floating base): reads the joint block of M^-1 and the rows'
 // right-hand sides into registers, writes the starting impulses into the rows' MR_ACC slots (every sweep form picks them
 // up there and adds the velocity change they amount to before its first iteration).
@@ -608,18 +630,24 @@ DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
   const DevScene& sc = ln.sc; const float h = sc.h;
   const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
   const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
-  float M[N * N], bb[N], smax[N], acc[N], dv[N];
+  float M[N * N], bb[N], smax[N], acc[N], dv[N], lb0[N], la0[N], lb1[N], la1[N];
+  const bool pinning = sc.HF[DG_HF_LIMIT_GUESS] > 0.f;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const bool has = i < n; const int ic = has ? i : 0;
-    const float maxf = ln.mt.v[3 * (first + ic) + 2]; smax[i] = has ? (maxf < 0.f ? -maxf : maxf * h) : 0.f;
+    const float maxf = ln.mt.v[3 * (first + ic) + 2]; smax[i] = has ? (maxf < 0.f ? -maxf : maxf * sc.hm) : 0.f;
     bb[i] = has ? ln.L(mo0 + ic * MR_STRIDE + MR_B) : 0.f; dv[i] = 0.f;
+    lb0[i] = ln.L(mo0 + ic * MR_STRIDE + MR_LO_B); la0[i] = has ? ln.L(mo0 + ic * MR_STRIDE + MR_LO_ACC) : -1.f;
+    lb1[i] = ln.L(mo0 + ic * MR_STRIDE + MR_HI_B); la1[i] = has ? ln.L(mo0 + ic * MR_STRIDE + MR_HI_ACC) : -1.f;
 #pragma unroll
     for (int c = 0; c < N; c++) { const float m = ln.L(mvo + (k0 + ic) * nv + k0 + (c < n ? c : 0)); M[i * N + c] = (has && c < n) ? m : 0.f; }
   }
-  chain_motor_guess_n<N>(M, bb, smax, acc, dv);
+  chain_motor_guess_n<N>(M, bb, smax, acc, dv, pinning, lb0, la0, lb1, la1);
 #pragma unroll
-  for (int i = 0; i < N; i++) if (i < n) ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
+  for (int i = 0; i < N; i++) if (i < n) {
+    ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
+    if (pinning) { ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC) = la0[i]; ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC) = la1[i]; }  // (starting impulses of pinned limit rows; every sweep form adds their velocity change)
+  }
 }
 // LDS form for a body with more than six joints: packed Cholesky of the motorised block in the (free) transient region --
 // call it after the dynamics and before the contact rows are built there.  The motor table is uniform over the envs, so
@@ -630,7 +658,7 @@ DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
   const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
   const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
   uint32_t motors = 0u; int k = 0;
-  for (int i = 0; i < n && i < 32; i++) { const float maxf = ln.mt.v[3 * (first + i) + 2]; if ((maxf < 0.f ? -maxf : maxf * h) > 0.f) { motors |= 1u << i; k++; } }
+  for (int i = 0; i < n && i < 32; i++) { const float maxf = ln.mt.v[3 * (first + i) + 2]; if ((maxf < 0.f ? -maxf : maxf * sc.hm) > 0.f) { motors |= 1u << i; k++; } }
   if (k == 0) return;
   const bool all = k == n;  // (every joint has a motor: the usual case -- pybullet gives every joint one at load)
   auto nth = [&](int a) { if (all) return a; uint32_t m = motors; for (int t = 0; t < a; t++) m &= m - 1; return __ffs((int)m) - 1; };  // a-th motorised joint
@@ -654,7 +682,7 @@ DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
   }
   bool fits = true;  // (a body of this size whose solution does not fit its bounds starts from zero, as without the guess)
   for (int a = 0; a < k; a++) {
-    const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * h;
+    const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * sc.hm;
     fits = fits && fabsf(ln.L(Y + a) * ln.L(S + a)) <= lim;
   }
   for (int a = 0; a < k; a++) ln.L(mo0 + nth(a) * MR_STRIDE + MR_ACC) = fits ? ln.L(Y + a) * ln.L(S + a) : 0.f;
@@ -699,7 +727,7 @@ DGD float pgs_rows_generic(const Lane<LANES>& ln, int b, bool live) {
     const int gl = first + i, j = k0 + i, mo = ln.pll(gl)[PLL_MROW], col = mvo + j * nv;
     const float diag = ln.L(col + j);
     if (!LIMITS) {
-      const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+      const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * sc.hm;
       if (!(maximp > 0.f)) continue;
       const float acc = ln.L(mo + MR_ACC);
       float delta = (ln.L(mo + MR_B) - ln.L(dvo + j)) / diag;
@@ -740,7 +768,7 @@ DGD float pgs_rows_small(const Lane<LANES>& ln, int b, bool live) {
       const int gl = first + i, mo = mo0 + i * MR_STRIDE /* MROW blocks of a body are contiguous */, col = mvo + i * n;
       const float diag = ln.L(col + i);
       if (!LIMITS) {
-        const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+        const float maxf = ln.mt.v[3 * gl + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * sc.hm;
         if (maximp > 0.f) {
           const float acc = ln.L(mo + MR_ACC);
           float delta = (ln.L(mo + MR_B) - dv[i]) / diag;
@@ -797,7 +825,7 @@ struct LinkRows {
       if (gl < ln.sc.nl) fill(gl, col, mo, j, base, nv, lim);
       motors = __ballot(lim > 0.f);
     } else {
-      for (int gl = 0; gl < ln.sc.nl && gl < 64; gl++) { const float maxf = ln.mt.v[3 * gl + 2]; if ((maxf < 0.f ? -maxf : maxf * ln.sc.h) > 0.f) motors |= 1ull << gl; }
+      for (int gl = 0; gl < ln.sc.nl && gl < 64; gl++) { const float maxf = ln.mt.v[3 * gl + 2]; if ((maxf < 0.f ? -maxf : maxf * ln.sc.hm) > 0.f) motors |= 1ull << gl; }
     }
   }
   DGD void fill(int gl, int& c, int& m, int& jj, int& bs, int& n, float& lm) const {
@@ -806,7 +834,7 @@ struct LinkRows {
     n = P[PLB_NV]; bs = P[PLB_DV] - sc.dv_base;
     const int jb = ((B[DG_BI_FLAGS] & DG_BODY_FIXED) ? 0 : 6) + gl - B[DG_BI_FIRST_LINK];
     c = P[PLB_MINV] + jb * n; jj = bs + jb; m = sc.PLL[gl * PLL_STRIDE + PLL_MROW];
-    const float maxf = ln.mt.v[3 * gl + 2]; lm = maxf < 0.f ? -maxf : maxf * sc.h;
+    const float maxf = ln.mt.v[3 * gl + 2]; lm = maxf < 0.f ? -maxf : maxf * sc.hm;
   }
   DGD void get(int gl, int& c, int& m, int& jj, int& bs, int& n, float& lm) const {
     if constexpr (FULL) {
@@ -879,10 +907,11 @@ DGD int pgs_dense(const Lane<LANES>& ln, int ncont, int wave_max_cont, uint64_t 
       for (int k = 0; k < NTB; k++) dv[k] += on ? W.R[k] * W.acc : 0.f;
     }
   }
-  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess; limit rows of pinned joints: limit_guess)
     DenseCol<NTB> W; load_motor(W, __ffsll((long long)m) - 1);
+    const float tot = W.acc + fmaxf(ln.L(W.mo + MR_LO_ACC), 0.f) - fmaxf(ln.L(W.mo + MR_HI_ACC), 0.f);
 #pragma unroll
-    for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * W.acc;
+    for (int k = 0; k < NTB; k++) dv[k] += W.R[k] * tot;
   }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
@@ -1038,10 +1067,11 @@ DGD int pgs_dense_sliced(const Lane<LANES>& ln, int ncont_primary, int wave_max_
       for (int i = 0; i < NS; i++) dv[i] += on ? W.R[i] * W.acc : 0.f;
     }
   }
-  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess; limit rows of pinned joints: limit_guess)
     Col W; load_motor(W, __ffsll((long long)m) - 1);
+    const float tot = W.acc + fmaxf(lq.L(W.mo + MR_LO_ACC), 0.f) - fmaxf(lq.L(W.mo + MR_HI_ACC), 0.f);
 #pragma unroll
-    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * W.acc;
+    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * tot;
   }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
@@ -1156,6 +1186,8 @@ DGD int pgs_dense_sliced_regs(const Lane<LANES>& ln, int ncont_primary, uint64_t
 #pragma unroll
     for (int i = 0; i < NS; i++) dv[i] += lR[gl][i] * macc[gl];
     lb[0][gl] = lq.L(mo + MR_LO_B); la[0][gl] = have ? lq.L(mo + MR_LO_ACC) : -1.f; lb[1][gl] = lq.L(mo + MR_HI_B); la[1][gl] = have ? lq.L(mo + MR_HI_ACC) : -1.f;
+    { const float tl = fmaxf(la[0][gl], 0.f) - fmaxf(la[1][gl], 0.f);  // (starting impulses of pinned limit rows: limit_guess)
+      _Pragma("unroll") for (int i = 0; i < NS; i++) dv[i] += lR[gl][i] * tl; }
     lji[gl] = j >> LOG; lmine[gl] = (j & (SL - 1)) == sl;
   }
   // DoF j of the velocity change, known to every lane of the group
@@ -1343,7 +1375,7 @@ DGD int pgs_wave_env(const Lane<1>& lq, int ncont, uint64_t limit_rows, Prof<PRO
   }
   static_for<0, NLM>([&](auto jc) {  // the velocity change the motor rows' starting impulses amount to
     constexpr int j = decltype(jc)::value;
-    if ((jmotor >> j) & 1ull) dv += lRd[j] * rdl(macc, j);
+    if ((jmotor >> j) & 1ull) dv += lRd[j] * rdl(macc + fmaxf(la0, 0.f) - fmaxf(la1, 0.f), j);  // (limit rows of pinned joints: limit_guess)
   });
   if (sc.warm_off >= 0) static_for<0, 3 * CM>([&](auto rc) {  // warm start: the velocity change the rows' starting impulses amount to
     constexpr int R = decltype(rc)::value, o = 16 + (R & 15), sl_ = R >> 4;
@@ -1436,7 +1468,12 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
   // (contact rows start from the impulse their builder left in the row -- warm start -- the others from zero)
   // (per-lane slots: the whole offset goes through the vector operand)
   for (int id = sl; id < n_acc; id += SL) acc[id * EPW] = (sc.warm_off >= 0 && id < 3 * ncont) ? BL(col_off + (unsigned)(sc.tr_off + id * rsw + 2 * sc.nt + 1) * W * 4u, 0) : 0.f;
-  for (int gl = sl; gl < sc.nl; gl += SL) acc[(3 * maxc + gl) * EPW] = BL(col_off + (unsigned)(sc.PLL[gl * PLL_STRIDE + PLL_MROW] + MR_ACC) * W * 4u, 0);  // motor rows: motor_guess (zero without it)
+  for (int gl = sl; gl < sc.nl; gl += SL) {
+    const unsigned mo = (unsigned)sc.PLL[gl * PLL_STRIDE + PLL_MROW];
+    acc[(3 * maxc + gl) * EPW] = BL(col_off + (mo + MR_ACC) * W * 4u, 0);  // motor rows: motor_guess (zero without it)
+    acc[(3 * maxc + sc.nl + 2 * gl) * EPW] = fmaxf(BL(col_off + (mo + MR_LO_ACC) * W * 4u, 0), 0.f);  // limit rows of pinned joints: limit_guess
+    acc[(3 * maxc + sc.nl + 2 * gl + 1) * EPW] = fmaxf(BL(col_off + (mo + MR_HI_ACC) * W * 4u, 0), 0.f);
+  }
   float dv[NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) dv[i] = 0.f;
@@ -1494,10 +1531,11 @@ DGD int pgs_dense_sliced_global(const Lane<LANES>& ln, float* accl, float* gws, 
       for (int i = 0; i < NS; i++) dv[i] += on ? W.R[i] * W.acc : 0.f;
     }
   }
-  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess)
-    Col W; load_motor(W, __ffsll((long long)m) - 1);
+  for (uint64_t m = rows.motors; m; m &= m - 1) {  // ... and the motor rows' (motor_guess; limit rows of pinned joints: limit_guess)
+    const int gl = __ffsll((long long)m) - 1; Col W; load_motor(W, gl);
+    const float tot = W.acc + acc[(3 * maxc + sc.nl + 2 * gl) * EPW] - acc[(3 * maxc + sc.nl + 2 * gl + 1) * EPW];
 #pragma unroll
-    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * W.acc;
+    for (int i = 0; i < NS; i++) dv[i] += W.R[i] * tot;
   }
   int iters_done = 0;
   for (int it = 0; it < sc.iters; it++) {
@@ -1646,7 +1684,7 @@ DGD void integrate_body(const Lane<LANES>& ln, int b) {
 #pragma unroll
     for (int j = 0; j < LCH; j++) {
       const int i = i0 + j; if (i >= n) break;
-      const float maxf = ln.mt.v[3 * (first + i) + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * h;
+      const float maxf = ln.mt.v[3 * (first + i) + 2]; const float maximp = maxf < 0.f ? -maxf : maxf * sc.hm;
       ln.Sset(lo_[j] + DG_LS_APPLIED, maximp > 0.f ? ac_[j] / h : 0.f);
       const float qd = fminf(fmaxf(qd_[j] + dv_[j], -vmax), vmax);
       ln.Sset(lo_[j] + DG_LS_QD, qd); ln.Sset(lo_[j] + DG_LS_Q, q_[j] + h * qd);
@@ -1729,7 +1767,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
     const bool has = i < n; const int ic = has ? i : 0;  // absent rows: clamped address, zeroed value
     const float mf0 = ln.mt.v[3 * (f0 + (i < n0 ? i : 0)) + 2], mf1 = ln.mt.v[3 * (f1 + (i < n1 ? i : 0)) + 2];
     const float maxf = half ? mf1 : mf0;
-    smax[i] = has ? (maxf < 0.f ? -maxf : maxf * h) : 0.f;
+    smax[i] = has ? (maxf < 0.f ? -maxf : maxf * sc.hm) : 0.f;
     const int mo = mo0 + ic * MR_STRIDE;
     rb[i] = has ? W(mo + MR_B) : 0.f; rdg[i] = has ? W(mvo + ic * n + ic) : 1.f; rdi[i] = has ? 1.0f / rdg[i] : 0.f;
     lb[0][i] = W(mo + MR_LO_B); la[0][i] = has ? W(mo + MR_LO_ACC) : -1.f;
@@ -1739,7 +1777,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
     for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
   }
-  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv);  // the sweeps start next to their fixed point
+  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv, sc.HF[DG_HF_LIMIT_GUESS] > 0.f, lb[0], la[0], lb[1], la[1]);  // the sweeps start next to their fixed point (limit rows of pinned joints included)
   // limit rows some lane of the wavefront has active (the flags cannot change during the sweeps): bit 2 i + side.  Rows
   // nobody needs are skipped with a wave-uniform branch, so a sweep costs what the wavefront's active limits cost
   unsigned lim_rows = 0u;
@@ -2034,7 +2072,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       for (int i = 0; i < RN; i++) {
         rdv[k][i] = 0.f; rb[k][i] = 0.f; racc[k][i] = 0.f; rdi[k][i] = 0.f; rdg[k][i] = 0.f; smax[k][i] = 0.f;
         if (i < n) {
-          const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[k][i] = maxf < 0.f ? -maxf : maxf * h;
+          const float maxf = ln.mt.v[3 * (first + i) + 2]; smax[k][i] = maxf < 0.f ? -maxf : maxf * sc.hm;
           rb[k][i] = ln.L(mo0 + i * MR_STRIDE + MR_B); rdg[k][i] = ln.L(mvo + i * n + i); rdi[k][i] = 1.0f / rdg[k][i];
         }
 #pragma unroll
@@ -2051,11 +2089,19 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   const float thr_abs = sqrtf(thr);  // the register rows track |residual|; same test as residual^2 <= thr
   if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) {  // the motor rows start next to their fixed point (motor_guess)
 #pragma unroll
-    for (int k = 0; k < NBR; k++) if (sc.reg_body[k] >= 0) chain_motor_guess(rM[k], rb[k], smax[k], racc[k], rdv[k]);
-    if (has_generic) for (int b = 0; b < sc.nba; b++) {  // (their starting impulses are in the rows' MR_ACC slots)
+    for (int k = 0; k < NBR; k++) if (sc.reg_body[k] >= 0) {
+      // (the limit rows of a register-chain body are swept through LDS: their right-hand sides and starting impulses live there)
+      const int mo0 = ln.pll(ln.bi(sc.reg_body[k])[DG_BI_FIRST_LINK])[PLL_MROW]; const bool pinning = sc.HF[DG_HF_LIMIT_GUESS] > 0.f;
+      float lb0[RN], la0[RN], lb1[RN], la1[RN];
+      _Pragma("unroll") for (int i = 0; i < RN; i++) { const bool has = i < rn[k]; const int mo = mo0 + (has ? i : 0) * MR_STRIDE;
+        lb0[i] = ln.L(mo + MR_LO_B); la0[i] = has ? ln.L(mo + MR_LO_ACC) : -1.f; lb1[i] = ln.L(mo + MR_HI_B); la1[i] = has ? ln.L(mo + MR_HI_ACC) : -1.f; }
+      chain_motor_guess(rM[k], rb[k], smax[k], racc[k], rdv[k], pinning, lb0, la0, lb1, la1);
+      if (pinning) { _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) { ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC) = la0[i]; ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC) = la1[i]; } }
+    }
+    if (has_generic) for (int b = 0; b < sc.nba; b++) {  // (their starting impulses are in the rows' MR_ACC / MR_LO_ACC / MR_HI_ACC slots)
       const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0 || b == sc.reg_body[0] || b == sc.reg_body[1]) continue;
       const int first = ln.bi(b)[DG_BI_FIRST_LINK], k0 = ln.fixed(b) ? 0 : 6, nv = ln.plb(b)[PLB_NV], dvo = ln.plb(b)[PLB_DV], mvo = ln.plb(b)[PLB_MINV];
-      for (int i = 0; i < n; i++) { const float a0 = ln.L(ln.pll(first + i)[PLL_MROW] + MR_ACC); lds_axpy(ln, dvo, mvo + (k0 + i) * nv, a0, nv); }
+      for (int i = 0; i < n; i++) { const int mo = ln.pll(first + i)[PLL_MROW]; const float a0 = ln.L(mo + MR_ACC) + fmaxf(ln.L(mo + MR_LO_ACC), 0.f) - fmaxf(ln.L(mo + MR_HI_ACC), 0.f); lds_axpy(ln, dvo, mvo + (k0 + i) * nv, a0, nv); }
     }
   }
   if (wave_max_cont > 0 && sc.warm_off >= 0) {  // warm start: the velocity change the rows' starting impulses amount to

@@ -81,6 +81,12 @@ DEFAULTS = dict(
     # motor rows start from the clamped direct solution of their body's unclamped motor system instead of zero (same
     # fixed point; 35 -> 6 sweeps for ur_high_5, 26 -> 1 for from_the_readme); 0 = Bullet's cold start [R]
     motor_guess=1.0,
+    # with motor_guess: a joint whose motor target lies beyond an ACTIVE joint-limit row starts with its motor saturated into
+    # the limit and the limit row holding the balance (one unknown in the guess's linear system) -- DG_HF_LIMIT_GUESS; 0 = off
+    limit_guess=1.0,
+    # time base of a motor row's impulse bound: 'substep' (max force x fixedTimeStep / numSubSteps) or 'step' (max force x
+    # fixedTimeStep: the other reading of pybullet's maxAppliedImpulse [R]) -- DG_HF_MOTOR_IMPULSE_SCALE
+    motor_impulse_timebase='substep',
 )
 
 
@@ -634,6 +640,10 @@ class SceneBuilder:
         HF[K.HF_WARMSTART] = p['warmstart']
         HF[K.HF_WARMSTART_FRICTION] = p['warmstart_friction']
         HF[K.HF_MOTOR_GUESS] = p['motor_guess']
+        HF[K.HF_LIMIT_GUESS] = p['limit_guess'] if p['motor_guess'] > 0 else 0.0
+        if p['motor_impulse_timebase'] not in ('substep', 'step'):
+            raise ValueError("motor_impulse_timebase must be 'substep' or 'step'")
+        HF[K.HF_MOTOR_IMPULSE_SCALE] = float(self.substeps) if p['motor_impulse_timebase'] == 'step' else 1.0
         off = K.HF_FLOAT_COUNT
         chunks_f = [HF]
         for name, t in tables_f:

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 11
+#define DG_VERSION 12
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -106,6 +106,19 @@ enum {
                                   those rows are held at their bounds and the others solved again -- then the clamp;
                              n <= DG_MOTOR_GUESS_MAX:    if a row exceeds its bound the body starts from zero (as without);
                              beyond:                     no starting guess (zero) */
+  DG_HF_LIMIT_GUESS,    /* > 0 (with DG_HF_MOTOR_GUESS, bodies of n <= DG_MOTOR_GUESS_REFINE joints): a joint whose motor target
+                           lies BEYOND an active joint-limit row (target velocity b_m above what the upper-limit row allows, or
+                           below what the lower-limit row demands) enters the guess as ONE unknown -- the joint's total impulse
+                           with the limit row's velocity as its right-hand side -- and starts with its motor saturated into the
+                           limit and the limit row holding the rest (acc_limit = max force x h - |total|), unless the motor alone
+                           is too weak to reach the limit velocity (then: held at its bound, limit row at zero).  From a motor-
+                           only guess (or from zero) such a joint ramps its two rows up against each other by
+                           (b_m - b_limit) / diag per sweep until the motor saturates: hundreds of sweeps for a target a
+                           hair beyond the limit.  Same fixed point; 0 = motor rows only, as in round 3 */
+  DG_HF_MOTOR_IMPULSE_SCALE, /* impulse bound of a motor row = max force x substep x this.  1: the substep is the time base
+                           (default).  Set to the number of substeps for the other reading of pybullet -- maxAppliedImpulse =
+                           force x fixedTimeStep, the FULL step, while the solver runs at fixedTimeStep / numSubSteps [R] --
+                           engine parameter motor_impulse_timebase = 'step' */
   DG_HF_FLOAT_COUNT
 };
 

@@ -691,6 +691,7 @@ typedef struct {
   real b, lo, hi, acc, diag; /* diag = J M^-1 J^T */
   int normal_row; real mu;   /* friction rows: index of the normal row */
   int motor_link;              /* global link index for motor rows else -1 */
+  int limit_dof; real limit_sign; /* joint-limit rows: local joint index (else -1) and +1 (lower) / -1 (upper) */
 } Row;
 
 static real row_jv(const Row* r, BodyWS* wsb) {
@@ -721,7 +722,7 @@ static void tangent_basis(v3 n, v3* t1, v3* t2) { /* btPlaneSpace1 [R] */
   }
 }
 static int make_contact_row(const Scene* s, const real* st, BodyWS* wsb, const Contact* c, v3 dir, Row* r) {
-  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1;
+  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1; r->limit_dof = -1;
   BodyWS *A = &wsb[c->body_a], *Bw = &wsb[c->body_b];
   int a_dyn = !(A->fixed && A->n == 0), b_dyn = !(Bw->fixed && Bw->n == 0);
   if (!a_dyn && !b_dyn) return 0;
@@ -752,7 +753,7 @@ static int make_contact_row(const Scene* s, const real* st, BodyWS* wsb, const C
  * (torque = 0), or a unit torque about `dir` on A and the opposite on B (torque = 1).  Like make_contact_row, the row's
  * first side is the dynamic one of (A, B). */
 static int make_constraint_row(const Scene* s, const real* st, BodyWS* wsb, const int32_t* ki, v3 pa, v3 pb, v3 dir, int torque, Row* r) {
-  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1; r->body_b = -1;
+  memset(r, 0, sizeof *r); r->motor_link = -1; r->normal_row = -1; r->limit_dof = -1; r->body_b = -1;
   const int ba = ki[DG_KI_BODY_A], bb = ki[DG_KI_BODY_B];
   BodyWS *A = &wsb[ba], *Bw = &wsb[bb];
   const int la = ki[DG_KI_LINK_A] < 0 ? -1 : ki[DG_KI_LINK_A] - A->first, lb = ki[DG_KI_LINK_B] < 0 ? -1 : ki[DG_KI_LINK_B] - Bw->first;
@@ -816,46 +817,14 @@ static void substep(dgo_world* w, int env, int last) {
     for (int i = 0; i < ws->n; i++) {
       int gl = ws->first + i; real* ls = st + link_i(s, gl)[DG_LI_STATE_OFF]; const real* mc = w->mcfg + gl * DG_MC_STRIDE;
       ls[DG_LS_APPLIED] = 0.0;
-      real maxf = mc[DG_MC_MAX_IMPULSE_SCALE], maximp = maxf < 0 ? -maxf : maxf * h;
+      real maxf = mc[DG_MC_MAX_IMPULSE_SCALE], maximp = maxf < 0 ? -maxf : maxf * h * s->F[DG_HF_MOTOR_IMPULSE_SCALE]; /* time base of the bound: substep or full step [R] */
       if (maximp > 0) {
-        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = gl;
+        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = gl; r->limit_dof = -1;
         body_response(ws, -1, NULL, i, r->JA, r->RA);
         r->diag = r->RA[6 + i];
         /* rhs = kp*(q*-q)/dt + qd + kd*(qd*-qd) as a velocity target; error = target - qd */
         r->b = mc[DG_MC_KP] * (ls[DG_LS_TARGET_POS] - ls[DG_LS_Q]) / h + mc[DG_MC_KD] * (ls[DG_LS_TARGET_VEL] - ls[DG_LS_QD]);
         r->lo = -maximp; r->hi = maximp;
-      }
-    }
-  }
-  /* Starting impulses of the motor rows (DG_HF_MOTOR_GUESS): without the clamps a body's motor rows are the linear system
-   * (M^-1 restricted to the motorised joints) lambda = b, solved directly here and clamped to the rows' bounds -- the
-   * sweeps then start next to their fixed point instead of at zero (Bullet starts at zero [R]; the fixed point is the
-   * same, the residual early-out fires after ~6 sweeps instead of ~35 for a position-controlled arm). */
-  if (s->F[DG_HF_MOTOR_GUESS] > 0) {
-    int r0 = 0;
-    for (int b = 0; b < s->nb; b++) {
-      BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
-      for (int r = r0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
-      if (k == 0 || ws->n > DG_MOTOR_GUESS_MAX) continue;
-      /* (symmetrically scaled to a unit diagonal first: finger joints and shoulder joints differ by 1e5 in M^-1, and the
-       * device solves this in fp32) */
-      real A[MAXL * MAXL], bb[MAXL], x[MAXL], sc_[MAXL];
-      for (int j = 0; j < k; j++) sc_[j] = 1.0 / sqrt(rows[idx[j]].RA[6 + dof[j]]);
-      for (int j = 0; j < k; j++) { bb[j] = rows[idx[j]].b * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l]; }
-      if (!spd_solve(k, A, bb, x)) continue;
-      int held[MAXL], any = 0; real val[MAXL];
-      for (int j = 0; j < k; j++) { const Row* r = &rows[idx[j]]; const real imp = x[j] * sc_[j]; held[j] = imp < r->lo || imp > r->hi; any |= held[j]; val[j] = (imp < r->lo ? r->lo : r->hi) / sc_[j]; }
-      if (any && ws->n > DG_MOTOR_GUESS_REFINE) continue; /* a bigger body whose solution does not fit its bounds: zero start */
-      if (any) { /* one active-set round: the rows beyond their bounds held there, the others solved again */
-        real A2[MAXL * MAXL], b2[MAXL];
-        for (int j = 0; j < k; j++) { b2[j] = bb[j]; for (int l = 0; l < k; l++) A2[l * k + j] = A[l * k + j]; }
-        for (int j = 0; j < k; j++) if (held[j]) for (int l = 0; l < k; l++) if (!held[l]) b2[l] -= A[l * k + j] * val[j];
-        for (int j = 0; j < k; j++) if (held[j]) { for (int l = 0; l < k; l++) { A2[l * k + j] = 0; A2[j * k + l] = 0; } A2[j * k + j] = 1; b2[j] = val[j]; }
-        if (!spd_solve(k, A2, b2, x)) continue;
-      }
-      for (int j = 0; j < k; j++) {
-        Row* r = &rows[idx[j]]; real imp = x[j] * sc_[j]; imp = imp < r->lo ? r->lo : (imp > r->hi ? r->hi : imp);
-        r->acc = imp; for (int q = 0; q < 6 + ws->n; q++) ws->dv[q] += r->RA[q] * imp;
       }
     }
   }
@@ -868,13 +837,69 @@ static void substep(dgo_world* w, int env, int last) {
         real sg = side == 0 ? 1.0 : -1.0;
         real dist = side == 0 ? ls[DG_LS_Q] - lf[DG_LF_LOWER] : lf[DG_LF_UPPER] - ls[DG_LS_Q];
         if (dist >= 0.25) continue; /* rows that cannot become active within one substep are skipped */
-        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = -1;
+        Row* r = &rows[nr++]; memset(r, 0, sizeof *r); r->body_a = b; r->body_b = -1; r->normal_row = -1; r->motor_link = -1; r->limit_dof = i; r->limit_sign = sg;
         body_response(ws, -1, NULL, i, r->JA, r->RA);
         for (int k = 0; k < 6 + ws->n; k++) { r->JA[k] *= sg; r->RA[k] *= sg; }
         r->diag = r->RA[6 + i] * sg;
         real relv = sg * ls[DG_LS_QD];
         r->b = -relv + (dist > 0 ? -dist / h : -dist * erp / h);
         r->lo = 0; r->hi = HUGE_R;
+      }
+    }
+  }
+  /* Starting impulses of the motor rows (DG_HF_MOTOR_GUESS): without the clamps a body's motor rows are the linear system
+   * (M^-1 restricted to the motorised joints) lambda = b, solved directly here and clamped to the rows' bounds -- the
+   * sweeps then start next to their fixed point instead of at zero (Bullet starts at zero [R]; the fixed point is the
+   * same, the residual early-out fires after ~6 sweeps instead of ~35 for a position-controlled arm).
+   * DG_HF_LIMIT_GUESS: a joint whose motor target lies beyond an ACTIVE limit row of the same joint (the two rows share their
+   * Jacobian) is "pinned": it enters the system as one unknown, the joint's total impulse t, with the limit row's velocity as
+   * right-hand side; it starts with the motor saturated into the limit (dir x bound) and the limit row holding the balance,
+   * bound - dir x t >= 0 -- unless the motor alone cannot reach the limit velocity (dir x t > bound: held at its bound like any
+   * other row that leaves its bounds, limit row at zero).  Left to the sweeps, such a pair of rows ramps up against each other
+   * by (b_motor - b_limit) / diag per sweep until the motor saturates. */
+  if (s->F[DG_HF_MOTOR_GUESS] > 0) {
+    const int pinning = s->F[DG_HF_LIMIT_GUESS] > 0;
+    for (int b = 0; b < s->nb; b++) {
+      BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
+      for (int r = 0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
+      if (k == 0 || ws->n > DG_MOTOR_GUESS_MAX) continue;
+      /* (symmetrically scaled to a unit diagonal first: finger joints and shoulder joints differ by 1e5 in M^-1, and the
+       * device solves this in fp32) */
+      real A[MAXL * MAXL], bb[MAXL], x[MAXL], sc_[MAXL]; int pin[MAXL], lrow[MAXL];
+      for (int j = 0; j < k; j++) sc_[j] = 1.0 / sqrt(rows[idx[j]].RA[6 + dof[j]]);
+      for (int j = 0; j < k; j++) {
+        real target = rows[idx[j]].b; pin[j] = 0; lrow[j] = -1;
+        if (pinning && ws->n <= DG_MOTOR_GUESS_REFINE)
+          for (int r = 0; r < nr; r++) { /* the joint's active limit rows: JA = +-e_dof, b = the velocity the row demands along JA */
+            const Row* q = &rows[r]; if (q->body_a != b || q->motor_link >= 0 || q->limit_dof != dof[j]) continue;
+            const real sg = q->limit_sign, vlim = sg * q->b; /* lower (sg = +1): dv >= vlim; upper (sg = -1): dv <= vlim */
+            if (sg > 0 ? rows[idx[j]].b < vlim : rows[idx[j]].b > vlim) { pin[j] = sg > 0 ? -1 : 1; lrow[j] = r; target = vlim; }
+          }
+        bb[j] = target * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l];
+      }
+      if (!spd_solve(k, A, bb, x)) continue;
+      int held[MAXL], any = 0; real val[MAXL];
+      for (int j = 0; j < k; j++) {
+        const Row* r = &rows[idx[j]]; const real imp = x[j] * sc_[j];
+        /* a pinned joint has a one-sided bound: dir x t <= the motor's bound (beyond it the motor is too weak to reach the limit) */
+        held[j] = pin[j] ? pin[j] * imp > r->hi : (imp < r->lo || imp > r->hi); any |= held[j];
+        val[j] = (pin[j] ? pin[j] * r->hi : (imp < r->lo ? r->lo : r->hi)) / sc_[j];
+      }
+      if (any && ws->n > DG_MOTOR_GUESS_REFINE) continue; /* a bigger body whose solution does not fit its bounds: zero start */
+      if (any) { /* one active-set round: the rows beyond their bounds held there, the others solved again */
+        real A2[MAXL * MAXL], b2[MAXL];
+        for (int j = 0; j < k; j++) { b2[j] = bb[j]; for (int l = 0; l < k; l++) A2[l * k + j] = A[l * k + j]; }
+        for (int j = 0; j < k; j++) if (held[j]) for (int l = 0; l < k; l++) if (!held[l]) b2[l] -= A[l * k + j] * val[j];
+        for (int j = 0; j < k; j++) if (held[j]) { for (int l = 0; l < k; l++) { A2[l * k + j] = 0; A2[j * k + l] = 0; } A2[j * k + j] = 1; b2[j] = val[j]; }
+        if (!spd_solve(k, A2, b2, x)) continue;
+      }
+      for (int j = 0; j < k; j++) {
+        Row* r = &rows[idx[j]]; real t = x[j] * sc_[j], imp, lim = 0.0;
+        if (pin[j] && !held[j]) { /* motor saturated into the limit, the limit row holds the balance (never negative) */
+          imp = pin[j] * r->hi; lim = r->hi - pin[j] * t; if (lim < 0) lim = 0;
+          Row* q = &rows[lrow[j]]; q->acc = lim; t = imp - pin[j] * lim; /* (the limit row pushes along -dir) */
+        } else { imp = t < r->lo ? r->lo : (t > r->hi ? r->hi : t); t = imp; }
+        r->acc = imp; for (int q = 0; q < 6 + ws->n; q++) ws->dv[q] += r->RA[q] * t;
       }
     }
   }

@@ -604,3 +604,81 @@ def test_fp32_build_of_the_oracle_and_what_it_says_about_tolerances():
         a.sim.step(a._all_slots, act); b.sim.step(b._all_slots, act)
         single += list(np.abs(a.sim.get_state() - b.sim.get_state())[:, kin].max(1))
     assert np.median(single) < 1e-4 and np.quantile(single, 0.9) < 1e-2 and np.max(single) > 1e-2, (np.median(single), np.quantile(single, 0.9), np.max(single))
+
+
+# ---- limit_guess: a motor pushing into an active joint limit (DG_HF_LIMIT_GUESS) -----------------------------------------------
+def _limited_pendulum(tmp_path, rest, iterations=150, **engine):
+    import yaml
+    cfg = {'render': False, 'solver_iterations': iterations,
+           'pend': {'model': os.path.join(G, 'urdf', 'pendulum_limited.urdf'), 'xyz': [0, 0, 0],
+                    'drive': {'addon': 'joint_controller', 'control_mode': 'position', 'rest_position': [rest]},
+                    'joints': {'addon': 'joint_state_sensor', 'include_effort': True}}}
+    path = tmp_path / ('limited_%s_%d.yaml' % ('_'.join('%s%s' % kv for kv in sorted(engine.items())), iterations))
+    yaml.safe_dump(cfg, open(path, 'w'), sort_keys=False)
+    return make(str(path), **NODAMP, **engine)
+
+
+@pytest.mark.parametrize('side', [1.0, -1.0])
+def test_motor_pushed_into_a_joint_limit_starts_at_its_fixed_point(tmp_path, side):
+    """A 1 kg bob on a 0.5 m arm rests ON its joint limit (+-0.5 rad); the position target lies 1e-4 rad beyond it.  The two
+    rows of that joint share their Jacobian: the fixed point is the motor saturated into the limit (+-300 N m, the URDF's
+    effort) with the limit row holding whatever gravity (m g L sin q = 2.35 N m, pulling back towards 0) leaves of it.  Left to the sweeps the two rows ramp
+    up against each other by (b_motor - b_limit) / diag per sweep -- ~1 700 sweeps here -- so at pybullet's 150 iterations
+    the reported effort is a few per cent of the true one.  With limit_guess the joint enters the motor guess as one
+    unknown and the sweeps start AT that fixed point.  Asserted: effort = +-300 to 1e-6 after <= 3 sweeps; the joint does
+    not move; without the guess the cap is hit and the effort is far off; and with the cap lifted the ungessed sweeps
+    reach the same state (same fixed point)."""
+    q0 = 0.5 * side
+    act = torch.tensor([[q0 + 1e-4 * side]])
+    on = _limited_pendulum(tmp_path, q0)
+    on.sim.step(on._all_slots, act)
+    qo = link_q(on, 0, 0)
+    s = on.sim.get_state()[0]
+    assert on.sim.iterations(0) <= 3, on.sim.iterations(0)
+    assert abs(s[qo + K.LS_APPLIED] - 300.0 * side) < 1e-6 and abs(s[qo] - q0) < 1e-6 and abs(s[qo + 1]) < 1e-6
+    off = _limited_pendulum(tmp_path, q0, limit_guess=0.0)
+    off.sim.step(off._all_slots, act)
+    so = off.sim.get_state()[0]
+    assert off.sim.iterations(0) == 150 and abs(so[qo + K.LS_APPLIED]) < 60.0   # the ramp: 150 of ~1 700 sweeps
+    assert abs(so[qo] - q0) < 1e-5                                               # (the joint itself is held either way)
+    full = _limited_pendulum(tmp_path, q0, iterations=20000, limit_guess=0.0)
+    full.sim.step(full._all_slots, act)
+    sf = full.sim.get_state()[0]
+    assert 150 < full.sim.iterations(0) < 20000
+    assert abs(sf[qo + K.LS_APPLIED] - 300.0 * side) < 1e-2 and abs(sf[qo] - s[qo]) < 1e-7 and abs(sf[qo + 1] - s[qo + 1]) < 1e-6
+
+
+def test_limit_guess_leaves_a_motor_alone_that_cannot_reach_the_limit(tmp_path):
+    """The other branch: the limit row is a candidate (the joint is within 0.25 rad of the limit) and the target lies beyond it,
+    but the motor (2 N m) is weaker than gravity (2.1 N m at 0.45 rad): it cannot even hold the joint, let alone reach the
+    limit velocity.  The pinned unknown then exceeds the motor's bound, the joint is held at that bound like any saturated
+    row and the limit row starts at zero -- the state after 20 steps is the one without limit_guess, bit for bit, and the
+    bob sinks."""
+    act = torch.tensor([[0.6]])
+    a = _limited_pendulum(tmp_path, 0.45); b = _limited_pendulum(tmp_path, 0.45, limit_guess=0.0)
+    for e in (a, b):
+        e.sim.set_motor_cfg(np.array([[0.03, 1.0, 2.0]]))
+    for _ in range(20):
+        for e in (a, b):
+            e.sim.step(0)   # (mask 0: the controller op does not rewrite the motor table; targets stay at the reset's rest position)
+    qo = link_q(a, 0, 0)
+    sa, sb = a.sim.get_state()[0], b.sim.get_state()[0]
+    assert np.array_equal(sa, sb) and sa[qo] < 0.45 - 1e-5 and abs(abs(sa[qo + K.LS_APPLIED]) - 2.0) < 1e-9
+
+
+def test_motor_impulse_time_base_substep_or_full_step(tmp_path):
+    """``motor_impulse_timebase``: the impulse bound of a motor row is max force x the SUBSTEP by default; 'step' makes it max
+    force x the full fixedTimeStep -- the other reading of pybullet's maxAppliedImpulse [R] -- i.e. a saturated motor is
+    numSubSteps (2) times as strong.  A 1.5 N m velocity motor against 1.91 N m of gravity at 0.4 rad: saturated and sinking
+    in the first reading; in the second its bound is 3.0 N m, it holds the joint and reports the gravity torque."""
+    q0 = 0.4
+    sub = _limited_pendulum(tmp_path, q0); full = _limited_pendulum(tmp_path, q0, motor_impulse_timebase='step')
+    for e in (sub, full):
+        e.sim.set_motor_cfg(np.array([[0.0, 1.0, 1.5]]))   # velocity motor, target 0, 1.5 N m
+        for _ in range(10):
+            e.sim.step(0)
+    qo = link_q(sub, 0, 0)
+    ss, sf = sub.sim.get_state()[0], full.sim.get_state()[0]
+    grav = 1.0 * 9.81 * 0.5 * np.sin(q0)   # 1.91 N m
+    assert abs(abs(ss[qo + K.LS_APPLIED]) - 1.5) < 1e-9 and ss[qo] < q0 - 1e-5         # 1.5 < 1.91: saturated, sinks
+    assert abs(abs(sf[qo + K.LS_APPLIED]) - grav) < 2e-2 and abs(sf[qo] - q0) < 1e-4   # bound 3.0 > 1.91: holds, effort = gravity

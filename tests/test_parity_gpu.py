@@ -270,6 +270,77 @@ def test_arms_driven_into_their_joint_limits(env_var):
     assert worst < 2e-3, worst
 
 
+@pytest.mark.parametrize('env_var', [None, 'DG_NO_HELPER_WAVE', 'DG_NO_SPLIT_SWEEPS'])
+def test_motors_pushing_into_joint_limits_start_at_their_fixed_point(env_var):
+    """limit_guess (DG_HF_LIMIT_GUESS) in the register sweeps of ur_high_5: both elbows start folded back ONTO their lower limit
+    (-pi), which is where thousands of random IK steps without an episode limit take them (bench.py's `aged` segment); every
+    second random IK target then lies a hair beyond the limit.  Without the guess such an env ramps its motor row and its
+    limit row up against each other for all 150 sweeps and its wavefront waits; with it both sides start at the fixed point.
+    Asserted against the oracle: observations, efforts (the pinned joints report the SATURATED motor, +-150 N m), iteration
+    counts within a few sweeps of each other and far below the cap, and that pinning actually happened."""
+    if env_var:
+        os.environ[env_var] = '1'
+    try:
+        gpu, cpu = make_pair('ur_ik', 67)
+        _, cold = make_pair('ur_ik', 67, limit_guess=0.0)
+    finally:
+        if env_var:
+            del os.environ[env_var]
+    L = gpu.layout
+    st = np.array(cpu.sim.get_state())
+    for arm in range(2):
+        o = L.link_state_off[6 * arm + 2]
+        st[:, o] = -np.pi + 1e-4 * (1 + np.arange(67) % 5); st[:, o + 1] = 0.0
+    gpu.sim.set_state(st); cpu.sim.set_state(st); cold.sim.set_state(st)
+    d = gpu.sim.enable_diagnostics()
+    lo, hi = action_bounds(gpu)
+    gen = torch.Generator().manual_seed(7)
+    worst_obs = worst_it = 0.0; most_it = most_cold = 0; saturated = 0
+    eo, _ = effort_columns(gpu)
+    for i in range(25):
+        act = lo + (hi - lo) * torch.rand((67, lo.numel()), generator=gen)
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act); cold.sim.step(cold._all_slots, act)
+        worst_obs = max(worst_obs, float((gpu.sim.obs.cpu() - cpu.sim.obs).abs()[:, :12].max()))
+        itc = np.array([cpu.sim.iterations(e) for e in range(67)]); itg = d[:, 1].cpu().numpy()
+        worst_it = max(worst_it, float(np.abs(itg - itc).max())); most_it = max(most_it, int(itc.max())); most_cold = max(most_cold, max(cold.sim.iterations(e) for e in range(67)))
+        a = np.asarray(cpu.sim.get_state()); g = np.asarray(gpu.sim.get_state())
+        for arm in range(2):
+            o = L.link_state_off[6 * arm + 2] + 5   # DG_LS_APPLIED of the elbow
+            sat = np.abs(np.abs(a[:, o]) - 150.0) < 1e-3
+            saturated += int(sat.sum())
+            assert np.abs(g[sat, o] - a[sat, o]).max(initial=0.0) < 1e-2   # the same joints are pinned, at the same (saturated) effort
+    assert worst_obs < 5e-4, worst_obs
+    assert saturated >= 10, saturated                 # pinning happened (20 elbow-steps in the oracle: most targets lead away from the limit)
+    assert most_cold == 150 and most_it < 60, (most_cold, most_it)   # what it is for
+    assert worst_it <= 6, worst_it
+
+
+@pytest.mark.parametrize('env_vars,lanes', [({}, 64), ({'DG_MAX_LANES': '32'}, 32), ({'DG_MAX_LANES': '16'}, 16), ({'DG_MAX_LANES': '8'}, 8),
+                                             ({'DG_MAX_LANES': '8', 'DG_NO_REG_ROWS': '1'}, 8), ({'DG_MAX_LANES': '4'}, 4), ({'DG_MAX_LANES': '1'}, 1)])
+def test_limit_guess_in_the_dense_sweep_forms(env_vars, lanes):
+    """The same starting impulses through the forms that keep every row of a scene in one sweep (64 envs per wavefront streamed,
+    lane-sliced from LDS and from registers, one env per wavefront): cart_tree's pole joints have tight limits, and the top of
+    the action range drives them in (tests/test_oracle_kat.py::test_joint_limit_stops_a_falling_link).  The limit rows of the
+    pinned joints start from a non-zero impulse, whose velocity change every form has to add before its first sweep."""
+    os.environ.update(env_vars)
+    try:
+        gpu, cpu = make_pair('cart_tree', 9, residual_threshold=1e-13)
+        _, off = make_pair('cart_tree', 9, residual_threshold=1e-13, limit_guess=0.0)
+    finally:
+        for k in env_vars:
+            del os.environ[k]
+    assert gpu.sim.lanes == lanes
+    lo, hi = action_bounds(gpu)
+    act = hi[None].repeat(9, 1)
+    worst = 0.0
+    for _ in range(60):
+        gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act); off.sim.step(off._all_slots, act)
+        worst = max(worst, float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()))
+    assert worst < 2e-3, worst
+    assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5 * CART_STATE_TOL
+    assert np.abs(phys_state(cpu) - phys_state(off)).max() > 1e-9     # the guess took part (same fixed point, another path to it)
+
+
 def test_arms_in_contact_under_ik_control_30_steps():
     gpu, cpu = make_pair('touching_ik', 37)
     d = gpu.sim.enable_diagnostics()

@@ -164,12 +164,59 @@ def usable_cores():
     return n
 
 
-def pybullet_status():
+def pybullet_baseline(seconds=10.0):
+    """SURVEY 8(d)'s opportunistic leg: when the pybullet module happens to be importable on the box, a loop WRITTEN HERE that
+    issues the call sequence of one reference env-step of ur_high_5 (diy_gym/diy_gym.py:187-209 with the addons of
+    examples/ur_high_5/ur_high_5.yaml: per arm getLinkState -> calculateInverseKinematics with the null-space lists ->
+    setJointMotorControlArray(POSITION_CONTROL); stepSimulation; per arm getJointStates; reach_target's getLinkState pairs for
+    reward and terminal) on one core, from this repo's own URDF files.  Nothing of the reference is imported.  pybullet is
+    absent from this image, so this function cannot be exercised here: any failure is reported as a string, never raised."""
     try:
-        import pybullet  # noqa: F401
-        return 'importable here but not timed (no reference code travels to the GPU box)'
+        import pybullet as p
     except Exception:
-        return 'unavailable on this box'
+        return {'status': 'pybullet unavailable on this box'}
+    try:
+        import numpy as np
+        cid = p.connect(p.DIRECT)
+        p.resetSimulation(physicsClientId=cid)
+        p.setPhysicsEngineParameter(fixedTimeStep=1.0 / 240.0, numSolverIterations=150, numSubSteps=2, physicsClientId=cid)
+        p.setGravity(0.0, 0.0, -9.81, physicsClientId=cid)
+        urdf = os.path.join(ROOT, 'diy_gym_amd', 'data', 'ur5', 'ur5_robot.urdf')
+        rest = [-0.17, -0.73, -1.93, -0.36, -0.03, -0.06]
+        arms = []
+        for xyz, yaw in (([-0.55, 0.4, 0.0], -1.57), ([0.55, 0.4, 0.0], 1.57)):
+            uid = p.loadURDF(urdf, physicsClientId=cid)
+            p.resetBasePositionAndOrientation(uid, xyz, p.getQuaternionFromEuler([0.0, 0.0, yaw]), physicsClientId=cid)
+            info = [p.getJointInfo(uid, i, physicsClientId=cid) for i in range(p.getNumJoints(uid, physicsClientId=cid))]
+            ee = [i[0] for i in info if i[1].decode() == 'ee_fixed_joint'][0]
+            joints = [i for i in info if i[3] > -1 and i[0] <= ee]
+            ids = [i[0] for i in joints]
+            for j, q in zip(ids, rest):
+                p.resetJointState(uid, j, q, physicsClientId=cid)
+            arms.append(dict(uid=uid, ee=ee, ids=ids, lo=[i[8] for i in joints], hi=[i[9] for i in joints], rng=[i[9] - i[8] for i in joints],
+                             force=[i[10] for i in joints]))
+        rng = np.random.RandomState(0)
+        steps, t0 = 0, time.time()
+        while time.time() - t0 < seconds:
+            for a in arms:
+                ls = p.getLinkState(a['uid'], a['ee'], physicsClientId=cid)
+                pos = [c + d for c, d in zip(ls[0], rng.uniform(-0.01, 0.01, 3))]
+                orn = p.multiplyTransforms([0, 0, 0], ls[1], [0, 0, 0], p.getQuaternionFromEuler(list(rng.uniform(-0.01, 0.01, 3))))[1]
+                q = p.calculateInverseKinematics(a['uid'], a['ee'], pos, orn, lowerLimits=a['lo'], upperLimits=a['hi'], jointRanges=a['rng'], restPoses=rest, physicsClientId=cid)
+                p.setJointMotorControlArray(a['uid'], a['ids'], p.POSITION_CONTROL, targetPositions=list(q)[:len(a['ids'])], positionGains=[0.015] * len(a['ids']),
+                                            velocityGains=[1.0] * len(a['ids']), forces=a['force'], physicsClientId=cid)
+            p.stepSimulation(physicsClientId=cid)
+            for a in arms:
+                p.getJointStates(a['uid'], a['ids'], physicsClientId=cid)
+            for _ in range(3):  # reach_target: reward + terminal, object_state_sensor
+                p.getLinkState(arms[0]['uid'], arms[0]['ee'], computeLinkVelocity=1, physicsClientId=cid); p.getLinkState(arms[1]['uid'], arms[1]['ee'], computeLinkVelocity=1, physicsClientId=cid)
+            steps += 1
+        dt = time.time() - t0
+        p.disconnect(cid)
+        return {'status': 'timed', 'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'steps': steps, 'seconds': round(dt, 2),
+                'what': 'build-written single-env loop over the pybullet module: the call sequence of one ur_high_5 reference step'}
+    except Exception as exc:  # pragma: no cover
+        return {'status': 'pybullet importable but the loop failed: %r' % (exc, )}
 
 
 def cpu_baseline(cfg, act_dim, lo, hi, seconds=4.0):
@@ -202,10 +249,11 @@ def cpu_baseline(cfg, act_dim, lo, hi, seconds=4.0):
     f32_n = rate('f32_omp', 64 * cores, seconds)
     f64_n = rate('f64_omp', 64 * cores, seconds)
     head = f32_n or f32_1 or f64_n
+    pyb = pybullet_baseline()
     return {'value': head['value'], 'unit': 'env-steps/s', 'cores': cores if head is not f32_1 else 1, 'kind': 'port', 'nproc': os.cpu_count(),
-            'fp32_1_core': f32_1, 'fp32_all_cores': f32_n, 'fp64_all_cores': f64_n,
+            'fp32_1_core': f32_1, 'fp32_all_cores': f32_n, 'fp64_all_cores': f64_n, 'pybullet': pyb,
             'sample': 'same config, random actions, ~%.0f s each: C oracle built as fp32 on 1 core (64 envs), fp32 with OpenMP over envs on %d cores (%d envs) '
-                      '[= value], fp64 on %d cores; pybullet itself is %s' % (seconds, cores, 64 * cores, cores, pybullet_status())}
+                      '[= value], fp64 on %d cores; pybullet itself: %s' % (seconds, cores, 64 * cores, cores, pyb['status'])}
 
 
 def quantiles(t):
@@ -215,13 +263,252 @@ def quantiles(t):
             'max': float(f.max())}
 
 
+# ----------------------------------------------------------------------------------------------- legs
+# A LEG = one world + one action ring + the loop the timed region runs on it.  The headline line is the leg `main`; the
+# default N = 1 run adds short legs for the other tail of the headline scene and for the other BASELINE configs:
+#   in_contact   ur_high_5, every env started from the crossed-forearms pose of tests/golden/ur_arms_touching_ik.yaml
+#   mixed        ur_high_5, every 100th env started from that pose (one touching env per 1.6 wavefronts)
+#   reference_solver_settings   ur_high_5 with motor_guess = 0, warmstart = 0.85: zero-started sweeps as the reference runs them [R]
+#   configs.*    r2d2_maze x 4 096, drone_pilot x 16 384, from_the_readme x 1 024 (BASELINE.json cfg 2, 4, 5)
+CROSSED = [1.35, -1.08, 1.03, -0.01, 0.09, 0.86]   # rest_position of tests/golden/ur_arms_touching_ik.yaml
+REFERENCE_SETTINGS = {'motor_guess': 0.0, 'warmstart': 0.85}
+LEGS = {
+    # name: (workload, envs or None (BASELINE size), engine overrides, fraction of envs put into the crossed pose, steps timed)
+    'in_contact': ('ur_high_5', None, None, 1.0, 104),
+    'mixed': ('ur_high_5', None, None, 0.01, 104),
+    'reference_solver_settings': ('ur_high_5', None, REFERENCE_SETTINGS, 0.0, 104),
+    'r2d2_maze': ('r2d2_maze', None, None, 0.0, 104),
+    'drone_pilot': ('drone_pilot', None, None, 0.0, 104),
+    'from_the_readme': ('from_the_readme', None, None, 0.0, 104),
+}
+CONFIG_LEGS = ('r2d2_maze', 'drone_pilot', 'from_the_readme')
+KERNEL_OF = {'from_the_readme': 'render_kernel'}   # dominant kernel quoted in a leg's roofline (default: the step kernel)
+
+
+class Leg:
+    R = 8  # action batches in the ring = steps per replayed graph segment
+
+    def __init__(self, name, workload, device, rank=0, envs=None, engine=None, crossed_frac=0.0, auto_reset=True):
+        import torch
+        import diy_gym_amd.examples  # noqa: F401
+        from diy_gym_amd import DIYGym
+        self.torch, self.name, self.workload, self.device = torch, name, workload, device
+        cfg_rel, self.desc = WORKLOADS[workload]
+        self.cfg = os.path.join(ROOT, cfg_rel)
+        self.B = B = envs or DEFAULT_ENVS.get(workload, 16384)
+        self.engine = dict(engine) if engine else None
+        self.env = env = DIYGym(self.cfg, num_envs=B, device=device, seed=1234, env_index_base=rank * B, engine=self.engine)
+        self.lo, self.hi = action_bounds(env)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        self.ring = [(self.lo + (self.hi - self.lo) * torch.rand((B, self.lo.numel()), generator=gen)).to(device) for _ in range(self.R)]
+        self.sim, self.slots, self.auto_reset = env.sim, env._all_slots, auto_reset
+        self.cameras = [a for r in env.receptors.values() for a in r.addons.values() if hasattr(a, 'camera_index')]
+        self.image_bytes = 0
+        for cam in self.cameras:  # allocate the image buffers once; the timed step renders into them
+            cam.observe()
+            self.image_bytes += sum(t.numel() * t.element_size() for t in cam._buffers if t is not None) // B
+        self.crossed_frac = crossed_frac
+        if crossed_frac > 0.0:  # joint angles of the chosen envs = the crossed-forearms pose, at rest
+            from diy_gym_amd.scene import K
+            every = max(1, int(round(1.0 / crossed_frac)))
+            idx = torch.arange(0, B, every, device=device)
+            L = env.layout
+            for arm in range(2):
+                for j, q in enumerate(CROSSED):
+                    o = L.link_state_off[6 * arm + j]
+                    self.sim.state[o + K.LS_Q, idx] = q
+                    self.sim.state[o + K.LS_QD, idx] = 0.0
+                    self.sim.state[o + K.LS_TARGET_POS, idx] = q
+            self.crossed_envs = int(idx.numel())
+        self.graph = self.graph_rest = self.graph_kernel = None
+        self.kernel_name = KERNEL_OF.get(workload, 'step_kernel_par' if getattr(self.sim, 'par', False) else 'step_kernel')
+        self.step_launches = 0   # step-kernel launches so far (eager or replayed): the profiled child's manifest counts them
+
+    def one_step(self, i):
+        self.sim.step(self.slots, self.ring[i % self.R])
+        for cam in self.cameras:
+            self.sim.render(cam.camera_index, *cam._buffers)
+        if self.auto_reset:
+            self.sim.reset(self.sim.term_flag)
+
+    def eager(self, n, start=0):
+        for i in range(start, start + n):
+            self.one_step(i)
+        self.step_launches += n
+
+    def capture(self, steps):
+        """hipGraphs of the timed loop: segments of R consecutive steps (+ a shorter one for steps % R), and the step kernel
+        alone for kernel_times().  Every graph gets ONE UNTIMED replay here, whatever --warmup says: the first launch of a
+        freshly instantiated hipGraph can pay a one-off upload of tens of milliseconds (profiles/, round 3)."""
+        torch, R = self.torch, self.R
+
+        def cap(n_steps, body):
+            st = torch.cuda.Stream(device=self.device)
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(st):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for i in range(n_steps):
+                        body(i)
+            torch.cuda.current_stream(self.device).wait_stream(st)
+            torch.cuda.synchronize()
+            return g
+
+        try:
+            self.graph = cap(R, self.one_step)
+            if steps % R:
+                self.graph_rest = cap(steps % R, self.one_step)
+            self.graph_kernel = cap(R, lambda i: self.sim.step(self.slots, self.ring[i % R]))
+        except Exception as exc:  # pragma: no cover
+            print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
+            self.graph = self.graph_rest = self.graph_kernel = None
+            return 0
+        n = 0
+        self.graph.replay(); n += R
+        if self.graph_rest is not None:
+            self.graph_rest.replay(); n += steps % R
+        self.graph_kernel.replay(); n += R
+        torch.cuda.synchronize()
+        self.step_launches += n
+        return n
+
+    def run(self, steps):
+        """EXACTLY `steps` steps, no synchronisation (the caller brackets it)."""
+        R = self.R
+        if self.graph is not None:
+            for _ in range(steps // R):
+                self.graph.replay()
+            if steps % R:
+                self.graph_rest.replay()
+        else:
+            for i in range(steps):
+                self.one_step(i)
+        self.step_launches += steps
+
+    def timed(self, steps):
+        torch = self.torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.run(steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def kernel_times(self, n):
+        """Average duration of the dominant kernel(s) by HIP events on the launch stream (torch's current stream IS the
+        stream the C-ABI launches on), same inputs, right after the timed region.  The step kernel: events around
+        replays of a graph of R back-to-back step launches (no host launch gaps inside); eager launches bracketed one by
+        one -- launch overhead included -- are reported next to it.  The render kernel: eager."""
+        import numpy as np
+        torch, R, sim = self.torch, self.R, self.sim
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        for i in range(n):
+            ev[i][0].record()
+            sim.step(self.slots, self.ring[i % R])
+            ev[i][1].record()
+            for cam in self.cameras:
+                sim.render(cam.camera_index, *cam._buffers)
+            ev[i][2].record()
+            if self.auto_reset:
+                sim.reset(sim.term_flag)
+        torch.cuda.synchronize()
+        self.step_launches += n
+        eager = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        render = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        replayed = None
+        if self.graph_kernel is not None:
+            reps = max(1, n // R)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(reps):
+                self.graph_kernel.replay()
+            g1.record()
+            torch.cuda.synchronize()
+            self.step_launches += reps * R
+            replayed = g0.elapsed_time(g1) / (reps * R)
+            if self.auto_reset:
+                sim.reset(sim.term_flag)
+        return (replayed if replayed is not None else eager), render, eager
+
+    def solver_stats(self, n=16):
+        """live Gauss-Seidel / IK statistics from the kernel's diagnostics buffer (a separate, untimed segment: the
+        production launches carry no diagnostics)"""
+        torch, sim, env, B = self.torch, self.sim, self.env, self.B
+        d = sim.enable_diagnostics()
+        acc = []
+        for i in range(n):
+            self.one_step(i)
+            acc.append(d.clone())
+        torch.cuda.synchronize()
+        sim.disable_diagnostics()
+        self.step_launches += n
+        D = torch.stack(acc)  # [n, B, 8]
+        n_ik = sum(1 for r in env.receptors.values() for a in r.addons.values() if type(a).__name__ == 'InverseKinematicsController')
+        per_wave = D[:, :, sim.DIAG_PGS_ITERS].reshape(n, -1, min(sim.envs_per_wave, B)).max(2).values if B % sim.envs_per_wave == 0 else None
+        return {'iteration_cap': int(env.builder.solver_iterations), 'substeps': env.layout.substeps,
+                'pgs_iterations_last_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS]),
+                'pgs_iterations_first_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS_FIRST]),
+                'pgs_iterations_wavefront_max': quantiles(per_wave) if per_wave is not None else None,
+                'contacts_per_env': quantiles(D[:, :, sim.DIAG_CONTACTS]),
+                'envs_with_contacts_frac': float((D[:, :, sim.DIAG_CONTACTS] > 0).float().mean()),
+                'ik_iteration_cap': int(env.builder.params['ik_iterations']) if n_ik else None,
+                'ik_iterations': quantiles(D[:, :, sim.DIAG_IK_ITERS:sim.DIAG_IK_ITERS + min(n_ik, sim.DIAG_N_IK)]) if n_ik else None,
+                'sample': '%d steps after the timed region, every env' % n}
+
+    def bytes_per_env_step(self):
+        return self.image_bytes if self.kernel_name == 'render_kernel' else algorithmic_bytes_per_env_step(self.env.layout)
+
+    def close(self):
+        self.graph = self.graph_rest = self.graph_kernel = None
+        self.env.close()
+
+
+def make_leg(name, device, rank=0, envs=None, auto_reset=True):
+    wl, n, engine, frac, _ = LEGS[name]
+    return Leg(name, wl, device, rank, envs or n, engine, frac, auto_reset)
+
+
+def leg_names(args):
+    if args.legs == 'none' or args.gpus > 1 or args.workload != 'ur_high_5' or args.envs_per_gpu not in (None, 16384):
+        return []   # the extra legs belong to the default headline run on one GPU
+    return list(LEGS) if args.legs == 'all' else [n for n in args.legs.split(',') if n in LEGS]
+
+
+# ----------------------------------------------------------------------------------------------- profiled child
+INNER_WARM, INNER_STEPS = 24, 40
+
+
+def inner_run(args):
+    """The command rocprofv3 profiles (``bench.py ... --inner --manifest PATH``): the eager loop of the main workload and of
+    every extra leg, one after the other in ONE process, nothing else.  The manifest lists the legs in launch order with
+    the number of step / render launches each made, so that the parent can cut the trace (or the counter rows) of this
+    process into legs by dispatch order -- the last INNER_STEPS launches of each leg are its sample."""
+    import torch
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    manifest = []
+    names = ['main'] + leg_names(args)
+    for name in names:
+        leg = Leg('main', args.workload, device, 0, args.envs_per_gpu, None, 0.0, not args.no_auto_reset) if name == 'main' else make_leg(name, device, auto_reset=not args.no_auto_reset)
+        leg.eager(INNER_WARM)
+        torch.cuda.synchronize()
+        leg.eager(INNER_STEPS, INNER_WARM)
+        torch.cuda.synchronize()
+        manifest.append({'leg': name, 'step_launches': leg.step_launches, 'render_launches': leg.step_launches * len(leg.cameras) + len(leg.cameras), 'sample': INNER_STEPS,
+                         'kernel': leg.kernel_name})
+        leg.close()
+        del leg
+    if args.manifest:
+        json.dump(manifest, open(args.manifest, 'w'))
+
+
 def profile_children(args, argv):
-    """N = 1, default on (``--no-pmc`` opts out): per-launch figures of the dominant kernel measured NOW by running this very
-    command (fewer steps, timed loop only) under rocprofv3 in fresh child processes -- started before this process touches
-    the GPU, ``python bench.py ...`` directly after ``--`` -- one pass each: a kernel trace (average duration), then the
-    HBM counters and the SQ counters in their own passes (never a trace and counters together).  Corrections per
+    """N = 1, default on (``--no-pmc`` opts out): per-launch figures of every leg's dominant kernel measured NOW by running
+    this very command's eager loops (inner_run) under rocprofv3 in fresh child processes -- started before this process
+    touches the GPU, ``python bench.py ...`` directly after ``--`` -- one pass each: a kernel trace (durations), then the HBM
+    counters and the SQ counters in their own passes (never a trace and counters together).  Corrections per
     MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950's FETCH_SIZE counts half of a coalesced read.
-    Bounded: a pass that fails or runs out of time leaves its fields null."""
+    The rows of a pass are cut into legs by dispatch order with the child's manifest.  Bounded: a pass that fails or runs
+    out of time leaves its fields null."""
     import csv
     import glob
     import shutil
@@ -231,46 +518,130 @@ def profile_children(args, argv):
     out, t_begin = {}, time.time()
     skip = ('--pmc', '--no-pmc')
     base = [a for a in argv if a not in skip]
-    inner = ['--steps', '40', '--warmup', '10', '--inner']
     env = dict(os.environ, TMPDIR=os.environ.get('TMPDIR', '/tmp'))
-    passes = [('trace', ['--kernel-trace', '--stats']), ('fetch', ['--pmc', 'FETCH_SIZE']), ('write', ['--pmc', 'WRITE_SIZE']),
+    passes = [('trace', ['--kernel-trace']), ('fetch', ['--pmc', 'FETCH_SIZE']), ('write', ['--pmc', 'WRITE_SIZE']),
               ('sq', ['--pmc', 'SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM'])]
-    for name, flags in passes:
+
+    def is_step(n):
+        return 'step_kernel' in n and 'reset' not in n
+
+    for pname, flags in passes:
         left = args.pmc_budget - (time.time() - t_begin)
-        if left < 20:
-            print('bench.py: profiling budget (%d s) spent before the %s pass; its fields stay null' % (args.pmc_budget, name), file=sys.stderr)
+        if left < 30:
+            print('bench.py: profiling budget (%d s) spent before the %s pass; its fields stay null' % (args.pmc_budget, pname), file=sys.stderr)
             break
         d = tempfile.mkdtemp(prefix='dg_prof_', dir=env['TMPDIR'])
-        cmd = ['rocprofv3'] + flags + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + inner
+        man = os.path.join(d, 'manifest.json')
+        cmd = ['rocprofv3'] + flags + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + base + ['--inner', '--manifest', man]
         try:
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left, check=True, cwd=env['TMPDIR'], env=env)
+            manifest = json.load(open(man))
         except Exception as exc:
-            print('bench.py: rocprofv3 %s pass failed (%s); its fields stay null' % (name, type(exc).__name__), file=sys.stderr)
+            print('bench.py: rocprofv3 %s pass failed (%s); its fields stay null' % (pname, type(exc).__name__), file=sys.stderr)
             shutil.rmtree(d, ignore_errors=True)
             continue
-        if name == 'trace':
-            for f in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+        # dispatches in launch order: (kernel name, value dict)
+        rows = []
+        if pname == 'trace':
+            for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if args.kernel_filter in r['Name'] and 'reset' not in r['Name']:
-                        out['trace'] = {'kernel': r['Name'].split('(')[0].replace('void ', ''), 'calls': int(r['Calls']), 'average_ns': float(r['AverageNs']),
-                                        'min_ns': float(r['MinNs']), 'max_ns': float(r['MaxNs'])}
-                        break
+                    rows.append((int(r['Start_Timestamp']), r['Kernel_Name'], {'ns': float(int(r['End_Timestamp']) - int(r['Start_Timestamp']))}))
         else:
-            agg = {}
+            per = {}
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if args.kernel_filter in r['Kernel_Name'] and 'reset' not in r['Kernel_Name']:
-                        agg.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-            for k, v in agg.items():
-                out[k] = sum(v) / len(v)
+                    k = int(r['Dispatch_Id'])
+                    per.setdefault(k, [r['Kernel_Name'], {}])[1][r['Counter_Name']] = per.get(k, [None, {}])[1].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+            rows = [(k, v[0], v[1]) for k, v in per.items()]
+        rows.sort(key=lambda t: t[0])
+        steps = [(n, v) for _, n, v in rows if is_step(n)]
+        renders = [(n, v) for _, n, v in rows if 'render_kernel' in n]
+        so = ro = 0
+        for m in manifest:
+            mine_s, mine_r = steps[so:so + m['step_launches']], renders[ro:ro + m['render_launches']]
+            so += m['step_launches']; ro += m['render_launches']
+            sample = (mine_r if m['kernel'] == 'render_kernel' else mine_s)[-m['sample']:]
+            if len(sample) < m['sample']:
+                continue  # (the trace does not hold what the manifest says: leave the leg's fields null)
+            rec = out.setdefault(m['leg'], {})
+            rec['kernel'] = sample[-1][0].split('(')[0].replace('void ', '')
+            if pname == 'trace':
+                v = [s_[1]['ns'] for s_ in sample]
+                rec['trace'] = {'calls': len(v), 'average_ns': sum(v) / len(v), 'min_ns': min(v), 'max_ns': max(v)}
+                if m['kernel'] == 'render_kernel' and len(mine_s) >= m['sample']:
+                    w = [s_[1]['ns'] for s_ in mine_s[-m['sample']:]]
+                    rec['step_trace'] = {'kernel': mine_s[-1][0].split('(')[0].replace('void ', ''), 'calls': len(w), 'average_ns': sum(w) / len(w)}
+            else:
+                for cname in sample[0][1]:
+                    rec[cname] = sum(s_[1].get(cname, 0.0) for s_ in sample) / len(sample)
+        if so != len(steps):
+            print('bench.py: the %s pass holds %d step launches, the manifest %d' % (pname, len(steps), so), file=sys.stderr)
         shutil.rmtree(d, ignore_errors=True)
     out['seconds'] = round(time.time() - t_begin, 1)
     return out
 
 
+def roofline_of(leg, kms_events, step_ms, render_ms, step_eager_ms, prof):
+    """The `roofline` object of one leg: its dominant kernel's average launch duration (from the rocprofv3 kernel trace of the
+    child run when there is one -- it cannot include launch gaps -- else from the HIP events), algorithmic bytes per launch over
+    that, and the counters of the child passes."""
+    B, kname, kbytes = leg.B, leg.kernel_name, leg.bytes_per_env_step()
+    kms, ksource = kms_events, 'HIP events around %s' % ('graph replays of back-to-back launches' if (leg.graph_kernel is not None and kname != 'render_kernel') else 'eager launches')
+    trace = prof.get('trace') if prof else None
+    if trace:
+        kms, ksource = trace['average_ns'] * 1e-6, 'rocprofv3 --kernel-trace of a child run of this command (%d launches)' % trace['calls']
+    achieved = kbytes * B / (kms * 1e-3) / 1e9
+    traffic = valu_frac = wait_frac = issue = None
+    if prof:
+        if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof:
+            traffic = (2.0 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0
+        if 'SQ_INSTS_VALU' in prof:  # one VALU wave-instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
+            valu_frac = prof['SQ_INSTS_VALU'] * 2.0 / (SIMDS * kms * 1e-3 * CLOCK_HZ)
+        if prof.get('SQ_WAVE_CYCLES'):
+            wait_frac = prof.get('SQ_WAIT_ANY', 0.0) / prof['SQ_WAVE_CYCLES']
+        if prof.get('SQ_WAVES') and 'SQ_INSTS_VALU' in prof:
+            # the bound that applies to these kernels: one wavefront per SIMD issues one instruction per ~4.5 cycles
+            # whatever its ILP (tools/micro/valu_issue*.hip, profiles/r2_micro_valu_issue_*.txt); the kernel's time is
+            # its longest wavefront's instruction stream at that rate.  Mean over ALL wavefronts of the launch here
+            # (helper wavefronts that wait at barriers included), so 1.0 would mean every wavefront issues flat out.
+            insts = sum(prof.get(k, 0.0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM')) / prof['SQ_WAVES']
+            cycles = kms * 1e-3 * CLOCK_HZ
+            issue = {'bound': 'lone-wavefront instruction issue', 'instructions_per_wavefront_mean': insts, 'kernel_cycles': cycles,
+                     'cycles_per_instruction_mean': cycles / insts if insts else None, 'lone_wavefront_limit_cycles_per_instruction': 4.5,
+                     'frac': 4.5 * insts / cycles if cycles else None, 'wavefronts': prof['SQ_WAVES']}
+    r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+         'kernel': (prof or {}).get('kernel', kname), 'kernel_ms': kms, 'kernel_ms_source': ksource, 'kernel_ms_hip_events': kms_events, 'bytes_per_env_step': kbytes,
+         'step_kernel_ms': step_ms, 'step_kernel_ms_event_bracketed_eager_launch': step_eager_ms, 'render_kernel_ms': render_ms if leg.cameras else None,
+         'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac, 'issue': issue}
+    if prof and prof.get('step_trace'):
+        r['step_kernel_trace'] = prof['step_trace']
+    return r
+
+
+def measure_leg(name, device, args, prof):
+    """One extra leg, start to finish: world, warm-up, graphs (first replay untimed), timed replay, kernel events, solver."""
+    import torch
+    steps = LEGS[name][4]
+    leg = make_leg(name, device, auto_reset=not args.no_auto_reset)
+    warm = 48
+    leg.eager(warm)
+    torch.cuda.synchronize()
+    untimed = warm + leg.capture(steps)
+    el = leg.timed(steps)
+    step_ms, render_ms, step_eager_ms = leg.kernel_times(32)
+    out = {'workload': '%s x %d envs' % (leg.workload, leg.B), 'what': leg.desc, 'engine': leg.engine, 'steps': steps, 'untimed_steps_before': untimed,
+           'ms_per_step': el / steps * 1e3, 'value': leg.B * steps / el, 'unit': 'env-steps/s',
+           'envs_per_wavefront': leg.sim.lanes, 'lds_bytes_per_workgroup': leg.sim.lds_bytes,
+           'roofline': roofline_of(leg, render_ms if leg.kernel_name == 'render_kernel' else step_ms, step_ms, render_ms, step_eager_ms, prof),
+           'solver': leg.solver_stats()}
+    if leg.crossed_frac > 0:
+        out['started_in_the_crossed_forearms_pose'] = {'envs': leg.crossed_envs, 'of': leg.B}
+    leg.close()
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def run_rank(args, argv):
-    import numpy as np
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -278,8 +649,7 @@ def run_rank(args, argv):
     distributed = world > 1
 
     pmc = None
-    if not args.no_pmc and not distributed and not args.inner:
-        args.kernel_filter = 'render_kernel' if args.workload == 'from_the_readme' else 'step_kernel'
+    if not args.no_pmc and not distributed:
         pmc = profile_children(args, argv)  # child processes; this process has not touched the GPU yet
 
     torch.cuda.set_device(local_rank)
@@ -288,75 +658,19 @@ def run_rank(args, argv):
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=device)
 
-    import diy_gym_amd.examples  # noqa: F401
     from diy_gym_amd import DIYGym
     from diy_gym_amd.config import Configuration
-    cfg_rel, cfg_desc = WORKLOADS[args.workload]
-    cfg = os.path.join(ROOT, cfg_rel)
-    B = args.envs_per_gpu or DEFAULT_ENVS.get(args.workload, 16384)
-    env = DIYGym(cfg, num_envs=B, device=device, seed=1234, env_index_base=rank * B)
-    lo, hi = action_bounds(env)
-    gen = torch.Generator().manual_seed(1234 + rank)
-    ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to(device) for _ in range(8)]
-    sim, slots = env.sim, env._all_slots
     auto_reset = not args.no_auto_reset
-    cameras = [a for r in env.receptors.values() for a in r.addons.values() if hasattr(a, 'camera_index')]
-    image_bytes = 0
-    for cam in cameras:  # allocate the image buffers once; the timed step renders into them
-        cam.observe()
-        image_bytes += sum(t.numel() * t.element_size() for t in cam._buffers if t is not None) // B
+    main = Leg('main', args.workload, device, rank, args.envs_per_gpu, None, 0.0, auto_reset)
+    env, sim, B, R, ring, cfg = main.env, main.sim, main.B, main.R, main.ring, main.cfg
 
-    def one_step(i):
-        sim.step(slots, ring[i % len(ring)])
-        for cam in cameras:
-            sim.render(cam.camera_index, *cam._buffers)
-        if auto_reset:
-            sim.reset(sim.term_flag)
-
-    # Warm-up: --warmup untimed steps in all.  The last ones are the FIRST replay of each graph the timed region uses (below):
-    # the first launch of a freshly instantiated hipGraph can pay a one-off upload of tens of milliseconds, which in a timed
-    # region of ~30 ms in all showed up once as 0.26 ms per step instead of 0.108 (profiles/, round 3).
-    R = len(ring)
-    n_graph_warm = 0 if args.eager else R + (args.steps % R)
-    if args.warmup < n_graph_warm:
-        n_graph_warm = 0  # (too few warm-up steps asked for to spend them on the graphs: the first replay is timed)
-    for i in range(args.warmup - n_graph_warm):
-        one_step(i)
+    # Warm-up: --warmup untimed eager steps, then -- ALWAYS, whatever --warmup says -- one untimed replay of every graph the
+    # timed region uses (Leg.capture); the number of untimed steps actually run is reported.
+    main.eager(args.warmup)
     torch.cuda.synchronize()
-    # The timed region replays hipGraphs of consecutive steps (step [+ render] + masked auto-reset each): the work is
-    # identical to the eager loop, but a busy host cannot stretch the gaps between the ~0.1 ms kernels.  EXACTLY --steps
-    # steps, all of them replayed: whole segments of len(ring) steps plus one shorter segment for the remainder.
-    def capture(n_steps, body):
-        cap = torch.cuda.Stream(device=device)
-        cap.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(cap):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
-                for i in range(n_steps):
-                    body(i)
-        torch.cuda.current_stream(device).wait_stream(cap)
-        torch.cuda.synchronize()
-        return g
-
-    graph = graph_rest = graph_kernel = None
+    untimed = args.warmup
     if not args.eager:
-        try:
-            graph = capture(R, one_step)
-            if args.steps % R:
-                graph_rest = capture(args.steps % R, one_step)
-            graph_kernel = capture(R, lambda i: sim.step(slots, ring[i % R]))  # the step kernel alone, for kernel_times()
-        except Exception as exc:  # pragma: no cover
-            print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
-            graph = graph_rest = graph_kernel = None
-    if graph is not None and n_graph_warm:  # the remaining warm-up steps, as the graphs' first replays
-        graph.replay()
-        if graph_rest is not None:
-            graph_rest.replay()
-        torch.cuda.synchronize()
-    elif graph is None:
-        for i in range(n_graph_warm):
-            one_step(i)
-        torch.cuda.synchronize()
+        untimed += main.capture(args.steps)
 
     def timed(steps):
         torch.cuda.synchronize()
@@ -364,14 +678,7 @@ def run_rank(args, argv):
             dist.barrier()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if graph is not None:
-            for _ in range(steps // R):
-                graph.replay()
-            if steps % R:
-                graph_rest.replay()
-        else:
-            for i in range(steps):
-                one_step(i)
+        main.run(steps)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -385,74 +692,17 @@ def run_rank(args, argv):
 
     elapsed = timed(args.steps)
     episodes_main = float(sim.state[1, :B].sum().item()) - B  # DG_ST_EPISODE summed over envs
-
-    def kernel_times(n):
-        """Average duration of the dominant kernel(s) by HIP events on the launch stream (torch's current stream IS the
-        stream the C-ABI launches on), same inputs, right after the timed region.  The step kernel: events around
-        replays of a graph of len(ring) back-to-back step launches (no host launch gaps inside); eager launches
-        bracketed one by one -- launch overhead included -- are reported next to it.  The render kernel: eager."""
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
-        for i in range(n):
-            ev[i][0].record()
-            sim.step(slots, ring[i % R])
-            ev[i][1].record()
-            for cam in cameras:
-                sim.render(cam.camera_index, *cam._buffers)
-            ev[i][2].record()
-            if auto_reset:
-                sim.reset(sim.term_flag)
-        torch.cuda.synchronize()
-        eager = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        render = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-        replayed = None
-        if graph_kernel is not None:
-            reps = max(1, n // R)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            for _ in range(reps):
-                graph_kernel.replay()
-            g1.record()
-            torch.cuda.synchronize()
-            replayed = g0.elapsed_time(g1) / (reps * R)
-            if auto_reset:
-                sim.reset(sim.term_flag)
-        return (replayed if replayed is not None else eager), render, eager
-
-    step_ms, render_ms, step_eager_ms = kernel_times(max(R, min(64, args.steps)))
-
-    # live solver statistics from the kernel's diagnostics buffer (a separate, untimed segment: the production
-    # launches above carry no diagnostics)
-    def solver_stats():
-        d = sim.enable_diagnostics()
-        acc = []
-        for i in range(16):
-            one_step(i)
-            acc.append(d.clone())
-        torch.cuda.synchronize()
-        sim.disable_diagnostics()
-        D = torch.stack(acc)  # [16, B, 8]
-        n_ik = sum(1 for r in env.receptors.values() for a in r.addons.values() if type(a).__name__ == 'InverseKinematicsController')
-        per_wave = D[:, :, sim.DIAG_PGS_ITERS].reshape(16, -1, min(sim.envs_per_wave, B)).max(2).values if B % sim.envs_per_wave == 0 else None
-        return {'iteration_cap': int(env.builder.solver_iterations), 'substeps': env.layout.substeps,
-                'pgs_iterations_last_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS]),
-                'pgs_iterations_first_substep': quantiles(D[:, :, sim.DIAG_PGS_ITERS_FIRST]),
-                'pgs_iterations_wavefront_max': quantiles(per_wave) if per_wave is not None else None,
-                'contacts_per_env': quantiles(D[:, :, sim.DIAG_CONTACTS]),
-                'envs_with_contacts_frac': float((D[:, :, sim.DIAG_CONTACTS] > 0).float().mean()),
-                'ik_iteration_cap': int(env.builder.params['ik_iterations']) if n_ik else None,
-                'ik_iterations': quantiles(D[:, :, sim.DIAG_IK_ITERS:sim.DIAG_IK_ITERS + min(n_ik, sim.DIAG_N_IK)]) if n_ik else None,
-                'sample': '16 steps after the timed region, every env'}
-
-    solver = solver_stats() if rank == 0 and not args.inner else None
+    step_ms, render_ms, step_eager_ms = main.kernel_times(max(R, min(64, args.steps)))
+    solver = main.solver_stats() if rank == 0 else None
 
     # (measured BEFORE the aged segment, so that the rates are those of the API on the same young rollout as `value`)
     # eager public-API rates: env.step() with the reference's dict actions, and with flatten_actions /
     # flatten_observations + collapsed reward / terminal (the trainer-facing fast path); auto-reset as above
     api = None
-    if rank == 0 and not args.inner and not args.no_api:
+    if rank == 0 and not args.no_api:
         from diy_gym_amd.utils import unflatten
         n_api = 100
-        dict_ring = [unflatten(r, env.action_space, batch_dims=1) for r in ring] if lo.numel() else [{} for _ in ring]
+        dict_ring = [unflatten(r, env.action_space, batch_dims=1) for r in ring] if main.lo.numel() else [{} for _ in ring]
         for i in range(5):
             env.step(dict_ring[i % R])
         torch.cuda.synchronize()
@@ -488,80 +738,61 @@ def run_rank(args, argv):
 
     # aged segment: the same loop after --age-steps more (untimed) steps of the same random-action rollout
     aged = None
-    if args.age_steps > 0 and not args.inner:
-        for i in range(args.age_steps // R if graph is not None else 0):
-            graph.replay()
-        for i in range((args.age_steps // R) * R if graph is not None else 0, args.age_steps):
-            one_step(i)
+    if args.age_steps > 0:
+        main.run((args.age_steps // R) * R)
+        main.eager(args.age_steps % R)
         el = timed(args.steps)
-        a_step_ms, a_render_ms, _ = kernel_times(max(R, min(32, args.steps)))
-        aged = {'after_steps': args.warmup + args.steps + 80 + args.age_steps + (105 if api else 0), 'ms_per_step_aged': el / args.steps * 1e3,
+        a_step_ms, a_render_ms, _ = main.kernel_times(max(R, min(32, args.steps)))
+        aged = {'after_steps': untimed + args.steps + 80 + args.age_steps + (105 if api else 0), 'ms_per_step_aged': el / args.steps * 1e3,
+                'ms_per_step_aged_over_young': (el / args.steps) / (elapsed / args.steps),
                 'value_aged': B * world * args.steps / el, 'kernel_ms_aged': a_step_ms,
                 'episodes_finished_rank0': float(sim.state[1, :B].sum().item()) - B,
-                'solver': solver_stats() if rank == 0 else None}
+                'solver': main.solver_stats() if rank == 0 else None}
 
     if rank == 0:
         total_envs = B * world
         value = total_envs * args.steps / elapsed
-        render_bound = bool(cameras) and render_ms > step_ms * 0.2
-        state_bytes = algorithmic_bytes_per_env_step(env.layout)
-        # the dominant kernel for the roofline: the step kernel, except for camera workloads whose image writes are
-        # the HBM-bound part of the step -- there the render kernel is quoted
-        if args.workload == 'from_the_readme':
-            kname, kms, kbytes = 'render_kernel', render_ms, image_bytes
-        else:
-            kname, kms, kbytes = ('step_kernel_par' if getattr(sim, 'par', False) else 'step_kernel'), step_ms, state_bytes
-        # kernel_ms: this kernel's average launch duration -- from the rocprofv3 kernel trace of a child run of this very
-        # command when there is one (it cannot include launch gaps), else from the HIP events above
-        kms_events, ksource = kms, 'HIP events around %s' % ('graph replays of back-to-back launches' if (graph_kernel is not None and kname != 'render_kernel') else 'eager launches')
-        trace = pmc.get('trace') if pmc else None
-        if trace:
-            kms, ksource = trace['average_ns'] * 1e-6, 'rocprofv3 --kernel-trace --stats of a child run of this command (%d launches)' % trace['calls']
-        achieved = kbytes * B / (kms * 1e-3) / 1e9
-        traffic = valu_frac = wait_frac = issue = None
-        if pmc:
-            if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
-                traffic = (2.0 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024.0
-            if 'SQ_INSTS_VALU' in pmc:  # one VALU wave-instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
-                valu_frac = pmc['SQ_INSTS_VALU'] * 2.0 / (SIMDS * kms * 1e-3 * CLOCK_HZ)
-            if pmc.get('SQ_WAVE_CYCLES'):
-                wait_frac = pmc.get('SQ_WAIT_ANY', 0.0) / pmc['SQ_WAVE_CYCLES']
-            if pmc.get('SQ_WAVES') and 'SQ_INSTS_VALU' in pmc:
-                # the bound that applies to these kernels: one wavefront per SIMD issues one instruction per ~4.5 cycles
-                # whatever its ILP (tools/micro/valu_issue*.hip, profiles/r2_micro_valu_issue_*.txt); the kernel's time is
-                # its longest wavefront's instruction stream at that rate.  Mean over ALL wavefronts of the launch here
-                # (helper wavefronts that wait at barriers included), so 1.0 would mean every wavefront issues flat out.
-                insts = sum(pmc.get(k, 0.0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM')) / pmc['SQ_WAVES']
-                cycles = kms * 1e-3 * CLOCK_HZ
-                issue = {'bound': 'lone-wavefront instruction issue', 'instructions_per_wavefront_mean': insts, 'kernel_cycles': cycles,
-                         'cycles_per_instruction_mean': cycles / insts if insts else None, 'lone_wavefront_limit_cycles_per_instruction': 4.5,
-                         'frac': 4.5 * insts / cycles if cycles else None, 'wavefronts': pmc['SQ_WAVES']}
+        kms_events = render_ms if main.kernel_name == 'render_kernel' else step_ms
+        roof = roofline_of(main, kms_events, step_ms, render_ms, step_eager_ms, pmc.get('main') if pmc else None)
+        roof['survey_bytes_per_env_step'] = 449 if args.workload.startswith('ur_high_5') else None
+        roof['limiter'] = ('NOT HBM either: VALU issue of the culling and intersection tests around 655 MB of image writes per launch (DESIGN.md 6)' if args.workload == 'from_the_readme' else
+                           'NOT HBM: instruction issue and latency of one wavefront per SIMD; the hbm fraction is reported because the contract asks for it')
+        roof['pmc_source'] = ('rocprofv3 child runs of this command, this invocation (%.0f s)' % pmc['seconds']) if pmc else None
+        if main.cameras and render_ms > step_ms * 0.2 and args.workload != 'from_the_readme':
+            roof['note'] = 'camera render takes %.2f ms of the step' % render_ms
         out = {
             'metric': 'env steps/sec (whole node)', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s x %d envs per GPU' % (args.workload, B), 'what': cfg_desc, 'envs_total': total_envs,
+            'config': {'workload': '%s x %d envs per GPU' % (args.workload, B), 'what': main.desc, 'envs_total': total_envs,
                        'timestep': 1.0 / 240.0, 'substeps': env.layout.substeps, 'solver_iteration_cap': int(env.builder.solver_iterations),
-                       'auto_reset': auto_reset, 'timed_path': 'backend entry points dg_world_step%s + dg_world_reset(term_flag); env.step() rates are in api_eager' % (' + dg_world_render' if cameras else ''),
-                       'launch': 'hipGraph replay of %d-step segments' % R if graph is not None else 'eager',
+                       'solver_start': {k: env.builder.params[k] for k in ('motor_guess', 'limit_guess', 'warmstart', 'warmstart_friction')},
+                       'auto_reset': auto_reset, 'timed_path': 'backend entry points dg_world_step%s + dg_world_reset(term_flag); env.step() rates are in api_eager' % (' + dg_world_render' if main.cameras else ''),
+                       'launch': 'hipGraph replay of %d-step segments' % R if main.graph is not None else 'eager',
+                       'untimed_steps_before_the_timed_region': untimed,
                        'episodes_finished_rank0': episodes_main, 'parallelism': 'independent env shards x%d, no collective' % world,
                        'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes,
                        'parity': 'vs the C oracle only; parity with pybullet itself is UNPINNED (DESIGN.md 4)'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': kname, 'kernel_ms': kms, 'kernel_ms_source': ksource, 'kernel_ms_hip_events': kms_events,
-                         'bytes_per_env_step': kbytes,
-                         'step_kernel_ms': step_ms, 'step_kernel_ms_event_bracketed_eager_launch': step_eager_ms, 'render_kernel_ms': render_ms if cameras else None,
-                         'survey_bytes_per_env_step': 449 if args.workload.startswith('ur_high_5') else None,
-                         'limiter': ('NOT HBM either: VALU issue of the culling and intersection tests around 655 MB of image writes per launch (DESIGN.md 6)' if args.workload == 'from_the_readme' else
-                                     'NOT HBM: instruction issue and latency of one wavefront per SIMD; the hbm fraction is reported because the contract asks for it'),
-                         'valu_issue_frac_2cyc': valu_frac, 'wave_wait_frac': wait_frac, 'issue': issue,
-                         'pmc_source': ('rocprofv3 child runs of this command, this invocation (%.0f s)' % pmc['seconds']) if pmc else None},
-            'solver': solver, 'aged': aged, 'api_eager': api,
+            'roofline': roof, 'solver': solver, 'aged': aged, 'api_eager': api,
         }
-        if render_bound and args.workload != 'from_the_readme':
-            out['roofline']['note'] = 'camera render takes %.2f ms of the step' % render_ms
-        if world == 1 and not args.no_cpu_baseline and not args.inner:
-            out['cpu_baseline'] = cpu_baseline(cfg, lo.numel(), lo, hi)
+        main.close()
+        # the other tail of the headline scene, the reference's solver settings, the other BASELINE configs (N = 1 default run)
+        t_legs = time.time()
+        for name in leg_names(args):
+            try:
+                rec = measure_leg(name, device, args, pmc.get(name) if pmc else None)
+            except Exception as exc:  # pragma: no cover
+                rec = {'error': repr(exc)}
+            if name in CONFIG_LEGS:
+                out.setdefault('configs', {})[name] = rec
+            else:
+                out[name] = rec
+                if 'ms_per_step' in rec:
+                    rec['ms_per_step_over_young'] = rec['ms_per_step'] / out['ms_per_step']
+        if leg_names(args):
+            out['legs_seconds'] = round(time.time() - t_legs, 1)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, main.lo.numel(), main.lo, main.hi)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
@@ -582,8 +813,10 @@ def main():
     ap.add_argument('--eager', action='store_true', help='time the eager launch loop instead of a replayed hipGraph')
     ap.add_argument('--pmc', action='store_true', help='(default at N=1; kept for old command lines)')
     ap.add_argument('--no-pmc', action='store_true', help='N=1: skip the rocprofv3 child runs (kernel trace + HBM / SQ counter passes) that fill roofline.traffic / kernel_ms')
-    ap.add_argument('--pmc-budget', type=int, default=360, help='seconds the rocprofv3 child runs may take in total')
-    ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)  # the profiled child of --pmc: timed loop only
+    ap.add_argument('--pmc-budget', type=int, default=420, help='seconds the rocprofv3 child runs may take in total')
+    ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)  # the profiled child: eager loops of every leg, nothing else
+    ap.add_argument('--manifest', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--legs', default='all', help="extra legs of the default N=1 ur_high_5 run: 'all', 'none' or a comma-separated subset of " + ','.join(LEGS))
     ap.add_argument('--master-port', type=int, default=0)
     ap.add_argument('--selftest-launcher', action='store_true', help='CPU-only rendezvous test of the N-rank launcher (gloo)')
     args = ap.parse_args()
@@ -600,6 +833,8 @@ def main():
         if world_env is None:
             os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
         return selftest_rank(args)
+    if args.inner:
+        return inner_run(args)
     run_rank(args, argv)
 
 

@@ -574,14 +574,15 @@ DGD void chol_unit_solve(OFF off, const float* rhs, float* x) {
 // velocity it is held at its bound like any row that leaves its bounds.  dv += M x (total impulse per joint).  Same steps as
 // the CPU checker (its comment "Starting impulses of the motor rows").
 template <int N>
-DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv, bool pinning, const float* lb0, float* la0, const float* lb1, float* la1) {
+DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, float* acc, float* dv, float ptol, const float* lb0, float* la0, const float* lb1, float* la1) {
+  const bool pinning = ptol >= 0.f;  // ptol: how far beyond the limit row's velocity the motor target must lie (the sweeps' own early-out, limit_ptol()); < 0: off
   // (the system is scaled symmetrically to a unit diagonal first: wrist and shoulder joints differ by orders of magnitude
   // in M^-1 and this is an fp32 factorisation; a pivot is floored at 1e-6 of its diagonal)
   float rhs[N], x[N], sd[N], pin[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     sd[i] = smax[i] > 0.f ? __frsqrt_rn(fmaxf(M[i * N + i], 1e-30f)) : 0.f;
-    const bool plo = pinning && smax[i] > 0.f && la0[i] >= 0.f && b[i] < lb0[i], phi = pinning && smax[i] > 0.f && la1[i] >= 0.f && b[i] > -lb1[i];
+    const bool plo = pinning && smax[i] > 0.f && la0[i] >= 0.f && b[i] < lb0[i] - ptol, phi = pinning && smax[i] > 0.f && la1[i] >= 0.f && b[i] > -lb1[i] + ptol;
     pin[i] = plo ? -1.f : (phi ? 1.f : 0.f);
     rhs[i] = (plo ? lb0[i] : (phi ? -lb1[i] : b[i])) * sd[i];
   }
@@ -621,7 +622,9 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
 #pragma unroll
     for (int c = 0; c < N; c++) dv[c] += M[i * N + c] * tot[i];
 }
-DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv, bool pinning, const float* lb0, float* la0, const float* lb1, float* la1) { chain_motor_guess_n<6>(M, b, smax, acc, dv, pinning, lb0, la0, lb1, la1); }
+DGD void chain_motor_guess(const float* M, const float* b, const float* smax, float* acc, float* dv, float ptol, const float* lb0, float* la0, const float* lb1, float* la1) { chain_motor_guess_n<6>(M, b, smax, acc, dv, ptol, lb0, la0, lb1, la1); }
+// DG_HF_LIMIT_GUESS as the tolerance chain_motor_guess_n takes: the sweeps' early-out on a row's velocity residual, or -1 (off)
+DGD float limit_ptol(const DevScene& sc) { return sc.HF[DG_HF_LIMIT_GUESS] > 0.f ? sqrtf(sc.HF[DG_HF_RESIDUAL_THRESHOLD]) : -1.f; }
 // LDS form for a body with at most N joints (fixed or floating base): reads the joint block of M^-1 and the rows'
 // right-hand sides into registers, writes the starting impulses into the rows' MR_ACC slots (every sweep form picks them
 // up there and adds the velocity change they amount to before its first iteration).
@@ -631,7 +634,7 @@ DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
   const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
   const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
   float M[N * N], bb[N], smax[N], acc[N], dv[N], lb0[N], la0[N], lb1[N], la1[N];
-  const bool pinning = sc.HF[DG_HF_LIMIT_GUESS] > 0.f;
+  const float ptol = limit_ptol(sc); const bool pinning = ptol >= 0.f;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const bool has = i < n; const int ic = has ? i : 0;
@@ -642,7 +645,7 @@ DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
 #pragma unroll
     for (int c = 0; c < N; c++) { const float m = ln.L(mvo + (k0 + ic) * nv + k0 + (c < n ? c : 0)); M[i * N + c] = (has && c < n) ? m : 0.f; }
   }
-  chain_motor_guess_n<N>(M, bb, smax, acc, dv, pinning, lb0, la0, lb1, la1);
+  chain_motor_guess_n<N>(M, bb, smax, acc, dv, ptol, lb0, la0, lb1, la1);
 #pragma unroll
   for (int i = 0; i < N; i++) if (i < n) {
     ln.L(mo0 + i * MR_STRIDE + MR_ACC) = acc[i];
@@ -1777,7 +1780,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
 #pragma unroll
     for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
   }
-  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv, sc.HF[DG_HF_LIMIT_GUESS] > 0.f, lb[0], la[0], lb[1], la[1]);  // the sweeps start next to their fixed point (limit rows of pinned joints included)
+  if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv, limit_ptol(sc), lb[0], la[0], lb[1], la[1]);  // the sweeps start next to their fixed point (limit rows of pinned joints included)
   // limit rows some lane of the wavefront has active (the flags cannot change during the sweeps): bit 2 i + side.  Rows
   // nobody needs are skipped with a wave-uniform branch, so a sweep costs what the wavefront's active limits cost
   unsigned lim_rows = 0u;
@@ -2091,11 +2094,11 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
 #pragma unroll
     for (int k = 0; k < NBR; k++) if (sc.reg_body[k] >= 0) {
       // (the limit rows of a register-chain body are swept through LDS: their right-hand sides and starting impulses live there)
-      const int mo0 = ln.pll(ln.bi(sc.reg_body[k])[DG_BI_FIRST_LINK])[PLL_MROW]; const bool pinning = sc.HF[DG_HF_LIMIT_GUESS] > 0.f;
+      const int mo0 = ln.pll(ln.bi(sc.reg_body[k])[DG_BI_FIRST_LINK])[PLL_MROW]; const float ptol = limit_ptol(sc); const bool pinning = ptol >= 0.f;
       float lb0[RN], la0[RN], lb1[RN], la1[RN];
       _Pragma("unroll") for (int i = 0; i < RN; i++) { const bool has = i < rn[k]; const int mo = mo0 + (has ? i : 0) * MR_STRIDE;
         lb0[i] = ln.L(mo + MR_LO_B); la0[i] = has ? ln.L(mo + MR_LO_ACC) : -1.f; lb1[i] = ln.L(mo + MR_HI_B); la1[i] = has ? ln.L(mo + MR_HI_ACC) : -1.f; }
-      chain_motor_guess(rM[k], rb[k], smax[k], racc[k], rdv[k], pinning, lb0, la0, lb1, la1);
+      chain_motor_guess(rM[k], rb[k], smax[k], racc[k], rdv[k], ptol, lb0, la0, lb1, la1);
       if (pinning) { _Pragma("unroll") for (int i = 0; i < RN; i++) if (i < rn[k]) { ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC) = la0[i]; ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC) = la1[i]; } }
     }
     if (has_generic) for (int b = 0; b < sc.nba; b++) {  // (their starting impulses are in the rows' MR_ACC / MR_LO_ACC / MR_HI_ACC slots)

@@ -859,6 +859,9 @@ static void substep(dgo_world* w, int env, int last) {
    * by (b_motor - b_limit) / diag per sweep until the motor saturates. */
   if (s->F[DG_HF_MOTOR_GUESS] > 0) {
     const int pinning = s->F[DG_HF_LIMIT_GUESS] > 0;
+    /* (only a target that lies beyond the limit by more than the sweeps' own early-out: closer than that the two rows are
+     * converged as they stand -- a joint RESTING on its limit under a zero-velocity motor sits exactly there, +-rounding) */
+    const real ptol = sqrt(s->F[DG_HF_RESIDUAL_THRESHOLD]);
     for (int b = 0; b < s->nb; b++) {
       BodyWS* ws = &wsb[b]; int idx[MAXL], dof[MAXL], k = 0;
       for (int r = 0; r < nr; r++) if (rows[r].body_a == b && rows[r].motor_link >= 0) { idx[k] = r; dof[k] = rows[r].motor_link - ws->first; k++; }
@@ -873,7 +876,7 @@ static void substep(dgo_world* w, int env, int last) {
           for (int r = 0; r < nr; r++) { /* the joint's active limit rows: JA = +-e_dof, b = the velocity the row demands along JA */
             const Row* q = &rows[r]; if (q->body_a != b || q->motor_link >= 0 || q->limit_dof != dof[j]) continue;
             const real sg = q->limit_sign, vlim = sg * q->b; /* lower (sg = +1): dv >= vlim; upper (sg = -1): dv <= vlim */
-            if (sg > 0 ? rows[idx[j]].b < vlim : rows[idx[j]].b > vlim) { pin[j] = sg > 0 ? -1 : 1; lrow[j] = r; target = vlim; }
+            if (sg > 0 ? rows[idx[j]].b < vlim - ptol : rows[idx[j]].b > vlim + ptol) { pin[j] = sg > 0 ? -1 : 1; lrow[j] = r; target = vlim; }
           }
         bb[j] = target * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l];
       }

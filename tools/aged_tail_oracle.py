@@ -29,7 +29,7 @@ def main():
     from diy_gym_amd.utils import flatten, get_bounds_for_space
     engine = {k: float(v) for k, v in (kv.split('=') for kv in args.engine.split(',') if kv)}
     B = args.envs
-    env = DIYGym(os.path.join(ROOT, args.config), num_envs=B, seed=1234, backend_factory=oracle_backend.flavour('f32_omp'), engine=engine)
+    env = DIYGym(os.path.join(ROOT, args.config), num_envs=B, seed=1234, backend_factory=oracle_backend.flavour(os.environ.get('DG_ORACLE_FLAVOUR', 'f32_omp')), engine=engine)
     lo = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, True)), dtype=torch.float32)
     hi = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, False)), dtype=torch.float32)
     gen = torch.Generator().manual_seed(1234)

@@ -274,11 +274,11 @@ CROSSED = [1.35, -1.08, 1.03, -0.01, 0.09, 0.86]   # rest_position of tests/gold
 REFERENCE_SETTINGS = {'motor_guess': 0.0, 'warmstart': 0.85}
 LEGS = {
     # name: (workload, envs or None (BASELINE size), engine overrides, fraction of envs put into the crossed pose, steps timed)
-    'in_contact': ('ur_high_5', None, None, 1.0, 104),
-    'mixed': ('ur_high_5', None, None, 0.01, 104),
-    'reference_solver_settings': ('ur_high_5', None, REFERENCE_SETTINGS, 0.0, 104),
-    'r2d2_maze': ('r2d2_maze', None, None, 0.0, 104),
-    'drone_pilot': ('drone_pilot', None, None, 0.0, 104),
+    'in_contact': ('ur_high_5', None, None, 1.0, 200),
+    'mixed': ('ur_high_5', None, None, 0.01, 200),
+    'reference_solver_settings': ('ur_high_5', None, REFERENCE_SETTINGS, 0.0, 304),
+    'r2d2_maze': ('r2d2_maze', None, None, 0.0, 200),
+    'drone_pilot': ('drone_pilot', None, None, 0.0, 304),
     'from_the_readme': ('from_the_readme', None, None, 0.0, 104),
 }
 CONFIG_LEGS = ('r2d2_maze', 'drone_pilot', 'from_the_readme')
@@ -335,6 +335,17 @@ class Leg:
         for i in range(start, start + n):
             self.one_step(i)
         self.step_launches += n
+
+    def warm_for(self, seconds, min_steps=48, max_steps=4000):
+        """Untimed eager steps until the GPU has been busy for `seconds` (at least min_steps): a leg starts right after its world
+        was built on the host, the GPU idle for a second or two, and with 0.1 ms kernels a 48-step warm-up is over before the
+        clocks are back up -- the first run of these legs timed drone_pilot and the zero-started ur_high_5 at 3-4x their kernel
+        time while the legs with long kernels were consistent."""
+        torch, n, t0 = self.torch, 0, time.perf_counter()
+        while n < min_steps or (time.perf_counter() - t0 < seconds and n < max_steps):
+            self.eager(16, n); n += 16
+            torch.cuda.synchronize()
+        return n
 
     def capture(self, steps):
         """hipGraphs of the timed loop: segments of R consecutive steps (+ a shorter one for steps % R), and the step kernel
@@ -623,10 +634,9 @@ def measure_leg(name, device, args, prof):
     import torch
     steps = LEGS[name][4]
     leg = make_leg(name, device, auto_reset=not args.no_auto_reset)
-    warm = 48
-    leg.eager(warm)
-    torch.cuda.synchronize()
-    untimed = warm + leg.capture(steps)
+    untimed = leg.warm_for(0.25)
+    untimed += leg.capture(steps)
+    leg.run(2 * leg.R); untimed += 2 * leg.R   # (two more untimed segments through the replayed graph)
     el = leg.timed(steps)
     step_ms, render_ms, step_eager_ms = leg.kernel_times(32)
     out = {'workload': '%s x %d envs' % (leg.workload, leg.B), 'what': leg.desc, 'engine': leg.engine, 'steps': steps, 'untimed_steps_before': untimed,

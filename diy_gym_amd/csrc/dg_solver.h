@@ -587,32 +587,51 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
     rhs[i] = (plo ? lb0[i] : (phi ? -lb1[i] : b[i])) * sd[i];
   }
   chol_unit_solve<N>([&](int i, int j) { return M[i * N + j] * sd[i] * sd[j]; }, rhs, x);
-  // one active-set round (DG_MOTOR_GUESS_REFINE): rows beyond their bounds are held there, the others solved again
-  bool held[N], any = false; float val[N];
+  // Primal-dual active set, at most DG_MOTOR_GUESS_ROUNDS rounds: the rows beyond their bounds are held there and the others
+  // solved again; the sets are then re-read from x + residual (the diagonal of the scaled system is 1) -- a held row whose
+  // residual pulls it back inside is released, a free row that left its bounds is held -- until no lane's sets change.  The
+  // fixed sets are the solution of the clamped system: the sweeps then only confirm it (one iteration for ur_high_5; a single
+  // round left 1e-2 .. 1e-1 rad/s behind whenever a row saturated: 8 sweeps at the 90th percentile, 18-24 for the slowest env
+  // of a wavefront).  Bounds in scaled units; a pinned joint's unknown (its total impulse) is bounded on one side only.
+  float blo[N], bhi[N]; bool up[N], dn[N], any = false;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const float imp = x[i] * sd[i];
-    held[i] = smax[i] > 0.f && (pin[i] != 0.f ? pin[i] * imp > smax[i] : fabsf(imp) > smax[i]); any = any || held[i];
-    val[i] = held[i] ? (pin[i] != 0.f ? pin[i] * smax[i] : copysignf(smax[i], imp)) * frcp(sd[i]) : 0.f;
+    const float bs = smax[i] > 0.f ? smax[i] * frcp(sd[i]) : 3.0e38f;
+    blo[i] = pin[i] > 0.f ? -3.0e38f : -bs; bhi[i] = pin[i] < 0.f ? 3.0e38f : bs;
+    up[i] = x[i] > bhi[i]; dn[i] = x[i] < blo[i]; any = any || up[i] || dn[i];
   }
   if (__any(any)) {
-    float r2[N], x2[N];
+#pragma unroll 1
+    for (int round = 0; round < DG_MOTOR_GUESS_ROUNDS; round++) {
+      float r2[N], x2[N], val[N]; bool held[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      float t = held[i] ? val[i] : rhs[i];
+      for (int i = 0; i < N; i++) { held[i] = up[i] || dn[i]; val[i] = up[i] ? bhi[i] : (dn[i] ? blo[i] : 0.f); }
 #pragma unroll
-      for (int j = 0; j < N; j++) if (j != i) t -= (!held[i] && held[j]) ? M[i * N + j] * sd[i] * sd[j] * val[j] : 0.f;
-      r2[i] = t;
+      for (int i = 0; i < N; i++) {
+        float t = held[i] ? val[i] : rhs[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) if (j != i) t -= (!held[i] && held[j]) ? M[i * N + j] * sd[i] * sd[j] * val[j] : 0.f;
+        r2[i] = t;
+      }
+      chol_unit_solve<N>([&](int i, int j) { return (held[i] || held[j]) ? 0.f : M[i * N + j] * sd[i] * sd[j]; }, r2, x2);
+      bool changed = false;
+#pragma unroll
+      for (int i = 0; i < N; i++) x[i] = any ? x2[i] : x[i];   // (a lane without a held row keeps its first solution, bit for bit)
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        float y = x[i] + rhs[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) y -= (j == i ? 1.f : M[i * N + j] * sd[i] * sd[j]) * x[j];
+        const bool nu = any && y > bhi[i], nd = any && y < blo[i]; changed = changed || nu != up[i] || nd != dn[i]; up[i] = nu; dn[i] = nd;
+      }
+      if (!__any(changed)) break;
     }
-    chol_unit_solve<N>([&](int i, int j) { return (held[i] || held[j]) ? 0.f : M[i * N + j] * sd[i] * sd[j]; }, r2, x2);
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] = any ? x2[i] : x[i];
   }
   float tot[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const float t = x[i] * sd[i], clamped = __builtin_amdgcn_fmed3f(t, -smax[i], smax[i]);
-    const bool pinned = pin[i] != 0.f && !held[i];
+    const bool pinned = pin[i] != 0.f && !(pin[i] * t > smax[i]);  // (beyond the bound: the motor alone is too weak to reach the limit velocity -- an ordinary saturated row)
     const float lim = pinned ? fmaxf(smax[i] - pin[i] * t, 0.f) : 0.f;  // what the limit row holds (it pushes along -pin)
     acc[i] = pinned ? pin[i] * smax[i] : clamped; tot[i] = acc[i] - pin[i] * lim;
     if (pinning) { if (pinned && pin[i] < 0.f) la0[i] = lim; if (pinned && pin[i] > 0.f) la1[i] = lim; }

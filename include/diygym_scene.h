@@ -102,8 +102,9 @@ enum {
   DG_HF_MOTOR_GUESS,    /* > 0: the motor rows of a body start from the clamped solution of the body's unclamped motor system
                            (M^-1 restricted to the motorised joints) lambda = b instead of from zero.  By the body's joint
                            count n (what the factorisation costs on the device decides the cut-offs):
-                             n <= DG_MOTOR_GUESS_REFINE: if a row of the solution exceeds its bound, ONE active-set round --
-                                  those rows are held at their bounds and the others solved again -- then the clamp;
+                             n <= DG_MOTOR_GUESS_REFINE: if a row of the solution exceeds its bound, a primal-dual active set of at
+                                  most DG_MOTOR_GUESS_ROUNDS rounds -- the rows beyond their bounds held there, the others solved
+                                  again, the sets re-read from x + residual -- then the clamp (round 3: one round);
                              n <= DG_MOTOR_GUESS_MAX:    if a row exceeds its bound the body starts from zero (as without);
                              beyond:                     no starting guess (zero) */
   DG_HF_LIMIT_GUESS,    /* > 0 (with DG_HF_MOTOR_GUESS, bodies of n <= DG_MOTOR_GUESS_REFINE joints): a joint whose motor target
@@ -139,6 +140,7 @@ enum { DG_KF_POS_A = 0, DG_KF_QUAT_A = 3, DG_KF_POS_B = 7, DG_KF_QUAT_B = 10, DG
 #define DG_MAX_CONSTRAINTS 4
 
 #define DG_MOTOR_GUESS_REFINE 8
+#define DG_MOTOR_GUESS_ROUNDS 4   /* rounds of the primal-dual active set in the motor guess (bodies of <= DG_MOTOR_GUESS_REFINE joints) */
 #define DG_MOTOR_GUESS_MAX 10
 
 /* ---- per-env state prefix --------------------------------------------- */

@@ -881,24 +881,38 @@ static void substep(dgo_world* w, int env, int last) {
         bb[j] = target * sc_[j]; for (int l = 0; l < k; l++) A[l * k + j] = rows[idx[j]].RA[6 + dof[l]] * sc_[j] * sc_[l];
       }
       if (!spd_solve(k, A, bb, x)) continue;
-      int held[MAXL], any = 0; real val[MAXL];
+      /* Bounds of the unknowns in the scaled system (unit diagonal).  A pinned joint's unknown is its TOTAL impulse, bounded on
+       * one side only: dir x t <= the motor's bound (beyond it the motor is too weak to reach the limit velocity). */
+      real blo[MAXL], bhi[MAXL]; int held[MAXL], up[MAXL], dn[MAXL], any = 0;
       for (int j = 0; j < k; j++) {
-        const Row* r = &rows[idx[j]]; const real imp = x[j] * sc_[j];
-        /* a pinned joint has a one-sided bound: dir x t <= the motor's bound (beyond it the motor is too weak to reach the limit) */
-        held[j] = pin[j] ? pin[j] * imp > r->hi : (imp < r->lo || imp > r->hi); any |= held[j];
-        val[j] = (pin[j] ? pin[j] * r->hi : (imp < r->lo ? r->lo : r->hi)) / sc_[j];
+        const Row* r = &rows[idx[j]];
+        blo[j] = pin[j] > 0 ? -HUGE_R : r->lo / sc_[j]; bhi[j] = pin[j] < 0 ? HUGE_R : r->hi / sc_[j];
+        up[j] = x[j] > bhi[j]; dn[j] = x[j] < blo[j]; held[j] = up[j] || dn[j]; any |= held[j];
       }
       if (any && ws->n > DG_MOTOR_GUESS_REFINE) continue; /* a bigger body whose solution does not fit its bounds: zero start */
-      if (any) { /* one active-set round: the rows beyond their bounds held there, the others solved again */
-        real A2[MAXL * MAXL], b2[MAXL];
+      /* Primal-dual active set (Hintermueller, Ito, Kunisch 2002 for box-constrained problems with an M-matrix-like operator):
+       * rows beyond their bounds are held there and the others solved again; then the sets are re-read from x + residual --
+       * a held row whose residual pulls it back inside is released, a free row that left its bounds is held -- until the sets
+       * repeat, at most DG_MOTOR_GUESS_ROUNDS times.  The fixed sets ARE the solution of the clamped system (2 000 systems of
+       * an ur_high_5 rollout: 1.25 rounds on average, 4 at most, and the sweeps confirm it in ONE iteration; a single round
+       * left residuals of 1e-2 .. 1e-1 rad/s behind whenever a row saturated: 8 sweeps at the 90th percentile, 26 at the 99th). */
+      for (int round = 0; any && round < DG_MOTOR_GUESS_ROUNDS; round++) {
+        real A2[MAXL * MAXL], b2[MAXL], val[MAXL];
+        for (int j = 0; j < k; j++) val[j] = up[j] ? bhi[j] : blo[j];
         for (int j = 0; j < k; j++) { b2[j] = bb[j]; for (int l = 0; l < k; l++) A2[l * k + j] = A[l * k + j]; }
         for (int j = 0; j < k; j++) if (held[j]) for (int l = 0; l < k; l++) if (!held[l]) b2[l] -= A[l * k + j] * val[j];
         for (int j = 0; j < k; j++) if (held[j]) { for (int l = 0; l < k; l++) { A2[l * k + j] = 0; A2[j * k + l] = 0; } A2[j * k + j] = 1; b2[j] = val[j]; }
-        if (!spd_solve(k, A2, b2, x)) continue;
+        if (!spd_solve(k, A2, b2, x)) break;
+        int changed = 0;
+        for (int j = 0; j < k; j++) { /* x + residual (the diagonal is 1): a free row's residual is zero, a held row's says which way it wants to go */
+          real y = x[j] + bb[j]; for (int l = 0; l < k; l++) y -= A[j * k + l] * x[l];
+          const int nu = y > bhi[j], nd = y < blo[j]; changed |= nu != up[j] || nd != dn[j]; up[j] = nu; dn[j] = nd; held[j] = nu || nd;
+        }
+        if (!changed) break;
       }
       for (int j = 0; j < k; j++) {
         Row* r = &rows[idx[j]]; real t = x[j] * sc_[j], imp, lim = 0.0;
-        if (pin[j] && !held[j]) { /* motor saturated into the limit, the limit row holds the balance (never negative) */
+        if (pin[j] && !(pin[j] * t > r->hi)) { /* motor saturated into the limit, the limit row holds the balance (never negative) */
           imp = pin[j] * r->hi; lim = r->hi - pin[j] * t; if (lim < 0) lim = 0;
           Row* q = &rows[lrow[j]]; q->acc = lim; t = imp - pin[j] * lim; /* (the limit row pushes along -dir) */
         } else { imp = t < r->lo ? r->lo : (t > r->hi ? r->hi : t); t = imp; }

@@ -198,19 +198,23 @@ class HipBackend:
 
     def apply_external_force(self, body, frame, force, pos=None, flags=2):
         """``p.applyExternalForce(uid, linkIndex, forceObj, posObj, flags)`` for every env at once (``force``: ``[B, 3]`` or
-        one 3-vector; ``pos``: likewise, default the origin).  ``frame`` is the index ``Model.get_frame_id`` returns
-        (-1: the base).  The force acts during the next ``step`` only, like pybullet's; see ``dg_world_apply_wrench``."""
+        one 3-vector; ``pos``: likewise, default the origin).  ``body`` is a Model's ``uid`` (an attached child model's alias
+        uid included), ``frame`` the index ``Model.get_frame_id`` returns (-1: the base).  ``LINK_FRAME`` means the link's
+        INERTIAL frame, as in pybullet.  The force acts during the next ``step`` only; see ``dg_world_apply_wrench``."""
+        body, frame = self.layout.resolve_frame(body, frame)   # (the uid of a merged child model is an alias into its parent's body)
         self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), _ptr(self._rows3('force', force)),
                                                    _ptr(self._rows3('pos', pos)), None, self._stream()))
 
     def apply_external_wrench(self, body, frame, force, pos, torque, flags=2):
         """Force at ``pos`` and torque in ONE launch (what the compiled ``propellor`` op does: its base torque is
         ``r x F + T`` summed before it is added to the state, so this form reproduces that op bit for bit)."""
+        body, frame = self.layout.resolve_frame(body, frame)
         self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), _ptr(self._rows3('force', force)),
                                                    _ptr(self._rows3('pos', pos)), _ptr(self._rows3('torque', torque)), self._stream()))
 
     def apply_external_torque(self, body, frame, torque, flags=2):
         """``p.applyExternalTorque(uid, linkIndex, torqueObj, flags)`` for every env at once."""
+        body, frame = self.layout.resolve_frame(body, frame)
         self._check(self.lib.dg_world_apply_wrench(self.handle, _ptr(self.state), int(body), int(frame), int(flags), None, None,
                                                    _ptr(self._rows3('torque', torque)), self._stream()))
 

@@ -2588,11 +2588,14 @@ DGD void apply_frame_wrench(const Lane<LANES>& ln, int b, int fr, V3 f, V3 pos, 
   V3 F = f, T = t, P = pos;
   if (link_frame) {
     V3 fp; M3 R;
+    // LINK_FRAME is the link's INERTIAL frame -- origin at its centre of mass, axes of the URDF <inertial> -- as pybullet's
+    // (btMultiBody's m_cachedWorldTransform / base world transform [R]), not the joint frame
     if (gl < 0) {  // on the base: pose from the state
-      const Q4 qb = ln.base_quat(b); const V3 pb = ln.base_pos(b); V3 off = v3(0.f, 0.f, 0.f); Q4 qo = {0.f, 0.f, 0.f, 1.f};
-      if (fr >= 0) { cfp ff = sc.FF + fr * DG_FF_STRIDE + DG_FF_POS; off = v3(ff[0], ff[1], ff[2]); Q4 tq = {ff[3], ff[4], ff[5], ff[6]}; qo = tq; }
+      const Q4 qb = ln.base_quat(b); const V3 pb = ln.base_pos(b);
+      cfp ff = fr >= 0 ? sc.FF + fr * DG_FF_STRIDE + DG_FF_COM_POS : ln.bf(b) + DG_BF_REPORT_POS;  // (both: pos3 then quat4)
+      const V3 off = v3(ff[0], ff[1], ff[2]); const Q4 qo = {ff[3], ff[4], ff[5], ff[6]};
       const V3 ro = mulx(qmat_x(qb), off); fp = v3(pb.x + ro.x, pb.y + ro.y, pb.z + ro.z); R = qmat_x(qnormalize_x(qmul_x(qb, qo)));
-    } else { V3 fv, fw; Q4 fq; ln.frame_state(b, fr, false, fp, fq, fv, fw, false); R = qmat_x(fq); }
+    } else { V3 fv, fw; Q4 fq; ln.frame_state(b, fr, true, fp, fq, fv, fw, false); R = qmat_x(fq); }
     F = mulx(R, f); T = mulx(R, t);
     const V3 rp = mulx(R, pos); P = v3(fp.x + rp.x, fp.y + rp.y, fp.z + rp.z);
   }

@@ -51,6 +51,8 @@ class DIYGym(Receptor):
         self.name = config.name
         self.compat = num_envs is None
         self.num_envs = 1 if num_envs is None else int(num_envs)
+        if not 4 <= int(max_hull_points) <= 256:
+            raise ValueError('max_hull_points must be in [4, 256] (a contact is identified by its hull vertex, DG_CONTACT_KEY)')
         self.max_hull_points = max_hull_points
         self._max_episode_steps = config.get('max_episode_steps') if 'max_episode_steps' in config else None
         self.hot_start = config.get('hot_start', 1)

@@ -669,6 +669,7 @@ class SceneLayout:
         self.addon_off = addon_off
         self.state_dim = state_dim
         self.max_contacts = max_contacts
+        self.aliases = dict(builder.aliases)  # uid of an attached child model -> (body, link offset, frame offset, frame that stands for its base)
         self.warm_off = int(I[K.H_WARM_OFF])  # state offset of the contact impulse cache (warm starting), -1: none
         self.physical_dim = self.warm_off if self.warm_off >= 0 else state_dim  # state columns before that cache
         self.act_dim = builder.dims['act']
@@ -680,3 +681,13 @@ class SceneLayout:
         self.n_slots = builder.n_slots
         self.substeps = builder.substeps
         self.dt = builder.timestep / builder.substeps
+
+    def resolve_frame(self, uid, frame):
+        """``(body index, body-local frame index)`` behind a Model's ``uid`` and one of ITS frame ids (-1: its base).  A model
+        attached to its parent with the default ``attach: merge`` owns no body: its uid is an alias, its frames live in the
+        parent's body behind an offset and its base is one of the parent's frames."""
+        uid, frame = int(uid), int(frame)
+        if uid in self.aliases:
+            body, _, foff, basef = self.aliases[uid]
+            return body, (basef if frame < 0 else foff + frame)
+        return uid, frame

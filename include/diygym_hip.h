@@ -105,7 +105,9 @@ int32_t dg_world_frame_state(dg_world* w, const float* state, int32_t body, int3
  * hook (reference examples/drone_pilot/drone_pilot.py:34-37, diy_gym/addons/addon.py:80-81 registry, :91-186 hooks;
  * diy_gym/addons/controllers/external_force.py:24) -- every env at once: force, pos, torque are device arrays
  * [num_envs][3] (any may be NULL = zero).  `frame` is the pybullet joint index of the link (-1 = base).  flags as in
- * pybullet: DG_WRENCH_LINK_FRAME -- force / torque in the link frame's axes, pos relative to its origin;
+ * pybullet: DG_WRENCH_LINK_FRAME -- force / torque along the axes of the link's INERTIAL frame (URDF <inertial> origin:
+ * centre of mass and its rpy), pos relative to that origin -- the frame pybullet resolves LINK_FRAME against [R], NOT the
+ * joint frame; for a link without an <inertial><origin> the two coincide;
  * DG_WRENCH_WORLD_FRAME -- all three in world coordinates.  The wrench acts during the NEXT dg_world_step only
  * (pybullet clears external forces after every stepSimulation) and adds to what compiled ops apply.  For a frame on a
  * movable link the joints between it and the base receive J^T of the wrench.  The compiled external_force / propellor

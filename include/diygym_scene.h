@@ -125,10 +125,10 @@ enum {
 
 /* ---- contact impulse cache (per-env state at DG_H_WARM_OFF, only when DG_HF_WARMSTART* > 0 and the scene has pairs) ----
  * [count] then max_contacts entries [key, normal, t1, t2]: the contacts of the env's most recent substep and the impulses
- * their rows ended with.  key = candidate pair index * 64 + feature (sphere / fitted capsule: 0; capsule against a box:
- * which end; hull against a box: the hull vertex index & 63).  A reset clears the count. */
+ * their rows ended with.  key = candidate pair index * 256 + feature (sphere / fitted capsule: 0; capsule against a box:
+ * which end; hull against a box: the hull vertex index).  A reset clears the count. */
 enum { DG_WS_KEY = 0, DG_WS_NORMAL, DG_WS_T1, DG_WS_T2, DG_WS_STRIDE };
-#define DG_CONTACT_KEY(pair, feature) ((pair) * 64 + ((feature) & 63))
+#define DG_CONTACT_KEY(pair, feature) ((pair) * 256 + ((feature) & 255))  /* exact in fp32 up to 65 536 candidate pairs; hulls of up to 256 points (DIYGym's max_hull_points is capped there) keep one key per vertex */
 
 /* ---- fixed constraints (reference model.py:74-75: p.createConstraint(parent, parent_frame, child, child_frame,
  * JOINT_FIXED, ...)) as SOLVER ROWS: three linear rows along the world axes at the pivot (pulling the pivot on side B onto

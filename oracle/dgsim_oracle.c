@@ -1226,7 +1226,7 @@ static void run_update_ops(dgo_world* w, int env, const real* act, uint64_t mask
       int b = oi[DG_OI_BODY]; real* as = st + s->addon_off + oi[DG_OI_STATE_OFF];
       as[0] = as[0] + (a[0] - as[0]) * of[2];
       if (body_fixed(s, b)) continue;
-      FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 0, NULL, &f);
+      FrameState f; frame_state(s, st, b, oi[DG_OI_FRAME], 1, NULL, &f); /* LINK_FRAME = the link's INERTIAL frame (btMultiBody's m_cachedWorldTransform [R]) */
       m3 R = qmat(f.q); real* bs = st + body_i(s, b)[DG_BI_STATE_OFF]; real* ex = body_ext(s, st, b);
       v3 fw = mv(&R, V(0, 0, of[0] * as[0])), tw = mv(&R, V(0, 0, of[1] * as[0]));
       v3 t = vadd(vcross(vsub(f.p, V(bs[0], bs[1], bs[2])), fw), tw);
@@ -1235,7 +1235,9 @@ static void run_update_ops(dgo_world* w, int env, const real* act, uint64_t mask
   }
 }
 /* p.applyExternalForce / p.applyExternalTorque on frame `fr` (global frame index, -1 base) of body b for one env, as a user
- * addon written in Python issues them (drone_pilot.py:34-37): base wrench + J^T on the joints between the link and the base */
+ * addon written in Python issues them (drone_pilot.py:34-37): base wrench + J^T on the joints between the link and the base.
+ * LINK_FRAME: force / torque along the axes of the link's INERTIAL frame, pos relative to its origin, the centre of mass
+ * (PhysicsServerCommandProcessor: mb->getLink(i).m_cachedWorldTransform / getBaseWorldTransform() [R]) */
 int dgo_apply_wrench(dgo_world* w, int32_t body, int32_t frame, int32_t link_frame, const real* force, const real* pos, const real* torque) {
   Scene* s = &w->sc;
   if (body < 0 || body >= s->nb || (body_i(s, body)[DG_BI_FLAGS] & DG_BODY_FROZEN)) { set_err("bad body %d", body); return 1; }
@@ -1243,7 +1245,7 @@ int dgo_apply_wrench(dgo_world* w, int32_t body, int32_t frame, int32_t link_fra
     real* st = env_state(w, e);
     v3 F = force ? V(force[3 * e], force[3 * e + 1], force[3 * e + 2]) : V(0, 0, 0), T = torque ? V(torque[3 * e], torque[3 * e + 1], torque[3 * e + 2]) : V(0, 0, 0);
     v3 P = pos ? V(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) : V(0, 0, 0);
-    if (link_frame) { FrameState f; frame_state(s, st, body, frame, 0, NULL, &f); m3 R = qmat(f.q); F = mv(&R, F); T = mv(&R, T); P = vadd(f.p, mv(&R, P)); }
+    if (link_frame) { FrameState f; frame_state(s, st, body, frame, 1, NULL, &f); /* the link's inertial frame, as pybullet's LINK_FRAME [R] */ m3 R = qmat(f.q); F = mv(&R, F); T = mv(&R, T); P = vadd(f.p, mv(&R, P)); }
     if (!body_fixed(s, body)) {
       real* bs = st + body_i(s, body)[DG_BI_STATE_OFF]; real* ex = body_ext(s, st, body);
       v3 t = vadd(vcross(vsub(P, V(bs[0], bs[1], bs[2])), F), T);

@@ -162,18 +162,21 @@ class OracleBackend:
         return np.ascontiguousarray(np.broadcast_to(a.reshape(-1, 3), (self.num_envs, 3)))
 
     def apply_external_force(self, body, frame, force, pos=None, flags=2):
+        body, frame = self.layout.resolve_frame(body, frame)
         gf = -1 if frame < 0 else self._global_frame(body, frame)
         f, p = self._rows3(force), self._rows3(pos)
         if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), _p(f), _p(p), None):
             raise RuntimeError(self.L.dgo_last_error().decode())
 
     def apply_external_wrench(self, body, frame, force, pos, torque, flags=2):
+        body, frame = self.layout.resolve_frame(body, frame)
         gf = -1 if frame < 0 else self._global_frame(body, frame)
         f, p, t = self._rows3(force), self._rows3(pos), self._rows3(torque)
         if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), _p(f), _p(p), _p(t)):
             raise RuntimeError(self.L.dgo_last_error().decode())
 
     def apply_external_torque(self, body, frame, torque, flags=2):
+        body, frame = self.layout.resolve_frame(body, frame)
         gf = -1 if frame < 0 else self._global_frame(body, frame)
         t = self._rows3(torque)
         if self.L.dgo_apply_wrench(self.handle, int(body), gf, int(flags == self.LINK_FRAME), None, None, _p(t)):

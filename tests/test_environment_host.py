@@ -346,3 +346,27 @@ def test_python_hook_addon_pushes_on_the_world_like_the_compiled_op():
     n = a.layout.addon_off
     assert np.allclose(a.sim.get_state()[:, :n], b.sim.get_state()[:, :n], rtol=0, atol=1e-12)
     assert np.abs(a.sim.get_state()[:, :n]).max() > 1.0
+
+
+def test_wrench_on_an_attached_child_model_resolves_its_alias_uid():
+    """A user addon on a CHILD model follows the README pattern -- ``self.uid = parent.uid`` and then
+    ``sim.apply_external_force(self.uid, frame_id, ...)``.  A child attached with the default ``attach: merge`` owns no body:
+    its uid is an alias (>= ALIAS_BASE) into the parent's body, its frames sit behind an offset there and its base is one of
+    the parent's frames.  Asserted: the call is accepted and equals the same wrench given through the parent's body and the
+    resolved frame, for a frame of the child and for its base (-1)."""
+    cfg = os.path.join(ROOT, 'tests', 'golden', 'ur5_child_gripper.yaml')
+    for child_frame in (-1, 2):
+        a = DIYGym(cfg, num_envs=2, backend_factory=OracleBackend); b = DIYGym(cfg, num_envs=2, backend_factory=OracleBackend)
+        grip = a.models['arm'].models['gripper']
+        assert grip.uid >= a.builder.ALIAS_BASE
+        body, frame = a.layout.resolve_frame(grip.uid, child_frame)
+        assert body == a.models['arm'].uid and frame >= 0
+        f = torch.tensor([[0.0, 3.0, -2.0], [1.0, 0.0, 0.5]])
+        a.sim.apply_external_force(grip.uid, child_frame, f, [0.01, 0.0, 0.02], a.sim.LINK_FRAME)
+        b.sim.apply_external_force(body, frame, f, [0.01, 0.0, 0.02], b.sim.LINK_FRAME)
+        zero = torch.zeros((2, a.layout.act_dim))
+        a.sim.step(0, zero); b.sim.step(0, zero)
+        sa, sb = np.asarray(a.sim.get_state()), np.asarray(b.sim.get_state())
+        assert np.array_equal(sa, sb)
+        c = DIYGym(cfg, num_envs=2, backend_factory=OracleBackend); c.sim.step(0, zero)
+        assert np.abs(sa - np.asarray(c.sim.get_state())).max() > 1e-6   # and it did push

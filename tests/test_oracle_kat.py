@@ -682,3 +682,23 @@ def test_motor_impulse_time_base_substep_or_full_step(tmp_path):
     grav = 1.0 * 9.81 * 0.5 * np.sin(q0)   # 1.91 N m
     assert abs(abs(ss[qo + K.LS_APPLIED]) - 1.5) < 1e-9 and ss[qo] < q0 - 1e-5         # 1.5 < 1.91: saturated, sinks
     assert abs(abs(sf[qo + K.LS_APPLIED]) - grav) < 2e-2 and abs(sf[qo] - q0) < 1e-4   # bound 3.0 > 1.91: holds, effort = gravity
+
+
+def test_link_frame_of_an_external_force_is_the_inertial_frame(tmp_path):
+    """p.applyExternalForce(uid, link, F, pos, LINK_FRAME): pybullet resolves force and position against the link's INERTIAL
+    frame (centre of mass, btMultiBody's cached world transform [R]), not the joint frame.  The pendulum's bob has its centre
+    of mass 0.5 m below the hinge: a unit force along x applied at pos = 0 in LINK_FRAME acts AT the bob, lever 0.5 m about
+    the hinge (y axis) -> qdd = tau / (m L^2) = 0.5 / 0.25 = 2 rad/s^2; the same force given in WORLD_FRAME at the world
+    position of the hinge (0, 0, 1) has no lever at all.  No gravity, motor off."""
+    import yaml
+    cfg = {'render': False, 'gravity': [0.0, 0.0, 0.0], 'pend': {'model': os.path.join(G, 'urdf', 'pendulum.urdf'), 'xyz': [0, 0, 0]}}
+    path = tmp_path / 'pend0g.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'), sort_keys=False)
+    for flags, pos, expect in ((OracleBackend.LINK_FRAME, [0.0, 0.0, 0.0], 2.0), (OracleBackend.WORLD_FRAME, [0.0, 0.0, 1.0], 0.0), (OracleBackend.WORLD_FRAME, [0.0, 0.0, 0.5], 2.0)):
+        env = make(str(path), **NODAMP)
+        env.sim.set_motor_cfg(np.array([[0.0, 1.0, 0.0]]))   # no motor
+        uid = env.models['pend'].uid
+        env.sim.apply_external_force(uid, env.models['pend'].get_frame_id('hinge'), [1.0, 0.0, 0.0], pos, flags)
+        env.sim.step(0)
+        qd = env.sim.get_state()[0, link_q(env, 0, 0) + 1]
+        assert abs(abs(qd) - expect * 0.25 / (0.25 + 1e-6) / 240.0) < 1e-9, (flags, pos, qd * 240.0)   # (the bob's own 1e-6 kg m^2 added to m L^2)

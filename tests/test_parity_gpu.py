@@ -1033,7 +1033,7 @@ def test_arms_touching_under_ik_control_at_the_size_the_bench_ships():
 def test_warm_started_contacts_cache_and_iterations():
     """Contact warm starting (engine parameters warmstart / warmstart_friction, DG_WS_* cache in the state): marbles at rest
     on the plane, one contact each, so the cached impulses are unique.  Asserted against the oracle: the cache itself
-    (count, the keys = pair * 64 + feature in contact order, normal impulses to 1e-3 relative = m g h), that from the
+    (count, the keys = pair * 256 + feature in contact order, normal impulses to 1e-3 relative = m g h), that from the
     second step of resting the sweeps of BOTH implementations leave in < 10 iterations (a cold start takes more), that a
     masked reset clears the cache of the reset envs only, and that with warmstart = 0 no cache exists (state as before)."""
     gpu, cpu = make_pair('marbles', 9)

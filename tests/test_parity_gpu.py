@@ -1029,6 +1029,29 @@ def test_arms_touching_under_ik_control_at_the_size_the_bench_ships():
     assert worst < 5e-3, worst
 
 
+# ---- the ledger of recollected constants: every one of them moved at once ------------------------------------------------------
+MOVED = dict(residual_threshold=3e-8, contact_erp=0.15, limit_erp=0.2, linear_slop=1e-4, linear_damping=0.1, angular_damping=0.02, max_coordinate_velocity=50.0,
+             default_motor_impulse=0.5, ik_iterations=12, ik_lambda_sq=0.2, ik_joint_damping=0.2, ik_residual=2e-4, ik_max_angle=0.3, ik_null_rest_gain=0.01,
+             ik_null_limit_gain=5.0, contact_margin=0.03, warmstart=0.85, warmstart_friction=0.3, motor_impulse_timebase='step')
+
+
+@pytest.mark.parametrize('name,steps,tol,scale', [('ur_ik', 40, 5e-4, 1.0), ('touching', 20, 5e-3, 0.3), ('marbles', 60, 2e-3, 1.0), ('readme', 20, 3e-3, 0.2), ('drone', 40, 2e-3, 1.0),
+                                                   ('cart_tree', 12, 2e-2, 1.0), ('maze', 12, 1e-2, 10.0)])
+def test_every_engine_parameter_overridden_at_once(name, steps, tol, scale):
+    """DESIGN.md 4 lists the Bullet constants this build restates from recollection, each behind an engine parameter
+    (diy_gym_amd/scene.py::DEFAULTS).  tests/test_engine_parameters.py shows on the CPU that every one of them is live; here all
+    of them are moved off their defaults at once -- the motor rows' time base included -- and the kernels must follow the oracle
+    as they do at the defaults: no kernel carries one of these values as a literal."""
+    gpu, cpu = make_pair(name, 9, **MOVED)
+    w = rollout(gpu, cpu, steps, scale=scale)
+    assert w['obs'] < tol and w['term_mismatch'] == 0, w
+    a, b = phys_state(gpu), phys_state(cpu)
+    assert np.isfinite(a).all()
+    L = gpu.layout
+    cols = [o + k for o in L.link_state_off for k in (0, )] + [o + k for i, o in enumerate(L.body_state_off) if o >= 0 for k in range(7)]
+    assert np.abs(a[:, cols] - b[:, cols]).max() < 10 * tol, np.abs(a[:, cols] - b[:, cols]).max()
+
+
 # ---- warm starting ---------------------------------------------------------------------------------------------------------
 def test_warm_started_contacts_cache_and_iterations():
     """Contact warm starting (engine parameters warmstart / warmstart_friction, DG_WS_* cache in the state): marbles at rest

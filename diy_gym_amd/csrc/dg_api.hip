@@ -299,7 +299,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   sc.PLB = (cip)w->d_plan; sc.PLL = sc.PLB + (size_t)nb * PLB_STRIDE; sc.PD = sc.PLB + pd_off; sc.GD = (cfp)(sc.PLB + gd_off); sc.SD = sc.PLB + sd_off; sc.AM = sc.PLB + am_off;
   sc.nba = 0; for (int b = 0; b < nb; b++) if (!(BI[b * DG_BI_STRIDE + DG_BI_FLAGS] & DG_BODY_FROZEN)) sc.nba = b + 1;
   sc.nsha = 0; for (int s = 0; s < I[DG_H_N_SHAPES]; s++) if (I[I[DG_H_OFF_SHAPE_I] + s * DG_SI_STRIDE + DG_SI_TYPE] != DG_SHAPE_BOX) sc.nsha = s + 1;
-  sc.no_minv_slices = getenv("DG_NO_MINV_SLICES") ? 1 : 0; sc.no_sliced_reset = getenv("DG_NO_SLICED_RESET") ? 1 : 0;
+  sc.no_minv_slices = getenv("DG_NO_MINV_SLICES") ? 1 : 0; sc.no_chain_rows = getenv("DG_NO_CHAIN_ROWS") ? 1 : 0; sc.no_sliced_reset = getenv("DG_NO_SLICED_RESET") ? 1 : 0;
   sc.nb = nb; sc.nl = nl; sc.nfr = I[DG_H_N_FRAMES]; sc.nsh = I[DG_H_N_SHAPES]; sc.npairs = I[DG_H_N_PAIRS]; sc.ngroups = I[DG_H_N_GROUPS]; sc.nops = I[DG_H_N_OPS];
   sc.act_dim = I[DG_H_ACT_DIM]; sc.obs_dim = I[DG_H_OBS_DIM]; sc.rew_dim = I[DG_H_REW_DIM]; sc.term_dim = I[DG_H_TERM_DIM];
   sc.substeps = I[DG_H_SUBSTEPS]; sc.iters = I[DG_H_SOLVER_ITERS]; sc.hot_start = I[DG_H_HOT_START]; sc.ik_iters = I[DG_H_IK_ITERS];

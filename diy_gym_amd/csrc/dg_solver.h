@@ -504,6 +504,87 @@ DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool ve
   return mine;
 }
 
+// The same rows for the lanes whose contact joins shapes on two FIXED-BASE SERIAL CHAINS of at most six joints (two arms touching:
+// the goal state of ur_high_5), in an all-dense scene, again without the pair-by-pair serialisation.  build_contact_rows keeps every
+// table lookup wave-uniform by handling the lanes pair by pair; at 16 384 envs in as many different poses the 64 envs of a
+// wavefront hold up to ~20 different (link, link) pairs per contact slot, and the row construction was 75 % of an in-contact step
+// (1.69 M of 2.26 M cycles per wavefront, profiles/r4_touching_ik_16384_inkernel_stamps_before.txt).  Here the pair's links are
+// per-lane values: the loops run over the six possible joints of a chain with a per-lane mask (joint k is above the contact's
+// link), poses and M^-1 come from per-lane LDS slots, axes from per-lane table loads -- ONE pass per contact slot.  Same
+// arithmetic per row as point_row (the Jacobian entry of a revolute joint is dir . (axis x (p - origin)): the cross product is
+// shared by the three directions).  Returns whether this lane's contact was such a contact.
+template <int LANES>
+DGD bool build_contact_rows_chains(const Lane<LANES>& ln, int c, bool has) {
+  const DevScene& sc = ln.sc;
+  if (!sc.dense) return false;
+  constexpr int W = envs_per_wave(LANES);
+  const int tl = sc.crow_tail, rs = crow_stride(tl), nt = sc.nt;
+  const int cc = has ? c : 0, co = sc.cont_off + 1 + cc * CL_STRIDE;
+  const int pair = has ? (int)ln.L(co + CL_PAIR) : 0;
+  const int pa = sc.PI[pair * DG_PI_STRIDE + DG_PI_A], pb = sc.PI[pair * DG_PI_STRIDE + DG_PI_B];  // (per-lane indices: vector loads)
+  const int bod[2] = {sc.SI[pa * DG_SI_STRIDE + DG_SI_BODY], sc.SI[pb * DG_SI_STRIDE + DG_SI_BODY]};
+  const int lnk[2] = {sc.SI[pa * DG_SI_STRIDE + DG_SI_LINK], sc.SI[pb * DG_SI_STRIDE + DG_SI_LINK]};
+  const bool mine = has && sc.PLB[bod[0] * PLB_STRIDE + PLB_CHAIN] != 0 && sc.PLB[bod[1] * PLB_STRIDE + PLB_CHAIN] != 0;
+  if (!__any(mine)) return false;
+  if (mine) {
+    const V3 p = ln.L3(co + CL_P), n = ln.L3(co + CL_N); const float dist = ln.L(co + CL_DIST);
+    V3 t1, t2; tangent_basis(n, t1, t2);
+    const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
+    ln.L(co + CL_MU) = sc.SF[pa * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[pb * DG_SF_STRIDE + DG_SF_FRICTION];
+    const int wfound = warm_find(ln, ln.L(co + CL_KEY));
+    const V3 dirs[3] = {n, t1, t2};
+    float diag[3] = {0.f, 0.f, 0.f}, jv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 3; d++) { const int ro = sc.tr_off + (3 * c + d) * rs; for (int k = 0; k < tl; k++) ln.L(ro + k) = 0.f; }  // rows are swept branch-free: pad with zeros
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const int b = bod[side]; const float sg = side == 0 ? 1.f : -1.f;  // (both sides can move: the first is A, pushed along +dir)
+      const int first = sc.BI[b * DG_BI_STRIDE + DG_BI_FIRST_LINK], nl = sc.BI[b * DG_BI_STRIDE + DG_BI_N_LINKS];
+      const int mo = sc.PLB[b * PLB_STRIDE + PLB_MINV], g = sc.PLB[b * PLB_STRIDE + PLB_DV] - sc.dv_base, top = lnk[side] < 0 ? -1 : lnk[side] - first;
+      V3 wk[6]; float qd[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {  // w_k: the Jacobian entry of joint k along a direction is dir . w_k (zero for a joint not above the contact's link)
+        const bool on = k < nl && k <= top; const int gl = first + (on ? k : 0);
+        const float* pz = ln.lds + (size_t)sc.PLL[gl * PLL_STRIDE + PLL_POSE] * W;  // per-lane POSE slot of the link
+        const V3 c0 = v3(pz[0], pz[W], pz[2 * W]), c1 = v3(pz[3 * W], pz[4 * W], pz[5 * W]), c2 = cross(c0, c1), pk = v3(pz[6 * W], pz[7 * W], pz[8 * W]);
+        cfp f = sc.LF + gl * DG_LF_STRIDE; const V3 ax = v3(f[DG_LF_AXIS], f[DG_LF_AXIS + 1], f[DG_LF_AXIS + 2]);
+        const V3 axw = c0 * ax.x + c1 * ax.y + c2 * ax.z;  // R (axis): the columns of R are c0, c1, c0 x c1
+        const V3 w = sc.LI[gl * DG_LI_STRIDE + DG_LI_TYPE] == 0 ? cross(axw, p - pk) : axw;
+        wk[k] = on ? w * sg : v3(0.f, 0.f, 0.f);
+        qd[k] = on ? ln.S(sc.LI[gl * DG_LI_STRIDE + DG_LI_STATE_OFF] + DG_LS_QD) : 0.f;
+      }
+      float Mi[36];  // the body's M^-1 (n x n, row-major from a per-lane slot), zero-padded to 6 x 6
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const bool in = r < nl && q < nl; const float m = ln.lds[(size_t)(mo + (in ? r * nl + q : 0)) * W]; Mi[6 * r + q] = in ? m : 0.f; }
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int ro = sc.tr_off + (3 * c + d) * rs; float J[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { J[k] = dot(dirs[d], wk[k]); jv[d] += J[k] * qd[k]; }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          float r = 0.f;
+#pragma unroll
+          for (int k = 0; k < 6; k++) r += Mi[6 * k + q] * J[k];  // (M^-1 is symmetric: column q = row q)
+          diag[d] += r * J[q];
+          if (q < nl) { ln.lds[(size_t)(ro + g + q) * W] = J[q]; ln.lds[(size_t)(ro + nt + g + q) * W] = r; }
+        }
+      }
+      if (side == 0) { ln.L(co + CL_DVA) = (float)sc.PLB[b * PLB_STRIDE + PLB_DV]; ln.L(co + CL_NVA) = (float)sc.PLB[b * PLB_STRIDE + PLB_NV]; }
+      else { ln.L(co + CL_DVB) = (float)sc.PLB[b * PLB_STRIDE + PLB_DV]; ln.L(co + CL_NVB) = (float)sc.PLB[b * PLB_STRIDE + PLB_NV]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int ro = sc.tr_off + (3 * c + d) * rs; float b = -jv[d];
+      if (d == 0) { const float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
+      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag[d] > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag[d];
+    }
+  }
+  return mine;
+}
+
 // ---- batched LDS vector helpers -------------------------------------------------------------------------
 // A single wave pays a full LDS round trip for every dependent access, so vectors of run-time length n are moved in
 // chunks of 8 independent accesses (reads past n stay inside the padded regions and are masked out).
@@ -2000,6 +2081,7 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   for (int c = 0; c < wave_max_cont; c++) {
     const bool has = c < ncont; const int mypair = has ? (int)ln.L(sc.cont_off + 1 + c * CL_STRIDE + CL_PAIR) : -1;
     bool todo = has && !build_contact_rows_base(ln, c, has, vel_dense);  // base-on-base contacts: one pass for every pair
+    if (!sc.no_chain_rows) todo = todo && !build_contact_rows_chains(ln, c, todo);  // chain-on-chain contacts (two arms touching): likewise
     while (__any(todo)) {
       const int leader = __ffsll((long long)__ballot(todo)) - 1;
       const int pair = __shfl(mypair, leader);
@@ -2535,6 +2617,150 @@ DGD int run_ik_chain(const Lane<LANES>& ln, int op, const float* act, bool live_
   return iters;
 }
 
+// ---- the same solve with PACKED fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two fp32 operations per lane per instruction) -----
+// A lone wavefront issues a v_pk_fma_f32 at the cadence of a v_fma_f32 (tools/micro/valu_issue4.hip: 5.01 against 5.08 cycles per
+// instruction per wavefront), and with one workgroup per CU the step kernel's time IS the length of its longest wavefront's
+// instruction stream -- 39 % of which was this loop.  The compiler's own pairing (SLP) lost to the register shuffling it needs
+// (csrc/Makefile); here the DATA is laid out in pairs instead: a vector is (xy pair, z), a rotation its three columns, so a
+// matrix-vector product is three packed and three scalar FMAs instead of nine, scalars enter through the instruction's
+// op_sel broadcast, and the 6-vectors of the task space are ordered [lin.x lin.y | ang.x ang.y | lin.z ang.z] so that a Jacobian
+// column is three pairs that come straight out of the kinematics (the normal matrix and the solve work in that order; the
+// solution is the same, the rounding differs in the last bits).  Same recursion, same constants, same iteration control as
+// run_ik_chain<.., FULL = true>; chosen for six-revolute-joint chains with the null-space lists (every 6-axis arm).
+typedef float v2f __attribute__((ext_vector_type(2)));
+DGD v2f sp2(float s) { v2f r = {s, s}; return r; }
+DGD v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct P3 { v2f xy; float z; };
+DGD P3 p3(V3 v) { P3 r; r.xy.x = v.x; r.xy.y = v.y; r.z = v.z; return r; }
+// acc + c0 x + c1 y + c2 z  (the columns of a rotation times a vector)
+DGD P3 colmul_acc(const P3& c0, const P3& c1, const P3& c2, float x, float y, float z, const P3& acc) {
+  P3 r; r.xy = fma2(c2.xy, sp2(z), fma2(c1.xy, sp2(y), fma2(c0.xy, sp2(x), acc.xy))); r.z = fmaf(c2.z, z, fmaf(c1.z, y, fmaf(c0.z, x, acc.z))); return r;
+}
+DGD P3 colmul(const P3& c0, const P3& c1, const P3& c2, float x, float y, float z) {
+  P3 r; r.xy = fma2(c2.xy, sp2(z), fma2(c1.xy, sp2(y), c0.xy * sp2(x))); r.z = fmaf(c2.z, z, fmaf(c1.z, y, c0.z * x)); return r;
+}
+template <int LANES, bool ORN>
+DGD int run_ik_chain_pk(const Lane<LANES>& ln, int op, const float* act, bool live_lane, float* qout) {
+  constexpr int N = 6;
+  const DevScene& sc = ln.sc; cip oi = sc.OI + op * DG_OI_STRIDE;
+  const int b = oi[DG_OI_BODY], fr = oi[DG_OI_FRAME];
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK];
+  cfp rest = sc.FL + oi[DG_OI_FLIST]; cfp ff = sc.FF + fr * DG_FF_STRIDE;
+  const V3 off = v3(ff[DG_FF_COM_POS], ff[DG_FF_COM_POS + 1], ff[DG_FF_COM_POS + 2]);
+  const Q4 qoff = {ff[DG_FF_COM_QUAT], ff[DG_FF_COM_QUAT + 1], ff[DG_FF_COM_QUAT + 2], ff[DG_FF_COM_QUAT + 3]};
+  const M3 R0 = ln.LR(ln.plb(b)[PLB_R0]); const V3 p0 = ln.base_pos(b);
+  float q[N];
+  // chain constants in the primed frames of run_ik_chain (every joint rotates about the z axis of its frame), pinned in VGPRs
+  float cR[N][9], cP[N][3];
+  M3 Qprev = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}, Qee = Qprev;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    cfp f = ln.lf(first + i); q[i] = ln.S(ln.li(first + i)[DG_LI_STATE_OFF] + DG_LS_Q);
+    M3 RT; _Pragma("unroll") for (int k = 0; k < 9; k++) RT.m[k] = pin(f[DG_LF_ROT + k]);
+    const V3 pT = v3(pin(f[DG_LF_POS]), pin(f[DG_LF_POS + 1]), pin(f[DG_LF_POS + 2]));
+    const V3 ax = v3(pin(f[DG_LF_AXIS]), pin(f[DG_LF_AXIS + 1]), pin(f[DG_LF_AXIS + 2]));
+    V3 u, v; tangent_basis(ax, u, v);
+    const M3 Qi = {{u.x, v.x, ax.x, u.y, v.y, ax.y, u.z, v.z, ax.z}};
+    const M3 RTp = mul(transpose(Qprev), mul(RT, Qi)); const V3 pTp = tmul(Qprev, pT);
+#pragma unroll
+    for (int k = 0; k < 9; k++) cR[i][k] = RTp.m[k];
+    cP[i][0] = pTp.x; cP[i][1] = pTp.y; cP[i][2] = pTp.z;
+    Qprev = Qi; if (i == N - 1) Qee = Qi;
+  }
+  const V3 offp = tmul(Qee, off);
+  float nRest[N], nLo[N], nHi[N], nIrg[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { nRest[i] = pin(rest[i]); nLo[i] = pin(rest[N + i]); nHi[i] = pin(rest[2 * N + i]); nIrg[i] = pin(frcp(rest[3 * N + i])); }
+  const P3 b0 = p3(v3(R0.m[0], R0.m[3], R0.m[6])), b1 = p3(v3(R0.m[1], R0.m[4], R0.m[7])), b2 = p3(v3(R0.m[2], R0.m[5], R0.m[8])), bp = p3(p0);
+  P3 ow[N], aw[N], pe, e0, e1, e2;  // link origins, world joint axes; end-effector point and the columns of its (primed) rotation
+  auto fk = [&]() {
+    P3 c0 = b0, c1 = b1, c2 = b2, p = bp;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const float* T = cR[i];
+      p = colmul_acc(c0, c1, c2, cP[i][0], cP[i][1], cP[i][2], p);
+      const P3 C0 = colmul(c0, c1, c2, T[0], T[3], T[6]), C1 = colmul(c0, c1, c2, T[1], T[4], T[7]), C2 = colmul(c0, c1, c2, T[2], T[5], T[8]);
+      const float sn = __sinf(q[i]), cs = __cosf(q[i]);
+      P3 n0, n1;
+      n0.xy = fma2(C1.xy, sp2(sn), C0.xy * sp2(cs)); n0.z = fmaf(C1.z, sn, C0.z * cs);
+      n1.xy = fma2(C0.xy, sp2(-sn), C1.xy * sp2(cs)); n1.z = fmaf(C0.z, -sn, C1.z * cs);
+      c0 = n0; c1 = n1; c2 = C2; ow[i] = p; aw[i] = C2;
+    }
+    pe = colmul_acc(c0, c1, c2, offp.x, offp.y, offp.z, p); e0 = c0; e1 = c1; e2 = c2;
+  };
+  fk();
+  const V3 pe0 = v3(pe.xy.x, pe.xy.y, pe.z);
+  const V3 tp = pe0 + v3(act[0], act[1], act[2]);
+  M3 Tm = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};
+  if (ORN) {
+    const M3 Re = {{e0.xy.x, e1.xy.x, e2.xy.x, e0.xy.y, e1.xy.y, e2.xy.y, e0.z, e1.z, e2.z}};
+    const Q4 qe0 = qnormalize(qmul(qfrom_mat(mul(Re, transpose(Qee))), qoff));
+    const Q4 tq = qmul(qe0, qfrom_euler(act[3], act[4], act[5]));
+    Tm = mul(mul(qmat(tq), transpose(qmat(qoff))), Qee);
+  }
+  const float lam2 = sc.HF[DG_HF_IK_LAMBDA_SQ], maxang = sc.HF[DG_HF_IK_MAX_ANGLE], g0 = sc.HF[DG_HF_IK_NULL_REST_GAIN], g1 = sc.HF[DG_HF_IK_NULL_LIMIT_GAIN];
+  const float resid = sc.HF[DG_HF_IK_RESIDUAL];
+  bool live = live_lane; int iters = 0;
+  for (int it = 0; it < sc.ik_iters; it++) {
+    if (it > 0) fk();
+    const v2f epxy = v2f{tp.x, tp.y} - pe.xy; const float epz = tp.z - pe.z;
+    if (it > 0 && fsqrt(epxy.x * epxy.x + epxy.y * epxy.y + epz * epz) < resid) live = false;
+    if (!__any(live)) break;
+    iters += live ? 1 : 0;
+    // task-space vectors in the order [lin.x lin.y | ang.x ang.y | lin.z ang.z]
+    v2f dA = epxy, dB = {0.f, 0.f}, dC = {epz, 0.f};
+    if (ORN) {
+      // M = Tm Re^T, row i of M = sum_k (column k of Re) Tm[i][k]; rotation vector from its trace and antisymmetric part
+      const P3 M0 = colmul(e0, e1, e2, Tm.m[0], Tm.m[1], Tm.m[2]), M1 = colmul(e0, e1, e2, Tm.m[3], Tm.m[4], Tm.m[5]), M2 = colmul(e0, e1, e2, Tm.m[6], Tm.m[7], Tm.m[8]);
+      const float tr = M0.xy.x + M1.xy.y + M2.z;
+      const float sx = 0.5f * (M2.xy.y - M1.z), sy = 0.5f * (M0.z - M2.xy.x), sz = 0.5f * (M1.xy.x - M0.xy.y);
+      const float sn = fsqrt(sx * sx + sy * sy + sz * sz), an = atan2f(sn, 0.5f * (tr - 1.0f)), k = sn > 1e-12f ? fdiv(an, sn) : 1.0f;
+      dB = v2f{sx * k, sy * k}; dC.y = sz * k;
+    }
+    // normal matrix U = J J^T + lambda^2 I in packed rows (row r: its entries left of and on the diagonal), J v0, the columns kept
+    float U00 = 0.f, U22 = 0.f, U44 = 0.f; v2f U1 = {0.f, 0.f}, U2a = U1, U3a = U1, U3b = U1, U4a = U1, U4b = U1, U5a = U1, U5b = U1, U5c = U1;
+    v2f JvA = U1, JvB = U1, JvC = U1, cA[N], cB[N], cC[N]; float v0[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float v = g0 * (nRest[i] - q[i]);
+      if (q[i] > nHi[i]) v += g1 * (nHi[i] - q[i]) * nIrg[i];
+      if (q[i] < nLo[i]) v += g1 * (nLo[i] - q[i]) * nIrg[i];
+      v0[i] = v;
+      // column i: linear part axis x (pe - origin), angular part the axis
+      const v2f dxy = pe.xy - ow[i].xy; const float dz = pe.z - ow[i].z; const P3& a = aw[i];
+      const v2f pa = {a.xy.y, -a.xy.x}, pd = {dxy.y, -dxy.x};   // (v.y, -v.x)
+      const v2f A = fma2(pa, sp2(dz), -(pd * sp2(a.z)));         // (a x d).xy = d.z perp(a.xy) - a.z perp(d.xy)
+      const float lz = a.xy.x * dxy.y - a.xy.y * dxy.x;
+      const v2f B = a.xy, C = {lz, a.z};
+      cA[i] = A; cB[i] = B; cC[i] = C;
+      JvA = fma2(A, sp2(v), JvA); JvB = fma2(B, sp2(v), JvB); JvC = fma2(C, sp2(v), JvC);
+      U00 = fmaf(A.x, A.x, U00); U1 = fma2(A, sp2(A.y), U1);
+      U2a = fma2(A, sp2(B.x), U2a); U22 = fmaf(B.x, B.x, U22);
+      U3a = fma2(A, sp2(B.y), U3a); U3b = fma2(B, sp2(B.y), U3b);
+      U4a = fma2(A, sp2(C.x), U4a); U4b = fma2(B, sp2(C.x), U4b); U44 = fmaf(C.x, C.x, U44);
+      U5a = fma2(A, sp2(C.y), U5a); U5b = fma2(B, sp2(C.y), U5b); U5c = fma2(C, sp2(C.y), U5c);
+    }
+    float U[21] = {U00 + lam2, U1.x, U1.y + lam2, U2a.x, U2a.y, U22 + lam2, U3a.x, U3a.y, U3b.x, U3b.y + lam2,
+                   U4a.x, U4a.y, U4b.x, U4b.y, U44 + lam2, U5a.x, U5a.y, U5b.x, U5b.y, U5c.x, U5c.y + lam2};
+    chol6(U);
+    const float rhs[6] = {dA.x - JvA.x, dA.y - JvA.y, dB.x - JvB.x, dB.y - JvB.y, dC.x - JvC.x, dC.y - JvC.y};
+    float y[6]; chol6_solve(U, rhs, y);
+    const v2f yA = {y[0], y[1]}, yB = {y[2], y[3]}, yC = {y[4], y[5]};
+    float dth[N], mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const v2f t = fma2(cC[i], yC, fma2(cB[i], yB, cA[i] * yA));
+      dth[i] = (t.x + t.y) + v0[i]; mx = fmaxf(mx, fabsf(dth[i]));
+    }
+    const float scl = mx > maxang ? fdiv(maxang, mx) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < N; i++) if (live) q[i] += scl * dth[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) qout[i] = q[i];
+  return iters;
+}
+
 // p.applyExternalForce / p.applyExternalTorque on frame `fr` (global frame index, -1: base) of body b: a force `f` acting at
 // `pos` and a torque `t`, all three in the frame's axes with `pos` relative to its origin (link_frame) or in world
 // coordinates, added to what the body feels during the NEXT simulation step only: the base's external wrench (state:
@@ -2641,8 +2867,10 @@ DGD void run_update_ops(const Lane<LANES>& ln, const float* act_row, uint64_t ma
       if (oi[DG_OI_FLAGS] & DG_IK_DEV_CHAIN) {
         float qs[6]; int ik_it;
         const int fl = oi[DG_OI_FLAGS];
-        if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE) && (fl & DG_IK_USE_ORIENTATION)) ik_it = run_ik_chain<LANES, 6, true, true, true>(ln, op, av, ln.valid, qs);
-        else if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE)) ik_it = run_ik_chain<LANES, 6, true, true, false>(ln, op, av, ln.valid, qs);
+        // (six revolute joints, null-space lists: the packed solve; DG_NO_FULL_IK at world creation keeps such an arm on the general
+        // register-resident form below -- the alternative the tests compare it with)
+        if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE) && (fl & DG_IK_USE_ORIENTATION)) ik_it = run_ik_chain_pk<LANES, true>(ln, op, av, ln.valid, qs);
+        else if ((fl & DG_IK_DEV_FULL) && (fl & DG_IK_NULLSPACE)) ik_it = run_ik_chain_pk<LANES, false>(ln, op, av, ln.valid, qs);
         else ik_it = run_ik_chain<LANES, 6>(ln, op, av, ln.valid, qs);
         if (diag && ln.valid && ik_ord < DG_DIAG_N_IK) diag[(size_t)DG_DIAG_STRIDE * ln.env + DG_DIAG_IK_ITERS + ik_ord] = ik_it;
         const int first = ln.bi(b)[DG_BI_FIRST_LINK];

@@ -335,9 +335,9 @@ def test_limit_guess_in_the_dense_sweep_forms(env_vars, lanes):
     worst = 0.0
     for i in range(60):
         gpu.sim.step(gpu._all_slots, act.to(gpu.device)); cpu.sim.step(cpu._all_slots, act); off.sim.step(off._all_slots, act)
-        # (the joints reach their limits after ~40 steps; around step 14 the cart lands, a transient in which even the oracle's own
-        # fp32 and fp64 builds are 7e-2 apart for a step or two -- tools: oracle_backend.flavour('f32') -- before closing in again)
-        if i >= 40:
+        # (the pole joints swing at +-18 rad/s between steps 12 and 40 -- fp32 against fp64 is 7e-2 apart on those rates for a step or
+        # two, the oracle's own fp32 build included, and below 8e-4 from step 41 on -- and are pinned to their limits from ~step 42)
+        if i >= 45:
             worst = max(worst, float((gpu.sim.obs.cpu() - cpu.sim.obs).abs().max()))
     assert worst < 2e-3, worst
     assert np.abs(phys_state(gpu) - phys_state(cpu)).max() < 5 * CART_STATE_TOL
@@ -588,7 +588,10 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('ur_ik', {'DG_NO_EARLY_DYNAMICS': '1'}, 64, 30, 5e-4),
     ('ur_ik', {'DG_NO_COLLIDE_WAVE': '1'}, 64, 30, 5e-4),    # main wave runs the narrow phase itself
     ('ur_ik', {'DG_NO_SPLIT_SWEEPS': '1'}, 64, 30, 5e-4),    # main wave sweeps both arms
+    ('ur_ik', {'DG_NO_FULL_IK': '1'}, 64, 30, 5e-4),         # the general register-resident IK instead of the packed six-axis solve
     ('touching', {'DG_NO_COLLIDE_SPLIT': '1'}, 64, 30, 5e-3),  # one narrow-phase wavefront instead of two (contacts present)
+    ('touching', {'DG_NO_CHAIN_ROWS': '1'}, 64, 30, 5e-3),     # contact rows of arm-arm contacts pair by pair (build_contact_rows) instead of per lane
+    ('touching_ik', {'DG_NO_CHAIN_ROWS': '1'}, 64, 30, 5e-3),
     ('touching', {'DG_NO_EARLY_DYNAMICS': '1'}, 64, 30, 5e-3),  # both substeps merge two contact lists
 ])
 def test_alternative_workspace_modes(name, env_vars, lanes, steps, tol):

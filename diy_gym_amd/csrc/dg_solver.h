@@ -667,7 +667,14 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
     pin[i] = plo ? -1.f : (phi ? 1.f : 0.f);
     rhs[i] = (plo ? lb0[i] : (phi ? -lb1[i] : b[i])) * sd[i];
   }
-  chol_unit_solve<N>([&](int i, int j) { return M[i * N + j] * sd[i] * sd[j]; }, rhs, x);
+  // the scaled matrix (unit diagonal), strictly-lower triangle packed: every round of the active set below works on it
+  float A[N * (N - 1) / 2 + 1];
+#pragma unroll
+  for (int i = 1; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) A[i * (i - 1) / 2 + j] = M[i * N + j] * sd[i] * sd[j];
+  auto a_of = [&](int i, int j) { return i > j ? A[i * (i - 1) / 2 + j] : A[j * (j - 1) / 2 + i]; };  // (i != j)
+  chol_unit_solve<N>([&](int i, int j) { return A[i * (i - 1) / 2 + j]; }, rhs, x);
   // Primal-dual active set, at most DG_MOTOR_GUESS_ROUNDS rounds: the rows beyond their bounds are held there and the others
   // solved again; the sets are then re-read from x + residual (the diagonal of the scaled system is 1) -- a held row whose
   // residual pulls it back inside is released, a free row that left its bounds is held -- until no lane's sets change.  The
@@ -691,18 +698,18 @@ DGD void chain_motor_guess_n(const float* M, const float* b, const float* smax, 
       for (int i = 0; i < N; i++) {
         float t = held[i] ? val[i] : rhs[i];
 #pragma unroll
-        for (int j = 0; j < N; j++) if (j != i) t -= (!held[i] && held[j]) ? M[i * N + j] * sd[i] * sd[j] * val[j] : 0.f;
+        for (int j = 0; j < N; j++) if (j != i) t -= (!held[i] && held[j]) ? a_of(i, j) * val[j] : 0.f;
         r2[i] = t;
       }
-      chol_unit_solve<N>([&](int i, int j) { return (held[i] || held[j]) ? 0.f : M[i * N + j] * sd[i] * sd[j]; }, r2, x2);
+      chol_unit_solve<N>([&](int i, int j) { return (held[i] || held[j]) ? 0.f : A[i * (i - 1) / 2 + j]; }, r2, x2);
       bool changed = false;
 #pragma unroll
       for (int i = 0; i < N; i++) x[i] = any ? x2[i] : x[i];   // (a lane without a held row keeps its first solution, bit for bit)
 #pragma unroll
       for (int i = 0; i < N; i++) {
-        float y = x[i] + rhs[i];
+        float y = rhs[i];  // x_i + residual_i = rhs_i - sum_{j != i} A_ij x_j  (unit diagonal)
 #pragma unroll
-        for (int j = 0; j < N; j++) y -= (j == i ? 1.f : M[i * N + j] * sd[i] * sd[j]) * x[j];
+        for (int j = 0; j < N; j++) if (j != i) y -= a_of(i, j) * x[j];
         const bool nu = any && y > bhi[i], nd = any && y < blo[i]; changed = changed || nu != up[i] || nd != dn[i]; up[i] = nu; dn[i] = nd;
       }
       if (!__any(changed)) break;

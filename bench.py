@@ -280,7 +280,10 @@ LEGS = {
     'r2d2_maze': ('r2d2_maze', None, None, 0.0, 200),
     'drone_pilot': ('drone_pilot', None, None, 0.0, 304),
     'from_the_readme': ('from_the_readme', None, None, 0.0, 104),
+    # not part of 'all' (no BASELINE config): the arm + gripper tree of SURVEY 8f N2, `--legs ur5_child_gripper`
+    'ur5_child_gripper': ('ur5_child_gripper', None, None, 0.0, 200),
 }
+DEFAULT_LEGS = ('in_contact', 'mixed', 'reference_solver_settings', 'r2d2_maze', 'drone_pilot', 'from_the_readme')
 CONFIG_LEGS = ('r2d2_maze', 'drone_pilot', 'from_the_readme')
 KERNEL_OF = {'from_the_readme': 'render_kernel'}   # dominant kernel quoted in a leg's roofline (default: the step kernel)
 
@@ -481,7 +484,7 @@ def make_leg(name, device, rank=0, envs=None, auto_reset=True):
 def leg_names(args):
     if args.legs == 'none' or args.gpus > 1 or args.workload != 'ur_high_5' or args.envs_per_gpu not in (None, 16384):
         return []   # the extra legs belong to the default headline run on one GPU
-    return list(LEGS) if args.legs == 'all' else [n for n in args.legs.split(',') if n in LEGS]
+    return list(DEFAULT_LEGS) if args.legs == 'all' else [n for n in args.legs.split(',') if n in LEGS]
 
 
 # ----------------------------------------------------------------------------------------------- profiled child
@@ -793,7 +796,7 @@ def run_rank(args, argv):
                 rec = measure_leg(name, device, args, pmc.get(name) if pmc else None)
             except Exception as exc:  # pragma: no cover
                 rec = {'error': repr(exc)}
-            if name in CONFIG_LEGS:
+            if name in CONFIG_LEGS or name not in DEFAULT_LEGS:
                 out.setdefault('configs', {})[name] = rec
             else:
                 out[name] = rec

@@ -2150,8 +2150,11 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
       else iters_done = pgs_dense_sliced_global<LANES, 32, PROF>(ln, smem, gws, ncont, wave_max_cont, limit_rows, prof);
     }
   } else if (PAR && split_now) {
+    prof.stamp(PS_PGS_MOTOR);    // (stamped build, split sweeps: [pgs_motor] = the wait at Bq for the helper's rows,
     pgs_reg_halves(ln, 0);
+    prof.stamp(PS_PGS_LIMIT);    //  [pgs_limit] = loads + motor guess + sweeps of this wavefront,
     __syncthreads();  // Bs: both wavefronts' velocity changes and impulses are in LDS
+    prof.stamp(PS_PGS_CONTACT);  //  [pgs_contact] = the wait at Bs for the other wavefront's sweeps)
     iters_done = (int)ln.L(split_slots(sc));
   } else if (primary) {
   bool live = ln.valid;

@@ -158,7 +158,11 @@ enum { RLI_TYPE = 0 /* -1: dropped */, RLI_SHAPE, RLI_PLANE_OFF, RLI_NP, RLI_PT_
 // was tried: the face planes of a thinned hull reach a hair beyond the sphere around its points, and single silhouette pixels
 // then differ from the brute-force picture.)
 DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int np, RayHit (&h)[2], int sh) {
-  float tn[2] = {-3.0e38f, -3.0e38f}, tf[2] = {3.0e38f, 3.0e38f}; int kn[2] = {0, 0}; bool miss[2] = {np == 0, np == 0};
+  // Crossing depths are kept as FRACTIONS while the faces are scanned -- the latest entry as sn / qn (s = the eye's distance from
+  // the face > 0, q = -(n . d) > 0), the earliest exit as af / df -- and compared by cross-multiplication: the loop then holds no
+  // reciprocal (a quarter-rate instruction, ~4 issue slots of the ~14 a face cost per ray); the two depths a ray needs are
+  // divided out once, after the loops, and are the bits the division per face gave (-s rcp(den) = s rcp(-den)).
+  float sn[2] = {-1.f, -1.f}, qn[2] = {1.f, 1.f}, af[2] = {3.0e38f, 3.0e38f}, df[2] = {1.f, 1.f}; int kn[2] = {0, 0}; bool miss[2] = {np == 0, np == 0};
   // (four faces per round, their LDS reads issued together: one face at a time the loop waits a whole LDS round trip per face)
   for (int k0 = 0; k0 < nout; k0 += 4) {
     float f[4][4];
@@ -170,17 +174,18 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
     for (int j = 0; j < 4; j++) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
-        const bool front = den <= -1e-30f;  // approached from outside, and not (numerically) parallel
+        const float q = -(f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z);
+        const bool front = q >= 1e-30f;  // approached from outside, and not (numerically) parallel
         miss[u] = miss[u] || !front;
-        const bool later = front && t > tn[u]; tn[u] = later ? t : tn[u]; kn[u] = later ? k0 + j : kn[u];  // (a repeated face never is `later`: kn < nout)
+        const bool later = front && f[j][3] * qn[u] > sn[u] * q;  // s / q > sn / qn, both denominators positive
+        sn[u] = later ? f[j][3] : sn[u]; qn[u] = later ? q : qn[u]; kn[u] = later ? k0 + j : kn[u];  // (a repeated face never is `later`: kn < nout)
       }
     }
     if (!__any(!miss[0] || !miss[1])) return;
   }
-  bool alive[2];
+  bool alive[2]; float tn[2];
 #pragma unroll
-  for (int u = 0; u < 2; u++) alive[u] = !miss[u] && tn[u] >= h[u].tmin && tn[u] < h[u].t;
+  for (int u = 0; u < 2; u++) { tn[u] = -sn[u] * __frcp_rn(-qn[u]); alive[u] = !miss[u] && tn[u] >= h[u].tmin && tn[u] < h[u].t; }
   if (!__any(alive[0] || alive[1])) return;
   for (int k0 = nout; k0 < np; k0 += 4) {
     float f[4][4];
@@ -190,13 +195,17 @@ DGD void ray_hull_world2(const V3 (&d)[2], const float (*pl)[4], int nout, int n
     for (int j = 0; j < 4; j++) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, t = -f[j][3] * __frcp_rn(den);
-        tf[u] = den >= 1e-30f ? fminf(tf[u], t) : tf[u];
+        const float den = f[j][0] * d[u].x + f[j][1] * d[u].y + f[j][2] * d[u].z, a = -f[j][3];
+        const bool earlier = den >= 1e-30f && a * df[u] < af[u] * den;  // a / den < af / df
+        af[u] = earlier ? a : af[u]; df[u] = earlier ? den : df[u];
       }
     }
   }
 #pragma unroll
-  for (int u = 0; u < 2; u++) if (alive[u] && !(tn[u] > tf[u])) { h[u].t = tn[u]; h[u].n = v3(pl[kn[u]][0], pl[kn[u]][1], pl[kn[u]][2]); h[u].shape = sh; }
+  for (int u = 0; u < 2; u++) {
+    const float tf = af[u] * __frcp_rn(df[u]);
+    if (alive[u] && !(tn[u] > tf)) { h[u].t = tn[u]; h[u].n = v3(pl[kn[u]][0], pl[kn[u]][1], pl[kn[u]][2]); h[u].shape = sh; }
+  }
 }
 // colour of a pixel whose ray (direction d) hit at h: Lambert factor x the shape's colour / procedural texture; e = rotation (9),
 // position (3) and texture (DG_TX_*) of the shape that was hit

@@ -1872,6 +1872,23 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
   const int mo0 = half ? ln.pll(f1)[PLL_MROW] : ln.pll(f0)[PLL_MROW];
   auto W = [&](int slot) -> float& { return col[slot * 64]; };
   float rM[RN * RN], rdv[RN], rb[RN], racc[RN], rdi[RN], rdg[RN], smax[RN], lb[2][RN], la[2][RN]; bool any_limit = false;
+  if (n0 == RN && n1 == RN) {
+    // both arms have all six joints (every pair of 6-axis arms): no per-lane row count, so every slot is a compile-time offset
+    // from two per-lane bases (the arm's M^-1 block, its first motor / limit row block) -- one ds_read per value, no address
+    // arithmetic, no masks (the general form below spends ~560 instructions on these 72 values)
+    const float* const cm = col + (size_t)mvo * 64; const float* const cr = col + (size_t)mo0 * 64;
+#pragma unroll
+    for (int i = 0; i < RN; i++) {
+      const float mf0 = ln.mt.v[3 * (f0 + i) + 2], mf1 = ln.mt.v[3 * (f1 + i) + 2], maxf = half ? mf1 : mf0;
+      smax[i] = maxf < 0.f ? -maxf : maxf * sc.hm;
+#pragma unroll
+      for (int c = 0; c < RN; c++) rM[i * RN + c] = cm[(i * RN + c) * 64];
+      rb[i] = cr[(i * MR_STRIDE + MR_B) * 64]; rdg[i] = rM[i * RN + i]; rdi[i] = 1.0f / rdg[i];
+      lb[0][i] = cr[(i * MR_STRIDE + MR_LO_B) * 64]; la[0][i] = cr[(i * MR_STRIDE + MR_LO_ACC) * 64];
+      lb[1][i] = cr[(i * MR_STRIDE + MR_HI_B) * 64]; la[1][i] = cr[(i * MR_STRIDE + MR_HI_ACC) * 64];
+      rdv[i] = 0.f; racc[i] = 0.f;
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < RN; i++) {
     const bool has = i < n; const int ic = has ? i : 0;  // absent rows: clamped address, zeroed value
@@ -1886,6 +1903,7 @@ DGD void pgs_reg_halves(const Lane<LANES>& ln, int wave) {
     rdv[i] = 0.f; racc[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < RN; c++) { const bool hc = has && c < n; const float m = W(mvo + ic * n + (c < n ? c : 0)); rM[i * RN + c] = hc ? m : 0.f; }
+  }
   }
   if (sc.HF[DG_HF_MOTOR_GUESS] > 0.f) chain_motor_guess(rM, rb, smax, racc, rdv, limit_ptol(sc), lb[0], la[0], lb[1], la[1]);  // the sweeps start next to their fixed point (limit rows of pinned joints included)
   // limit rows some lane of the wavefront has active (the flags cannot change during the sweeps): bit 2 i + side.  Rows

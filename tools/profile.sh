@@ -1,15 +1,16 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun): bash tools/profile.sh <tag>   (tag: r3, ...).  Kernel trace + stats per workload, then the HBM / SQ
+# Profiling recipe (run on the GPU box through gpurun): bash tools/profile.sh <tag>   (tag: r4, ...).  (`--legs none`: the headline loop alone, so that a
+# kernel's row in kernel_stats.csv is that loop's launches and nothing else.)  Kernel trace + stats per workload, then the HBM / SQ
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; never --pmc together with a trace).
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 trace() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python3 bench.py "$@" --no-pmc --no-cpu-baseline --no-api > $OUT/bench_$name.json 2> $OUT/trace_$name.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python3 bench.py "$@" --no-pmc --no-cpu-baseline --no-api --legs none > $OUT/bench_$name.json 2> $OUT/trace_$name.err
   echo "trace $name rc=$?"
 }
 trace ur_high_5 --steps 104 --warmup 20 --age-steps 0
@@ -17,7 +18,7 @@ trace from_the_readme --workload from_the_readme --steps 40 --warmup 30 --age-st
 trace r2d2_maze --workload r2d2_maze --steps 40 --warmup 20 --age-steps 0
 pmc() {  # name, counters..., then -- bench args
   local name=$1; shift; local counters=(); while [ "$1" != "--" ]; do counters+=("$1"); shift; done; shift
-  rocprofv3 --pmc "${counters[@]}" --output-format csv -d $OUT/pmc_$name -- python3 bench.py "$@" --no-pmc --no-cpu-baseline --no-api --age-steps 0 --inner > /dev/null 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc "${counters[@]}" --output-format csv -d $OUT/pmc_$name -- python3 bench.py "$@" --no-pmc --no-cpu-baseline --no-api --age-steps 0 --legs none --inner > /dev/null 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?"
 }
 pmc ur_fetch FETCH_SIZE -- --steps 40 --warmup 10

@@ -5,7 +5,7 @@ of the same commands.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 10
 FETCH_SIZE counts half of a coalesced read -- MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
 src = os.path.join(ROOT, 'gpurun_out', 'prof_%s' % tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)

@@ -325,22 +325,35 @@ DGD void tangent_basis(V3 n, V3& t1, V3& t2) {
 // the velocity change those starting impulses amount to before their first iteration.
 // Index of the cached entry with this key, -1 if there is none (or no cache).  Called under divergence: the loop bound
 // is uniform over the ACTIVE lanes, the key loads are independent of each other.
+// (The cache lives in the state, i.e. in global memory, and a lone wavefront pays a whole round trip per DEPENDENT load: the keys
+// are read eight at a time with the count, their loads issued together, and a contact's three impulses together -- two round trips
+// per contact instead of count + 4.  With one load per entry behind an early exit this search was ~40 % of the row construction of
+// every scene with resting contacts: marbles 105 k of 335 k cycles per step in `rows`, from_the_readme (25 contacts: 25 x 25
+// dependent loads per substep) 421 k of 2.36 M.)
 template <int LANES>
 DGD int warm_find(const Lane<LANES>& ln, float key) {
   const DevScene& sc = ln.sc; if (sc.warm_off < 0) return -1;
-  const int np = (int)ln.S(sc.warm_off); int found = -1;
-  for (int j = 0; j < sc.max_contacts; j++) {
-    if (!__any(j < np)) break;
-    const float kj = ln.S(sc.warm_off + 1 + j * DG_WS_STRIDE + DG_WS_KEY);
-    if (j < np && kj == key && found < 0) found = j;
+  constexpr int CH = 8;
+  int found = -1, np = 0;
+  for (int j0 = 0; j0 < sc.max_contacts; j0 += CH) {
+    if (j0 > 0 && !__any(j0 < np)) break;
+    float kj[CH]; const float npf = ln.S(sc.warm_off);
+#pragma unroll
+    for (int t = 0; t < CH; t++) kj[t] = ln.S(sc.warm_off + 1 + min(j0 + t, sc.max_contacts - 1) * DG_WS_STRIDE + DG_WS_KEY);
+    np = (int)npf;
+#pragma unroll
+    for (int t = 0; t < CH; t++) if (j0 + t < np && kj[t] == key && found < 0) found = j0 + t;
   }
   return found;
 }
+// the starting impulses of a contact's three rows (normal, t1, t2): factor x what the cached entry ended with, zero without one
 template <int LANES>
-DGD float warm_impulse(const Lane<LANES>& ln, int found, int d) {
-  const DevScene& sc = ln.sc;
-  const float fac = d == 0 ? sc.HF[DG_HF_WARMSTART] : sc.HF[DG_HF_WARMSTART_FRICTION];
-  return (found >= 0 && fac > 0.f) ? fac * ln.S(sc.warm_off + 1 + max(found, 0) * DG_WS_STRIDE + DG_WS_NORMAL + d) : 0.f;
+DGD void warm_impulses(const Lane<LANES>& ln, int found, float (&out)[3]) {
+  const DevScene& sc = ln.sc; out[0] = out[1] = out[2] = 0.f;
+  if (sc.warm_off < 0) return;
+  const int e = sc.warm_off + 1 + max(found, 0) * DG_WS_STRIDE + DG_WS_NORMAL;
+  const float v0 = ln.S(e), v1 = ln.S(e + 1), v2 = ln.S(e + 2), fn = sc.HF[DG_HF_WARMSTART], ft = sc.HF[DG_HF_WARMSTART_FRICTION];
+  out[0] = (found >= 0 && fn > 0.f) ? fn * v0 : 0.f; out[1] = (found >= 0 && ft > 0.f) ? ft * v1 : 0.f; out[2] = (found >= 0 && ft > 0.f) ? ft * v2 : 0.f;
 }
 // this substep's contacts and the impulses their rows ended with (every sweep form leaves them in the rows' `acc` slots)
 template <int LANES>
@@ -369,7 +382,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
   V3 t1, t2; tangent_basis(n, t1, t2);
   const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
   ln.L(co + CL_MU) = sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_A] * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[sc.PI[pair * DG_PI_STRIDE + DG_PI_B] * DG_SF_STRIDE + DG_SF_FRICTION];
-  const int wfound = warm_find(ln, ln.L(co + CL_KEY));
+  const int wfound = warm_find(ln, ln.L(co + CL_KEY)); float wimp[3]; warm_impulses(ln, wfound, wimp);
   for (int d = d_lo; d < d_hi; d++) {  // (lane-sliced callers give each lane of an env's group one direction)
     V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
     int ro = sc.tr_off + (3 * c + d) * rs; float diag = 0.f, jv = 0.f;
@@ -389,7 +402,7 @@ DGD void build_contact_rows(const Lane<LANES>& ln, int c, int pair, bool mine, b
     } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
     float b = -jv;
     if (d == 0) { float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-    ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag;
+    ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? (d == 0 ? wimp[0] : d == 1 ? wimp[1] : wimp[2]) : 0.f; ln.L(ro + tl + 2) = diag;
   }
 }
 
@@ -459,7 +472,7 @@ DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool ve
     V3 t1, t2; tangent_basis(n, t1, t2);
     const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
     ln.L(co + CL_MU) = sc.SF[pa * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[pb * DG_SF_STRIDE + DG_SF_FRICTION];
-    const int wfound = warm_find(ln, ln.L(co + CL_KEY));
+    const int wfound = warm_find(ln, ln.L(co + CL_KEY)); float wimp[3]; warm_impulses(ln, wfound, wimp);
     // one side: Jacobian of the body's base coordinates, response through the first six rows of its M^-1, J . v
     auto side = [&](int b, int flags, V3 d, int ro, float& diag, float& jv) {
       cip P = sc.PLB + b * PLB_STRIDE; const int nv = P[PLB_NV], mo = P[PLB_MINV], dvo = P[PLB_DV], g = dvo - sc.dv_base;
@@ -498,7 +511,7 @@ DGD bool build_contact_rows_base(const Lane<LANES>& ln, int c, bool has, bool ve
       } else { ln.L(co + CL_DVB) = 0.f; ln.L(co + CL_NVB) = 0.f; }
       float b = -jv;
       if (d == 0) { const float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag;
+      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag > 1e-18f ? (d == 0 ? wimp[0] : d == 1 ? wimp[1] : wimp[2]) : 0.f; ln.L(ro + tl + 2) = diag;
     }
   }
   return mine;
@@ -531,7 +544,7 @@ DGD bool build_contact_rows_chains(const Lane<LANES>& ln, int c, bool has) {
     V3 t1, t2; tangent_basis(n, t1, t2);
     const float h = sc.h, cerp = sc.HF[DG_HF_CONTACT_ERP], slop = sc.HF[DG_HF_LINEAR_SLOP];
     ln.L(co + CL_MU) = sc.SF[pa * DG_SF_STRIDE + DG_SF_FRICTION] * sc.SF[pb * DG_SF_STRIDE + DG_SF_FRICTION];
-    const int wfound = warm_find(ln, ln.L(co + CL_KEY));
+    const int wfound = warm_find(ln, ln.L(co + CL_KEY)); float wimp[3]; warm_impulses(ln, wfound, wimp);
     const V3 dirs[3] = {n, t1, t2};
     float diag[3] = {0.f, 0.f, 0.f}, jv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -579,7 +592,7 @@ DGD bool build_contact_rows_chains(const Lane<LANES>& ln, int c, bool has) {
     for (int d = 0; d < 3; d++) {
       const int ro = sc.tr_off + (3 * c + d) * rs; float b = -jv[d];
       if (d == 0) { const float pen = dist + slop; b += pen > 0.f ? -pen / h : -pen * cerp / h; }
-      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag[d] > 1e-18f ? warm_impulse(ln, wfound, d) : 0.f; ln.L(ro + tl + 2) = diag[d];
+      ln.L(ro + tl) = b; ln.L(ro + tl + 1) = diag[d] > 1e-18f ? wimp[d] : 0.f; ln.L(ro + tl + 2) = diag[d];
     }
   }
   return mine;

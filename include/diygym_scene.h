@@ -140,7 +140,9 @@ enum { DG_KF_POS_A = 0, DG_KF_QUAT_A = 3, DG_KF_POS_B = 7, DG_KF_QUAT_B = 10, DG
 #define DG_MAX_CONSTRAINTS 4
 
 #define DG_MOTOR_GUESS_REFINE 8
+#ifndef DG_MOTOR_GUESS_ROUNDS
 #define DG_MOTOR_GUESS_ROUNDS 4   /* rounds of the primal-dual active set in the motor guess (bodies of <= DG_MOTOR_GUESS_REFINE joints) */
+#endif
 #define DG_MOTOR_GUESS_MAX 10
 
 /* ---- per-env state prefix --------------------------------------------- */

@@ -199,10 +199,14 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
   if (lanes == 1 && !(sliceable && nt <= 32 && nl <= 32 && maxc <= 32)) lanes = 4;  // (DG_MAX_LANES=1 on a scene the mode does not hold)
   if (sliceable && lanes == 1) min_lanes = 1;  // (asked for with DG_MAX_LANES=1, or picked above)
   while (lanes >= min_lanes && total * lanes * 4 > LDS_MAX) lanes >>= 1;
-  // Latency: a big batch of a sliceable scene that still leaves most SIMDs without a wavefront (fewer than two
-  // workgroups per CU) is cut into smaller workgroups -- the sweeps get more lanes per env, the rest loses nothing.
+  // Latency: a big batch of a sliceable scene that still leaves SIMDs without a wavefront (fewer than FOUR one-wavefront
+  // workgroups per CU) is cut into smaller workgroups -- the sweeps get more lanes per env, the rest loses nothing, and a scene
+  // whose workspace lets only one or two workgroups of 32 envs share a CU's LDS gets three to eight of 16.  (Round 4: the target
+  // was two per CU; at 16 384 envs one wavefront on EVERY SIMD measured drone_pilot 0.195 -> 0.168 ms per step and the 12-joint
+  // UR5 + gripper tree 1.16 -> 0.84, marbles unchanged; two per SIMD -- 8 envs per wavefront -- is slower again for drone_pilot:
+  // profiles/r4_workspace_modes_16384.txt.)
   if (sliceable && lanes >= min_lanes && num_envs >= 2048 && !getenv("DG_MAX_LANES") && !getenv("DG_NO_NARROW_MODES")) {
-    while (lanes > 8 && (num_envs + lanes - 1) / lanes < 2 * w->cu_count) lanes >>= 1;
+    while (lanes > 8 && (num_envs + lanes - 1) / lanes < 4 * w->cu_count) lanes >>= 1;
   }
   if (lanes < min_lanes) {
     // too big for LDS even at 16 envs per wavefront: per-env scratch moves to a global buffer

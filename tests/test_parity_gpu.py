@@ -578,7 +578,9 @@ def test_from_the_readme_resting_contacts_60_steps():
     ('marbles', {'DG_MAX_LANES': '16'}, 16, 100, 2e-3),
     ('marbles', {'DG_MAX_LANES': '8'}, 8, 100, 2e-3),
     ('maze', {'DG_MAX_LANES': '8'}, 8, 25, 5e-3),           # the mode dg_world_create picks for r2d2_maze at BASELINE's 4 096 envs
-    ('drone', {'DG_MAX_LANES': '32'}, 32, 40, 2e-3),        # ... and for drone_pilot at 16 384 envs
+    ('drone', {'DG_MAX_LANES': '32'}, 32, 40, 2e-3),
+    ('drone', {'DG_MAX_LANES': '16'}, 16, 40, 2e-3),        # ... and for drone_pilot at 16 384 envs (one wavefront per SIMD)
+    ('child', {'DG_MAX_LANES': '16'}, 16, 30, 2e-3),        # ... and for the UR5 + gripper tree
     ('maze', {'DG_MAX_LANES': '4'}, 4, 25, 5e-3),
     ('constrained', {'DG_MAX_LANES': '32'}, 32, 30, 2e-3),   # fixed-constraint rows (generic sweeps) with the idle lanes of the narrow modes around them
     ('constrained', {'DG_MAX_LANES': '16'}, 16, 30, 2e-3),

@@ -195,9 +195,35 @@ struct Lane {
 
   // ------------------------------------------------------------ kinematics
   // world pose of every link of body b into the POSE region (q from state, or from LDS at qoff when qoff >= 0)
+  // The same for a fixed-base serial chain of at most six joints (PLB_CHAIN: every 6-axis arm): the parent's pose is carried in
+  // registers instead of being read back from the POSE slots it was just written to -- a lone wavefront pays that LDS round
+  // trip per link, and the whole call was ~10 k cycles for ~130 instructions of arithmetic per link (three calls per step: 14 %
+  // of step_kernel_par).  The carried rotation is what LR() would read back -- the two stored columns and their cross product
+  // -- so the poses are the same bits as the general loop's.
+  DGD void kinematics_chain(int b) const {
+    constexpr int N = 6;
+    cip B = bi(b); const int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
+    M3 R = qmat(base_quat(b)); V3 p = base_pos(b);
+    LRset(plb(b)[PLB_R0], R);
+    float qv[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) qv[j] = S(li(first + min(j, n - 1))[DG_LI_STATE_OFF] + DG_LS_Q);  // every load before the first transform
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      if (j < n) {
+        const int gl = first + j; M3 Rpc; V3 r; joint_xform(gl, qv[j], Rpc, r);
+        const M3 Rn = mul(R, Rpc); p = p + mul(R, r);
+        const int o = pll(gl)[PLL_POSE];
+        LRset(o, Rn); L3set(o + 6, p);
+        const V3 c0 = v3(Rn.m[0], Rn.m[3], Rn.m[6]), c1 = v3(Rn.m[1], Rn.m[4], Rn.m[7]), c2 = cross(c0, c1);
+        const M3 Rb = {{c0.x, c1.x, c2.x, c0.y, c1.y, c2.y, c0.z, c1.z, c2.z}}; R = Rb;
+      }
+    }
+  }
   DGD void kinematics(int b, int qoff = -1) const {
     cip B = bi(b);
     if (B[DG_BI_FLAGS] & DG_BODY_FROZEN) return;  // no per-env pose storage: its shapes are in world coordinates
+    if (qoff < 0 && plb(b)[PLB_CHAIN]) { kinematics_chain(b); return; }
     int first = B[DG_BI_FIRST_LINK], n = B[DG_BI_N_LINKS];
     M3 R0 = qmat(base_quat(b)); V3 p0 = base_pos(b);
     LRset(plb(b)[PLB_R0], R0);

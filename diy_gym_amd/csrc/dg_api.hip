@@ -162,6 +162,7 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
       if (par >= 0 && par != first + i - 1 && PLL[par * PLL_STRIDE + PLL_IAACC] < 0) { PLL[par * PLL_STRIDE + PLL_IAACC] = tr_off + need; need += 21; }
     }
     tr = std::max(tr, need);
+    if (n > 6) tr = std::max(tr, n * (n + 1) / 2 + 2 * n + 24);  // motor_guess_lds: packed factor + y + scaling, padded
   }
   // contact rows carry a second body's Jacobian / response only if some candidate pair has two moving bodies
   bool two_sided = ncons > 0;

@@ -772,13 +772,51 @@ DGD void motor_guess_small(const Lane<LANES>& ln, int b) {
     if (pinning) { ln.L(mo0 + i * MR_STRIDE + MR_LO_ACC) = la0[i]; ln.L(mo0 + i * MR_STRIDE + MR_HI_ACC) = la1[i]; }  // (starting impulses of pinned limit rows; every sweep form adds their velocity change)
   }
 }
+// LDS form for a body with more than six joints: packed Cholesky of the motorised block in the (free) transient region --
+// call it after the dynamics and before the contact rows are built there.  The motor table is uniform over the envs, so
+// every loop bound and every slot index is wave-uniform.
+template <int LANES>
+DGD void motor_guess_lds(const Lane<LANES>& ln, int b) {
+  const DevScene& sc = ln.sc; const float h = sc.h;
+  const int first = ln.bi(b)[DG_BI_FIRST_LINK], n = ln.bi(b)[DG_BI_N_LINKS], k0 = ln.fixed(b) ? 0 : 6;
+  const int nv = ln.plb(b)[PLB_NV], mvo = ln.plb(b)[PLB_MINV], mo0 = ln.pll(first)[PLL_MROW];
+  uint32_t motors = 0u; int k = 0;
+  for (int i = 0; i < n && i < 32; i++) { const float maxf = ln.mt.v[3 * (first + i) + 2]; if ((maxf < 0.f ? -maxf : maxf * sc.hm) > 0.f) { motors |= 1u << i; k++; } }
+  if (k == 0) return;
+  const bool all = k == n;  // (every joint has a motor: the usual case -- pybullet gives every joint one at load)
+  auto nth = [&](int a) { if (all) return a; uint32_t m = motors; for (int t = 0; t < a; t++) m &= m - 1; return __ffs((int)m) - 1; };  // a-th motorised joint
+  // workspace in the transient region: packed lower triangle (diagonal inverted, as chol6), then y / x, then the scaling
+  const int A = sc.tr_off, Y = A + k * (k + 1) / 2 + 8, S = Y + k + 8;
+  auto at = [&](int a, int c) { return A + a * (a + 1) / 2 + c; };
+  // symmetric scaling to a unit diagonal (finger and shoulder joints differ by 1e5 in M^-1; this is an fp32 factorisation)
+  for (int a = 0; a < k; a++) { const int ia = nth(a); ln.L(S + a) = __frsqrt_rn(fmaxf(ln.L(mvo + (k0 + ia) * nv + k0 + ia), 1e-30f)); }
+  for (int a = 0; a < k; a++) { const int ia = nth(a); const float sa = ln.L(S + a); for (int c = 0; c < a; c++) ln.L(at(a, c)) = ln.L(mvo + (k0 + ia) * nv + k0 + nth(c)) * sa * ln.L(S + c); ln.L(at(a, a)) = 1.f; }
+  for (int a = 0; a < k; a++) {
+    for (int c = 0; c <= a; c++) {
+      const float s = ln.L(at(a, c)) - lds_dot(ln, at(a, 0), at(c, 0), c);
+      ln.L(at(a, c)) = a == c ? __frsqrt_rn(fmaxf(s, 1e-6f)) : s * ln.L(at(c, c));  // (pivot floored at 1e-6 of its diagonal)
+    }
+  }
+  for (int a = 0; a < k; a++) ln.L(Y + a) = (ln.L(mo0 + nth(a) * MR_STRIDE + MR_B) * ln.L(S + a) - lds_dot(ln, at(a, 0), Y, a)) * ln.L(at(a, a));
+  for (int a = k - 1; a >= 0; a--) {
+    float s = ln.L(Y + a);
+    for (int t = a + 1; t < k; t++) s -= ln.L(at(t, a)) * ln.L(Y + t);
+    ln.L(Y + a) = s * ln.L(at(a, a));
+  }
+  bool fits = true;  // (a body of this size whose solution does not fit its bounds starts from zero, as without the guess)
+  for (int a = 0; a < k; a++) {
+    const int i = nth(a); const float maxf = ln.mt.v[3 * (first + i) + 2], lim = maxf < 0.f ? -maxf : maxf * sc.hm;
+    fits = fits && fabsf(ln.L(Y + a) * ln.L(S + a)) <= lim;
+  }
+  for (int a = 0; a < k; a++) ln.L(mo0 + nth(a) * MR_STRIDE + MR_ACC) = fits ? ln.L(Y + a) * ln.L(S + a) : 0.f;
+}
 template <int LANES>
 DGD void motor_guess(const Lane<LANES>& ln, int b) {
   if (!(ln.sc.HF[DG_HF_MOTOR_GUESS] > 0.f)) return;
   const int n = ln.bi(b)[DG_BI_N_LINKS]; if (n == 0) return;
-  // registers throughout: six, eight or twelve joints (round 3 factorised 9-10 joints in LDS, all or nothing, and had no guess for
-  // the 12-joint UR5 + gripper tree, whose zero-started sweeps were 38 % of its step); none beyond DG_MOTOR_GUESS_MAX
-  if (n <= 6) motor_guess_small<LANES, 6>(ln, b); else if (n <= 8) motor_guess_small<LANES, 8>(ln, b); else if (n <= DG_MOTOR_GUESS_MAX) motor_guess_small<LANES, DG_MOTOR_GUESS_MAX>(ln, b);
+  // (registers up to eight joints, with one active-set round; up to ten in LDS, all-or-nothing; none beyond: on a 12-joint
+  // tree under saturating position control the LDS factorisation cost 17 % of the step and the clamped guess two more sweeps)
+  if (n <= 6) motor_guess_small<LANES, 6>(ln, b); else if (n <= DG_MOTOR_GUESS_REFINE) motor_guess_small<LANES, DG_MOTOR_GUESS_REFINE>(ln, b); else if (n <= DG_MOTOR_GUESS_MAX) motor_guess_lds(ln, b);
 }
 
 // one PGS update of contact row at ro; returns the squared velocity residual

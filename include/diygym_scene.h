@@ -102,13 +102,12 @@ enum {
   DG_HF_MOTOR_GUESS,    /* > 0: the motor rows of a body start from the clamped solution of the body's unclamped motor system
                            (M^-1 restricted to the motorised joints) lambda = b instead of from zero.  By the body's joint
                            count n (what the factorisation costs on the device decides the cut-offs):
-                             n <= DG_MOTOR_GUESS_MAX: if a row of the solution exceeds its bound, a primal-dual active set of at
+                             n <= DG_MOTOR_GUESS_REFINE: if a row of the solution exceeds its bound, a primal-dual active set of at
                                   most DG_MOTOR_GUESS_ROUNDS rounds -- the rows beyond their bounds held there, the others solved
-                                  again, the sets re-read from x + residual -- then the clamp (round 3: one round up to 8 joints,
-                                  all-or-nothing for 9-10; round 4: the active set for every body of up to 12 joints, on the
-                                  device in registers throughout);
-                             beyond:                  no starting guess (zero) */
-  DG_HF_LIMIT_GUESS,    /* > 0 (with DG_HF_MOTOR_GUESS, bodies of n <= DG_MOTOR_GUESS_MAX joints): a joint whose motor target
+                                  again, the sets re-read from x + residual -- then the clamp (round 3: one round);
+                             n <= DG_MOTOR_GUESS_MAX:    if a row exceeds its bound the body starts from zero (as without);
+                             beyond:                     no starting guess (zero) */
+  DG_HF_LIMIT_GUESS,    /* > 0 (with DG_HF_MOTOR_GUESS, bodies of n <= DG_MOTOR_GUESS_REFINE joints): a joint whose motor target
                            lies BEYOND an active joint-limit row (target velocity b_m above what the upper-limit row allows, or
                            below what the lower-limit row demands) enters the guess as ONE unknown -- the joint's total impulse
                            with the limit row's velocity as its right-hand side -- and starts with its motor saturated into the
@@ -140,10 +139,11 @@ enum { DG_KI_BODY_A = 0, DG_KI_LINK_A /* global link index or -1 */, DG_KI_BODY_
 enum { DG_KF_POS_A = 0, DG_KF_QUAT_A = 3, DG_KF_POS_B = 7, DG_KF_QUAT_B = 10, DG_KF_MAX_FORCE = 14, DG_KF_STRIDE = 16 };
 #define DG_MAX_CONSTRAINTS 4
 
+#define DG_MOTOR_GUESS_REFINE 8
 #ifndef DG_MOTOR_GUESS_ROUNDS
-#define DG_MOTOR_GUESS_ROUNDS 4   /* rounds of the primal-dual active set in the motor guess */
+#define DG_MOTOR_GUESS_ROUNDS 4   /* rounds of the primal-dual active set in the motor guess (bodies of <= DG_MOTOR_GUESS_REFINE joints) */
 #endif
-#define DG_MOTOR_GUESS_MAX 12   /* bodies with more joints start their motor rows from zero (the device holds the system in registers: 6, 8 or 12 joints) */
+#define DG_MOTOR_GUESS_MAX 10
 
 /* ---- per-env state prefix --------------------------------------------- */
 enum { DG_ST_STEP = 0 /* step_counter (reference diy_gym.py:139,206) */, DG_ST_EPISODE /* resets so far (RNG stream) */,

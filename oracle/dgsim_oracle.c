@@ -872,7 +872,7 @@ static void substep(dgo_world* w, int env, int last) {
       for (int j = 0; j < k; j++) sc_[j] = 1.0 / sqrt(rows[idx[j]].RA[6 + dof[j]]);
       for (int j = 0; j < k; j++) {
         real target = rows[idx[j]].b; pin[j] = 0; lrow[j] = -1;
-        if (pinning)
+        if (pinning && ws->n <= DG_MOTOR_GUESS_REFINE)
           for (int r = 0; r < nr; r++) { /* the joint's active limit rows: JA = +-e_dof, b = the velocity the row demands along JA */
             const Row* q = &rows[r]; if (q->body_a != b || q->motor_link >= 0 || q->limit_dof != dof[j]) continue;
             const real sg = q->limit_sign, vlim = sg * q->b; /* lower (sg = +1): dv >= vlim; upper (sg = -1): dv <= vlim */
@@ -889,6 +889,7 @@ static void substep(dgo_world* w, int env, int last) {
         blo[j] = pin[j] > 0 ? -HUGE_R : r->lo / sc_[j]; bhi[j] = pin[j] < 0 ? HUGE_R : r->hi / sc_[j];
         up[j] = x[j] > bhi[j]; dn[j] = x[j] < blo[j]; held[j] = up[j] || dn[j]; any |= held[j];
       }
+      if (any && ws->n > DG_MOTOR_GUESS_REFINE) continue; /* a bigger body whose solution does not fit its bounds: zero start */
       /* Primal-dual active set (Hintermueller, Ito, Kunisch 2002 for box-constrained problems with an M-matrix-like operator):
        * rows beyond their bounds are held there and the others solved again; then the sets are re-read from x + residual --
        * a held row whose residual pulls it back inside is released, a free row that left its bounds is held -- until the sets

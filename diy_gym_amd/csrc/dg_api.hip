@@ -58,13 +58,14 @@ struct dg_world {
   bool par = false;  // step runs as two wavefronts per workgroup (helper wave)
   bool no_par_reset = false;  // DG_NO_PAR_RESET: masked resets through reset_kernel<64> (one wavefront, generic solver)
   float* d_gws = nullptr;  // global scratch when the scene does not fit LDS (lanes == 0)
+  float* d_hull_ws = nullptr;  // polytope workspace of the hull-hull narrow phase (dg_hull.h), one block per wavefront of the step grid
   int cu_count = 1;     // multiProcessorCount of `device`, read once in dg_world_create
   int render_diag = 0;  // DG_RENDER_NO_CULL / DG_RENDER_DIAG at creation (diagnostics), dg_world_set_render_diag later
   int render_wpe = 2;   // wavefronts per SIMD of the render kernel's build (DG_RENDER_WPE=3: the spilling build)
   int ncam = 0; float* d_render_table = nullptr; cip d_CI = nullptr; cfp d_CF = nullptr, d_PLN = nullptr;
   ~dg_world() {  // also the clean-up of a dg_world_create that failed half way
     DeviceGuard g(device);
-    (void)hipFree(d_gws); (void)hipFree(d_render_table); (void)hipFree(d_blob_i); (void)hipFree(d_blob_f); (void)hipFree(d_plan); (void)hipFree(d_init);
+    (void)hipFree(d_gws); (void)hipFree(d_hull_ws); (void)hipFree(d_render_table); (void)hipFree(d_blob_i); (void)hipFree(d_blob_f); (void)hipFree(d_plan); (void)hipFree(d_init);
   }
 };
 
@@ -332,6 +333,16 @@ int32_t dg_world_create(const int32_t* I, int64_t n_i, const double* F, int64_t 
     }
   }
   w->par = sc.helper_body >= 0; w->no_par_reset = getenv("DG_NO_PAR_RESET") != nullptr;
+  // polytope workspace of the hull-hull narrow phase: only worlds that collide two hulls
+  { bool hull_pairs = false; const int32_t* PIh = I + I[DG_H_OFF_PAIR_I]; const int32_t* SIh = I + I[DG_H_OFF_SHAPE_I];
+    for (int p = 0; p < I[DG_H_N_PAIRS] && !hull_pairs; p++)
+      hull_pairs = SIh[PIh[p * DG_PI_STRIDE + DG_PI_A] * DG_SI_STRIDE + DG_SI_TYPE] == DG_SHAPE_POINTS && SIh[PIh[p * DG_PI_STRIDE + DG_PI_B] * DG_SI_STRIDE + DG_SI_TYPE] == DG_SHAPE_POINTS;
+    if (hull_pairs && F[DG_HF_HULL_CONTACTS] > 0) {
+      const int per = envs_per_wave(lanes); const size_t waves = (size_t)((num_envs + per - 1) / per) * (w->par ? 4 : 1);
+      HIP_TRY(hipMalloc((void**)&w->d_hull_ws, sizeof(float) * waves * (size_t)HH_WS_SLOTS * 64));
+    }
+    sc.hull_ws = w->d_hull_ws; }
+
   // third wavefront for the narrow phase: it uses the transient region as its shape cache while the other two run
   // dynamics, so every moving body must have the register-resident (transient-free) dynamics
   sc.coll_wave = 0;
@@ -536,6 +547,39 @@ int32_t dg_debug_render_counters(uint64_t* out16, int32_t reset) {
   HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_render_count), sizeof h));
   for (int k = 0; k < 16; k++) out16[k] = h[k];
   if (reset) { memset(h, 0, sizeof h); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_render_count), h, sizeof h)); }
+  return DG_OK;
+}
+
+// diagnostics: the hull-against-hull narrow phase (dg_hull.h) on its own, one pair of poses per lane -- tests/test_hull_contacts.py
+// compares it with the CPU checker and a brute-force Minkowski difference; host pointers; not part of the public header.
+// poses [n][24] = A: rotation (9, row-major), position (3); B: the same.  out [n][11] = witness on A, witness on B, normal from B
+// towards A, signed distance, 1 if the pair is nearer than max_dist (else the rest is undefined).
+__global__ __launch_bounds__(64) void hull_pair_kernel(cfp pts, int na, int nb, const float* poses, int n, float max_dist, float* out, float* ws) {
+  const int i = blockIdx.x * 64 + threadIdx.x; const bool have = i < n; const float* p = poses + 24 * (size_t)(have ? i : n - 1);
+  HullPairD h; h.pa = pts; h.na = na; h.pb = pts + 3 * na; h.nb = nb;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { h.RA.m[k] = p[k]; h.RB.m[k] = p[12 + k]; }
+  const V3 ta = v3(p[9], p[10], p[11]), tb = v3(p[21], p[22], p[23]); h.tBA = tb - ta;
+  V3 ca = v3(0.f, 0.f, 0.f), cb = ca;  // seed: the difference of the centroids, as the checker's test entry
+  for (int k = 0; k < na; k++) ca = ca + v3(h.pa[3 * k], h.pa[3 * k + 1], h.pa[3 * k + 2]);
+  for (int k = 0; k < nb; k++) cb = cb + v3(h.pb[3 * k], h.pb[3 * k + 1], h.pb[3 * k + 2]);
+  const V3 seed = mul(h.RA, ca * (1.0f / (float)na)) - (mul(h.RB, cb * (1.0f / (float)nb)) + h.tBA);
+  h.ew = hull_ws_of(ws); hull_tables(h, na <= 64 && nb <= 64);  // (every lane of the wavefront is here)
+  HullHit r; hull_hull(h, seed, max_dist, have, r);
+  if (have) { float* o = out + 11 * (size_t)i; const V3 pa = r.pa + ta, pb = r.pb + ta;
+    o[0] = pa.x; o[1] = pa.y; o[2] = pa.z; o[3] = pb.x; o[4] = pb.y; o[5] = pb.z; o[6] = r.n.x; o[7] = r.n.y; o[8] = r.n.z; o[9] = r.dist; o[10] = r.hit ? 1.f : 0.f; }
+}
+int32_t dg_debug_hull_hull(const float* pts_a, int32_t na, const float* pts_b, int32_t nb, const float* poses, int32_t n, float max_dist, float* out11) {
+  if (!pts_a || !pts_b || !poses || !out11 || na < 1 || nb < 1 || na > 256 || nb > 256 || n < 1) return fail(DG_ERR_ARG, "dg_debug_hull_hull: bad argument");
+  float *d_pts = nullptr, *d_poses = nullptr, *d_out = nullptr, *d_ws = nullptr; const size_t blocks = (size_t)((n + 63) / 64);
+  HIP_TRY(hipMalloc(&d_ws, sizeof(float) * blocks * (size_t)HH_WS_SLOTS * 64));
+  HIP_TRY(hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)(na + nb))); HIP_TRY(hipMalloc(&d_poses, sizeof(float) * 24 * (size_t)n)); HIP_TRY(hipMalloc(&d_out, sizeof(float) * 11 * (size_t)n));
+  HIP_TRY(hipMemcpy(d_pts, pts_a, sizeof(float) * 3 * (size_t)na, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(d_pts + 3 * na, pts_b, sizeof(float) * 3 * (size_t)nb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_poses, poses, sizeof(float) * 24 * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(hull_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)0, (cfp)d_pts, na, nb, (const float*)d_poses, n, max_dist, d_out, d_ws);
+  HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out11, d_out, sizeof(float) * 11 * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(d_pts); (void)hipFree(d_poses); (void)hipFree(d_out); (void)hipFree(d_ws);
   return DG_OK;
 }
 

@@ -59,6 +59,7 @@ struct DevScene {
   int32_t debug_keep_ext;  // DG_DEBUG_KEEP_EXT: external wrenches and joint torques are NOT cleared at the end of a step (diagnostic: lets a test read what the update ops applied)
   int32_t no_chain_rows;  // DG_NO_CHAIN_ROWS: contacts between two register-chain bodies build their rows pair by pair (ablation / tests)
   int32_t warm_off;  // state offset of the contact impulse cache (DG_WS_*), -1: no warm starting
+  float* hull_ws;  // hull-hull narrow phase (dg_hull.h): HH_WS_SLOTS x 64 floats per wavefront of the step grid, or null (no pair of two hulls)
   int32_t ncons; cip KI; cfp KF;  // fixed constraints between two bodies (DG_KI_*, DG_KF_*): six solver rows each, generic sweeps only
   int32_t nb, nl, nfr, nsh, npairs, ngroups, nops, act_dim, obs_dim, rew_dim, term_dim, substeps, iters, hot_start, ik_iters;
   int32_t state_dim, addon_off, max_contacts, term_mode, n_term_groups;

@@ -3,6 +3,7 @@
 // Lane<> workspace of dg_kernels.h.
 #pragma once
 #include "dg_kernels.h"
+#include "dg_hull.h"
 
 namespace dg {
 
@@ -121,6 +122,7 @@ enum { SC_C = 0, SC_H = 3, SC_R = 6, SC_BOUND = 7, SC_STRIDE = 8 };
 template <int LANES, int TBL, int SLC = 1>
 DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff, int list = -1, int sl = 0) {
   const DevScene& sc = ln.sc; int cnt = 0; const float margin = sc.HF[DG_HF_CONTACT_MARGIN];
+  const bool hull_mode = sc.HF[DG_HF_HULL_CONTACTS] > 0.f; const float hmg = sc.HF[DG_HF_HULL_MARGIN];
   if (list < 0) list = sc.cont_off;
   if (sc.npairs == 0) { ln.L(list) = 0.f; return 0; }
   for (int sh = 0; sh < sc.nsha; sh++) {
@@ -128,7 +130,9 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
     WShape w; shape_world(ln, sh, w); V3 e0 = w.p, e1 = w.p;
     if (type != DG_SHAPE_SPHERE) seg_ends(w, e0, e1);
     const int o = sc.tr_off + sh * SC_STRIDE;
-    ln.L3set(o + SC_C, (e0 + e1) * 0.5f); ln.L3set(o + SC_H, (e1 - e0) * 0.5f); ln.L(o + SC_R) = w.prm0; ln.L(o + SC_BOUND) = w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
+    ln.L3set(o + SC_C, (e0 + e1) * 0.5f); ln.L3set(o + SC_H, (e1 - e0) * 0.5f); ln.L(o + SC_R) = w.prm0;
+    // (a hull's fitted capsule lets hull points near its caps stick out: with hull contacts the bound is the sphere that holds them all)
+    ln.L(o + SC_BOUND) = (hull_mode && type == DG_SHAPE_POINTS) ? fmaxf(w.prm0 + w.prm1, w.prm2) : w.prm0 + (type == DG_SHAPE_SPHERE ? 0.f : w.prm1);
   }
   // broad phase: a group = all pairs between one moving body and one shape of the static world (or another
   // moving body); skipped as a whole when the bounding spheres are apart in every lane of the wave
@@ -252,6 +256,37 @@ DGD int collide(const Lane<LANES>& ln, int pair_lo = 0, int pair_hi = 0x7fffffff
     const int pi = first + c0 + k, d = cu.desc;
     const int sa = d & 4095, sb = (d >> 12) & 4095, ta = (d >> 24) & 3, tb = (d >> 26) & 3; const float flip = (d >> 28) & 1 ? -1.f : 1.f;
     const int oa = sc.tr_off + sa * SC_STRIDE, ob = sc.tr_off + sb * SC_STRIDE;
+#ifndef DG_NO_HULL_CODE
+    if (hull_mode && ta == DG_SHAPE_POINTS && tb == DG_SHAPE_POINTS) {
+      // hull against hull (DG_HF_HULL_CONTACTS, dg_hull.h): the lanes whose bounding spheres reach each other run GJK on the two
+      // point sets in their link frames; one contact per pair
+      const float reach = cu.reach + 2.f * hmg; const V3 dc = cu.ca - cu.cb; const bool near = dot(dc, dc) < reach * reach;
+      if (!__any(near)) continue;
+      cip da = sc.SD + 4 * sa, db = sc.SD + 4 * sb;
+      auto frame_of = [&](cip sd, M3& Rl, V3& pl) {
+        if (sd[0] < 0) { M3 Id = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; Rl = Id; pl = v3(0.f, 0.f, 0.f); }
+        else { Rl = ln.LR(sd[0]); pl = sd[1] >= 0 ? v3(ln.S(sd[1]), ln.S(sd[1] + 1), ln.S(sd[1] + 2)) : ln.L3(sd[0] + 6); }
+      };
+      HullPairD hp; V3 pla, plb; frame_of(da, hp.RA, pla); frame_of(db, hp.RB, plb);
+      // second cull: the capsules that CONTAIN the hulls (the fitted axis and radius, half length DG_SF_HULL_HALF) -- their distance
+      // is a lower bound of the hulls'.  Two arms working next to each other pass the sphere test all the time and this one rarely.
+      bool close = near;
+      { cfp fa = sc.SF + sa * DG_SF_STRIDE, fb = sc.SF + sb * DG_SF_STRIDE;
+        M3 Rsa, Rsb; _Pragma("unroll") for (int q = 0; q < 9; q++) { Rsa.m[q] = fa[DG_SF_ROT + q]; Rsb.m[q] = fb[DG_SF_ROT + q]; }
+        const V3 axa = mul(hp.RA, v3(Rsa.m[2], Rsa.m[5], Rsa.m[8])) * fa[DG_SF_HULL_HALF], axb = mul(hp.RB, v3(Rsb.m[2], Rsb.m[5], Rsb.m[8])) * fb[DG_SF_HULL_HALF];
+        V3 qa, qb; seg_seg(cu.ca - axa, cu.ca + axa, cu.cb - axb, cu.cb + axb, qa, qb);
+        const float lim = ln.L(oa + SC_R) + ln.L(ob + SC_R) + margin + 2.f * hmg; const V3 dq = qa - qb;
+        close = near && dot(dq, dq) < lim * lim; }
+      if (!__any(close)) continue;
+      hp.pa = sc.PF + 3 * da[2]; hp.na = da[3]; hp.pb = sc.PF + 3 * db[2]; hp.nb = db[3]; hp.tBA = plb - pla;
+      hp.ew = hull_ws_of(sc.hull_ws);
+      hull_tables(hp, TBL > 0 && hp.na <= (TBL > 0 ? TBL : 1) && hp.nb <= (TBL > 0 ? TBL : 1));
+      HullHit hh; hull_hull(hp, dc, margin + 2.f * hmg, close, hh);
+      Hit h; h.hit = hh.hit && hh.dist - 2.f * hmg < margin; h.n = hh.n; h.dist = hh.dist - 2.f * hmg;
+      h.pa = (hh.pa + pla) - hh.n * hmg; h.pb = (hh.pb + pla) + hh.n * hmg;
+      emit_contact(ln, list, cnt, pi, h, flip);
+    } else
+#endif
     if (tb != DG_SHAPE_BOX) {
       // round vs round: closest points of the two segments, then sphere-sphere
       { const V3 dc = cu.ca - cu.cb; if (!__any(dot(dc, dc) < cu.reach * cu.reach)) continue; }
@@ -2077,8 +2112,8 @@ DGD void substep(const Lane<LANES>& ln, int32_t* diag_out, Prof<PROF>& prof, flo
   if (PAR) __syncthreads();  // B2: the helper's joint velocities (state) and M^-1 (LDS) are in place
   if (!own_collide) {
     ncont = (int)ln.L(sc.cont_off);  // written by the narrow-phase wavefront(s) before B2
-    if (sc.coll_split && !early) {  // append the second wavefront's contacts (later pairs) behind the first's (the early
-                                    // first substep was done by one wavefront over the whole pair table)
+    if (sc.coll_split) {  // append the second wavefront's contacts (later pairs) behind the first's (the early first substep
+                          // too: its narrow phase is cut in two like the others since round 4)
       const int nb2 = (int)ln.L(sc.cont2_off);
       if (__any(nb2 > 0)) {
         for (int j = 0; j < sc.max_contacts; j++) {

@@ -87,6 +87,11 @@ DEFAULTS = dict(
     # time base of a motor row's impulse bound: 'substep' (max force x fixedTimeStep / numSubSteps) or 'step' (max force x
     # fixedTimeStep: the other reading of pybullet's maxAppliedImpulse [R]) -- DG_HF_MOTOR_IMPULSE_SCALE
     motor_impulse_timebase='substep',
+    # two convex hulls (URDF collision meshes; boxes on moving bodies) collide as hulls: GJK closest points, an expanding polytope
+    # for the depth once they overlap, one contact per pair -- what Bullet's btConvexConvexAlgorithm does per call [R]; 0 = through
+    # the capsule fitted to each hull (the narrow phase of rounds 1-3) -- DG_HF_HULL_CONTACTS
+    hull_contacts=1.0,
+    hull_margin=0.001,  # [R] gUrdfDefaultCollisionMargin: a hull is inflated by this radius -- DG_HF_HULL_MARGIN
 )
 
 
@@ -424,7 +429,7 @@ class SceneBuilder:
                 link_reach.append(r)
             anchored = flat.fixed_base and b not in respawned  # the base never leaves its load pose
             for sh in flat.shapes:
-                kind, T, prm, pts = sh.kind, sh.T, np.zeros(3), None
+                kind, T, prm, pts, hull_half = sh.kind, sh.T, np.zeros(3), None, 0.0
                 if kind == SHAPE_SPHERE:
                     prm[0] = sh.params[0]
                 elif kind == SHAPE_BOX:
@@ -444,7 +449,12 @@ class SceneBuilder:
                     kind = SHAPE_POINTS
                 if kind == SHAPE_POINTS:
                     T, r, half = fit_capsule(pts)
-                    prm = np.array([r, half, 0.0])
+                    # (third parameter: radius of the sphere around the capsule's centre that holds every hull point -- the
+                    # fitted capsule itself lets points near its caps stick out; the cull of the hull-hull narrow phase)
+                    prm = np.array([r, half, float(np.max(np.linalg.norm(pts - T.p, axis=1)))])
+                    # (and the half length at which a capsule of that radius about that axis contains every point, DG_SF_HULL_HALF)
+                    t_ax = (pts - T.p) @ T.R[:, 2]; rho2 = np.sum((pts - T.p) ** 2, axis=1) - t_ax ** 2
+                    hull_half = float(max(np.max(np.abs(t_ax) - np.sqrt(np.maximum(r * r - rho2, 0.0))), 0.0)) + 1e-9
                 wflag = (K.SHAPE_WORLD if frozen else 0) | (K.SHAPE_NO_COLLIDE if getattr(sh, 'visual_only', False) else 0)
                 wflag |= ((sh.urdf_link + 1) & 0xFFFF) << 8  # pybullet link index + 1, for segmentation masks
                 if frozen:  # bake the body pose in
@@ -463,7 +473,7 @@ class SceneBuilder:
                 # model.py:82-83), else the link's URDF material, else the body's default grey
                 mat = getattr(sh, 'color', None)
                 rgb3 = self.colors[b][:3] if ((sh.urdf_link < 0 and self.color_set[b]) or mat is None) else mat
-                shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction, *rgb3, 0.0])
+                shape_f.append([*T.p, *T.R.reshape(-1), *prm, sh.friction, *rgb3, hull_half])
                 shape_dyn.append(dynamic)
                 # bounding sphere that holds the shape in EVERY reachable configuration, or None (floating / respawned base)
                 if not anchored:
@@ -643,6 +653,8 @@ class SceneBuilder:
         HF[K.HF_LIMIT_GUESS] = p['limit_guess'] if p['motor_guess'] > 0 else 0.0
         if p['motor_impulse_timebase'] not in ('substep', 'step'):
             raise ValueError("motor_impulse_timebase must be 'substep' or 'step'")
+        HF[K.HF_HULL_CONTACTS] = p['hull_contacts']
+        HF[K.HF_HULL_MARGIN] = p['hull_margin']
         HF[K.HF_MOTOR_IMPULSE_SCALE] = float(self.substeps) if p['motor_impulse_timebase'] == 'step' else 1.0
         off = K.HF_FLOAT_COUNT
         chunks_f = [HF]

@@ -18,7 +18,7 @@
 #define DIYGYM_SCENE_H
 
 #define DG_MAGIC 0x44475953 /* 'DGYS' */
-#define DG_VERSION 12
+#define DG_VERSION 13
 
 /* ---- header ints ---------------------------------------------------- */
 enum {
@@ -120,6 +120,11 @@ enum {
                            (default).  Set to the number of substeps for the other reading of pybullet -- maxAppliedImpulse =
                            force x fixedTimeStep, the FULL step, while the solver runs at fixedTimeStep / numSubSteps [R] --
                            engine parameter motor_impulse_timebase = 'step' */
+  DG_HF_HULL_CONTACTS,  /* > 0: two convex hulls (URDF collision meshes, boxes on moving bodies) collide as HULLS -- GJK closest
+                           points, an expanding polytope for the depth once they overlap -- one contact per pair, as Bullet's
+                           btConvexConvexAlgorithm finds per call [R]; 0: through the capsule fitted to each hull (rounds 1-3) */
+  DG_HF_HULL_MARGIN,    /* collision margin of a hull shape: the hull is inflated by this radius, i.e. the distance of two hulls
+                           is the GJK distance minus twice this (gUrdfDefaultCollisionMargin = 0.001 [R]) */
   DG_HF_FLOAT_COUNT
 };
 
@@ -217,6 +222,10 @@ enum { DG_SF_POS = 0, DG_SF_ROT = 3, DG_SF_PARAMS = 12 /* sphere r | box half[3]
        DG_SF_COLOR = 16 /* rgb of the shape in camera images: the URDF <material><color> of its link's first <visual>, the
                            YAML `color` for shapes of the base link (reference model.py:82-83: changeVisualShape(uid, -1, rgbaColor)),
                            else grey 0.8 */,
+       DG_SF_HULL_HALF = 19 /* DG_SHAPE_POINTS: half length of the capsule of radius PARAMS[0] along the fitted capsule's axis that
+                           CONTAINS every hull point (the fitted one, PARAMS[1], lets points near its caps stick out); PARAMS[2] =
+                           radius of the sphere around the capsule's centre that contains them.  Culling data of the hull-hull
+                           narrow phase (DG_HF_HULL_CONTACTS) */,
        DG_SF_STRIDE = 20 };
 /* ---- procedural textures (visual_randomizer) ------------------------------------------------------------------------
  * The per-env addon state of a visual_randomizer op: colour A rgb, colour B rgb, frequency [cells per metre], kind.

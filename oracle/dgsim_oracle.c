@@ -380,6 +380,13 @@ real* dgo_state(dgo_world* w) { return w->state; }
 real* dgo_motor_cfg(dgo_world* w) { return w->mcfg; }
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env) { return w->last_contacts[env]; }
 int32_t dgo_last_iterations(const dgo_world* w, int32_t env) { return w->last_iters[env]; }
+/* contact k of env's most recent substep: [point 3, normal 3 (from B towards A), signed distance, normal impulse] */
+int32_t dgo_last_contact(const dgo_world* w, int32_t env, int32_t k, real* out8) {
+  if (env < 0 || env >= w->B || k < 0 || k >= w->last_contacts[env]) return 0;
+  const Contact* c = &w->last_cs[(size_t)env * MAXC + k];
+  out8[0] = c->p.x; out8[1] = c->p.y; out8[2] = c->p.z; out8[3] = c->n.x; out8[4] = c->n.y; out8[5] = c->n.z; out8[6] = c->dist; out8[7] = c->imp[0];
+  return 1;
+}
 
 /* --------------------------------------------------------- kinematics */
 static void body_kinematics(const Scene* s, const real* st, int b, BodyWS* ws, const real* q_override) {
@@ -635,6 +642,232 @@ static int sphere_sphere(v3 ca, real ra, v3 cb, real rb, real margin, v3* pa, v3
   return 1;
 }
 
+
+/* ---- convex hull against convex hull (DG_HF_HULL_CONTACTS) ----------------------------------------------------------------
+ * What pybullet does with two URDF collision meshes (reference model.py:65 loadURDF; e.g. data/ur5/ur5_robot.urdf collision
+ * <mesh> elements): Bullet collides their convex hulls -- btConvexConvexAlgorithm, GJK closest points on the hulls WITHOUT their
+ * collision margin, the margins (gUrdfDefaultCollisionMargin = 0.001 per shape [R]) subtracted from the distance afterwards, and
+ * an expanding-polytope search for the penetration depth once the margin-free hulls themselves overlap [R].  Restated here on
+ * the (thinned) hull points of the scene tables:
+ *   C = A - B (Minkowski difference), support s_C(d) = s_A(d) - s_B(-d);
+ *   GJK: closest point v of C to the origin, simplex of <= 4 support points with the Voronoi-region tests of Ericson, Real-Time
+ *        Collision Detection 5.1.5 / 5.1.6; distance |v|, normal v / |v| (from B to A), witness points from the barycentric
+ *        weights; gives up early once v . w / |v| (a lower bound of the distance) exceeds `max_dist`;
+ *   EPA: when the origin is inside C or nearer than HH_SWITCH to it -- an expanding polytope inside C, started from a
+ *        tetrahedron of four support points chosen independently of the GJK simplex, its faces kept with SIGNED plane
+ *        distances of the origin (so a start polytope that does not yet hold the origin is fine): the face with the smallest
+ *        one is pushed out to its support point until it is a face of C; depth = that distance, normal = minus its normal.
+ * Coordinates are relative to A's frame origin (fp32 build: world coordinates of ~1 m would cost three digits).
+ * The HIP kernels run the same steps (dg_solver.h hull_hull); both are checked against a brute-force construction of C with
+ * scipy's ConvexHull in tests/test_oracle_kat.py. */
+#define HH_GJK_ITERS 32
+#define HH_EPA_ITERS 24
+#define HH_EPA_MAXV (4 + HH_EPA_ITERS)
+#define HH_EPA_MAXF (2 * HH_EPA_MAXV)
+#define HH_EPA_MAXE 96  /* horizon edges held at a time (the device keeps them in per-lane scratch) */
+#define HH_FACE_PTS 8  /* coplanar support points gathered for the witness points of a polytope face */
+#define HH_SWITCH ((real)1e-4)  /* the origin nearer to C than this: the polytope search decides (v / |v| is noise there) */
+typedef struct { const real *pa, *pb; int na, nb; m3 RA, RB; v3 tBA; } HullPair;
+typedef struct { v3 w, a, b; int ia, ib; } HV;
+static int hh_argmax(const real* p, int n, v3 d) {
+  int bi = 0; real best = -HUGE_R;
+  for (int k = 0; k < n; k++) { real sd = p[3 * k] * d.x + p[3 * k + 1] * d.y + p[3 * k + 2] * d.z; if (sd > best) { best = sd; bi = k; } }
+  return bi;
+}
+static HV hh_support(const HullPair* h, v3 d) {
+  HV o; o.ia = hh_argmax(h->pa, h->na, mtv(&h->RA, d)); o.ib = hh_argmax(h->pb, h->nb, mtv(&h->RB, vscale(d, -1.0)));
+  o.a = mv(&h->RA, V(h->pa[3 * o.ia], h->pa[3 * o.ia + 1], h->pa[3 * o.ia + 2]));
+  o.b = vadd(mv(&h->RB, V(h->pb[3 * o.ib], h->pb[3 * o.ib + 1], h->pb[3 * o.ib + 2])), h->tBA);
+  o.w = vsub(o.a, o.b); return o;
+}
+/* barycentric weights of the point of triangle (a, b, c) closest to the origin (Ericson 5.1.5) */
+static void hh_closest_tri(v3 a, v3 b, v3 c, real* l) {
+  v3 ab = vsub(b, a), ac = vsub(c, a);
+  real d1 = -vdot(ab, a), d2 = -vdot(ac, a);
+  l[0] = l[1] = l[2] = 0;
+  if (d1 <= 0 && d2 <= 0) { l[0] = 1; return; }
+  real d3 = -vdot(ab, b), d4 = -vdot(ac, b);
+  if (d3 >= 0 && d4 <= d3) { l[1] = 1; return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { real t = d1 / (d1 - d3); l[0] = 1 - t; l[1] = t; return; }
+  real d5 = -vdot(ab, c), d6 = -vdot(ac, c);
+  if (d6 >= 0 && d5 <= d6) { l[2] = 1; return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { real t = d2 / (d2 - d6); l[0] = 1 - t; l[2] = t; return; }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { real t = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[1] = 1 - t; l[2] = t; return; }
+  real den = 1.0 / (va + vb + vc); l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+}
+/* point of the simplex (n vertices) closest to the origin: weights l[0..n); returns 1 when the origin is inside a tetrahedron */
+static int hh_closest_simplex(const HV* sx, int n, real* l) {
+  for (int k = 0; k < 4; k++) l[k] = 0;
+  if (n == 1) { l[0] = 1; return 0; }
+  if (n == 2) {
+    v3 ab = vsub(sx[1].w, sx[0].w); real den = vdot(ab, ab), t = den > 0 ? -vdot(sx[0].w, ab) / den : 0.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t); l[0] = 1 - t; l[1] = t; return 0;
+  }
+  if (n == 3) { hh_closest_tri(sx[0].w, sx[1].w, sx[2].w, l); return 0; }
+  /* tetrahedron (Ericson 5.1.6): the faces that have the origin on their outer side (a flat tetrahedron: every face) */
+  static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+  real best = HUGE_R; int inside = 1;
+  for (int f = 0; f < 4; f++) {
+    v3 a = sx[F[f][0]].w, b = sx[F[f][1]].w, c = sx[F[f][2]].w, d = sx[F[f][3]].w;
+    v3 nn = vcross(vsub(b, a), vsub(c, a));
+    real sp = -vdot(a, nn), sd = vdot(vsub(d, a), nn), scale = vdot(nn, nn) * vdot(vsub(d, a), vsub(d, a));
+    int flat = sd * sd <= (real)1e-10 * scale, outside = flat || sp * sd < 0;
+    if (!outside) continue;
+    inside = 0;
+    real lt[3]; hh_closest_tri(a, b, c, lt);
+    v3 q = vadd(vadd(vscale(a, lt[0]), vscale(b, lt[1])), vscale(c, lt[2])); real qq = vdot(q, q);
+    if (qq < best) { best = qq; for (int k = 0; k < 4; k++) l[k] = 0; l[F[f][0]] = lt[0]; l[F[f][1]] = lt[1]; l[F[f][2]] = lt[2]; }
+  }
+  return inside;
+}
+typedef struct { int v[3]; v3 n; real d; int alive; } HF;
+static void hh_face(HF* f, const HV* vs, int i, int j, int k, v3 g) {
+  f->v[0] = i; f->v[1] = j; f->v[2] = k; f->alive = 1;
+  v3 nn = vcross(vsub(vs[j].w, vs[i].w), vsub(vs[k].w, vs[i].w)); real len = vnorm(nn);
+  if (!(len > (real)1e-12)) { f->n = V(0, 0, 1); f->d = HUGE_R; return; }  /* a sliver: kept for the topology, never the closest */
+  nn = vscale(nn, 1.0 / len);
+  if (vdot(nn, vsub(vs[i].w, g)) < 0) { nn = vscale(nn, -1.0); f->v[1] = k; f->v[2] = j; }  /* outward: away from the interior point g */
+  f->n = nn; f->d = vdot(nn, vs[i].w);
+}
+/* signed distance of the origin from the boundary of C along its nearest face (> 0: inside, the penetration depth), that
+ * face's outward normal and the witness points of the origin's projection onto it */
+static real hh_epa(const HullPair* h, v3 seed, v3* n_out, v3* pa, v3* pb, int* iters_out) {
+  HV vs[HH_EPA_MAXV]; HF fs[HH_EPA_MAXF]; int nv = 0, nf = 0;
+  /* a tetrahedron of C: two opposite support points, the one farthest from their line, the one farthest from their plane */
+  v3 d0 = vdot(seed, seed) > (real)1e-12 ? vscale(seed, 1.0 / vnorm(seed)) : V(1, 0, 0);
+  vs[0] = hh_support(h, d0); vs[1] = hh_support(h, vscale(d0, -1.0));
+  v3 e = vsub(vs[1].w, vs[0].w);
+  v3 ax = fabs(e.x) <= fabs(e.y) && fabs(e.x) <= fabs(e.z) ? V(1, 0, 0) : (fabs(e.y) <= fabs(e.z) ? V(0, 1, 0) : V(0, 0, 1));
+  v3 d1 = vcross(e, ax); d1 = vscale(d1, 1.0 / (vnorm(d1) + TINY_R));
+  HV c1 = hh_support(h, d1), c2 = hh_support(h, vscale(d1, -1.0));
+  vs[2] = fabs(vdot(vsub(c1.w, vs[0].w), d1)) >= fabs(vdot(vsub(c2.w, vs[0].w), d1)) ? c1 : c2;
+  v3 nn = vcross(e, vsub(vs[2].w, vs[0].w)); nn = vscale(nn, 1.0 / (vnorm(nn) + TINY_R));
+  c1 = hh_support(h, nn); c2 = hh_support(h, vscale(nn, -1.0));
+  vs[3] = fabs(vdot(vsub(c1.w, vs[0].w), nn)) >= fabs(vdot(vsub(c2.w, vs[0].w), nn)) ? c1 : c2;
+  nv = 4;
+  v3 g = vscale(vadd(vadd(vs[0].w, vs[1].w), vadd(vs[2].w, vs[3].w)), 0.25);
+  hh_face(&fs[0], vs, 0, 1, 2, g); hh_face(&fs[1], vs, 0, 1, 3, g); hh_face(&fs[2], vs, 0, 2, 3, g); hh_face(&fs[3], vs, 1, 2, 3, g); nf = 4;
+  int best = 0;
+  for (int it = 0; it < HH_EPA_ITERS; it++) {
+    best = -1; real bd = HUGE_R;
+    for (int f = 0; f < nf; f++) if (fs[f].alive && fs[f].d < bd) { bd = fs[f].d; best = f; }
+    if (best < 0) { best = 0; break; }
+    HV w = hh_support(h, fs[best].n);
+    if (vdot(w.w, fs[best].n) - fs[best].d <= (real)1e-6 || nv >= HH_EPA_MAXV) break;  /* the face lies on the boundary of C */
+    int dup = 0; for (int k = 0; k < nv; k++) if (vs[k].ia == w.ia && vs[k].ib == w.ib) dup = 1;
+    if (dup) break;
+    vs[nv] = w;
+    /* faces that see the new point go; the edges that belonged to exactly one of them are the horizon */
+    int ed[HH_EPA_MAXE], ne = 0, full = 0;  /* an edge = its two vertex indices, lower one first: i | j << 8 */
+    for (int f = 0; f < nf; f++) {
+      if (!fs[f].alive || fs[f].d >= HUGE_R) continue;
+      if (!(vdot(fs[f].n, w.w) - fs[f].d > (real)1e-9) && f != best) continue;
+      fs[f].alive = 0;
+      for (int q = 0; q < 3; q++) {
+        int i = fs[f].v[q], j = fs[f].v[(q + 1) % 3], key = i < j ? (i | (j << 8)) : (j | (i << 8)), found = -1;
+        for (int t = 0; t < ne; t++) if (ed[t] == key) { found = t; break; }
+        if (found >= 0) { ed[found] = ed[ne - 1]; ne--; } else if (ne < HH_EPA_MAXE) ed[ne++] = key; else full = 1;
+      }
+    }
+    /* (a sliver is never removed: its edges never enter the horizon and the surface stays closed) */
+    for (int t = 0; t < ne; t++) {
+      int slot = -1; for (int f = 0; f < nf; f++) if (!fs[f].alive) { slot = f; break; }
+      if (slot < 0) { if (nf >= HH_EPA_MAXF) break; slot = nf++; }
+      hh_face(&fs[slot], vs, ed[t] & 255, ed[t] >> 8, nv, g);
+    }
+    if (full) { nv++; break; }
+    nv++;
+  }
+  if (iters_out) *iters_out = nv - 4;
+  const HF* f = &fs[best];
+  /* Witness points: the origin's projection p onto the face's plane, as a combination of support points lying IN that plane.
+   * The triangle found is only part of C's face there -- a parallelogram when two edges cross, a polygon when a face of one hull
+   * rests on the other -- and p may lie in another part of it: while p is outside every triangle of the coplanar points found so
+   * far, the support point of a direction tilted from the normal towards p (1e-3 rad) is the face's corner on that side. */
+  const v3 p = vscale(f->n, f->d);
+  HV pl[HH_FACE_PTS]; int np = 3; pl[0] = vs[f->v[0]]; pl[1] = vs[f->v[1]]; pl[2] = vs[f->v[2]];
+  int bi = 0, bj = 1, bk = 2; real bl[3] = {1, 0, 0};
+  for (int round = 0; ; round++) {
+    real bq = HUGE_R; v3 qbest = p;
+    for (int i = 0; i < np; i++) for (int j = i + 1; j < np; j++) for (int k = j + 1; k < np; k++) {
+      real l[3]; hh_closest_tri(vsub(pl[i].w, p), vsub(pl[j].w, p), vsub(pl[k].w, p), l);
+      v3 q = vadd(vadd(vscale(vsub(pl[i].w, p), l[0]), vscale(vsub(pl[j].w, p), l[1])), vscale(vsub(pl[k].w, p), l[2])); real qq = vdot(q, q);
+      if (qq < bq) { bq = qq; qbest = q; bi = i; bj = j; bk = k; bl[0] = l[0]; bl[1] = l[1]; bl[2] = l[2]; }
+    }
+    if (bq <= (real)1e-12 || np >= HH_FACE_PTS || round >= HH_FACE_PTS) break;
+    HV w = hh_support(h, vadd(f->n, vscale(qbest, -(real)1e-3 / sqrt(bq))));  /* (qbest = nearest point - p: towards p is -qbest) */
+    if (f->d - vdot(w.w, f->n) > (real)1e-4) break;  /* not in the plane (0.1 mm): the face ends before p */
+    int dup = 0; for (int k = 0; k < np; k++) if (pl[k].ia == w.ia && pl[k].ib == w.ib) dup = 1;
+    if (dup) break;
+    pl[np++] = w;
+  }
+  *pa = vadd(vadd(vscale(pl[bi].a, bl[0]), vscale(pl[bj].a, bl[1])), vscale(pl[bk].a, bl[2]));
+  *pb = vadd(vadd(vscale(pl[bi].b, bl[0]), vscale(pl[bj].b, bl[1])), vscale(pl[bk].b, bl[2]));
+  *n_out = f->n; return f->d;
+}
+/* signed distance of hull A from hull B (< 0: they overlap by that much), unit normal from B towards A, witness points (world,
+ * relative to A's frame origin).  Returns 0 -- nothing else set -- once the distance is known to exceed max_dist. */
+static long long g_hh_calls, g_hh_far, g_hh_epa, g_hh_gjk_iters;  /* diagnostic tallies (dgo_hull_tallies; not thread-safe: serial builds only) */
+static int hull_hull(const HullPair* h, v3 seed, real max_dist, v3* pa, v3* pb, v3* n, real* dist, int* stats) {
+  g_hh_calls++;
+  HV sx[4]; int ns = 0; real l[4] = {0, 0, 0, 0};
+  v3 v = vdot(seed, seed) > (real)1e-12 ? seed : V(1, 0, 0); real vv = HUGE_R; int inside = 0, it;
+  for (it = 0; it < HH_GJK_ITERS; it++) {
+    HV w = hh_support(h, vscale(v, -1.0));
+    if (ns > 0) {
+      real vw = vdot(v, w.w), vn = sqrt(vv);
+      if (vw > max_dist * vn) { if (stats) stats[0] = it + 1; g_hh_far++; g_hh_gjk_iters += it + 1; return 0; }  /* a separating plane farther than anyone asks */
+      int dup = 0; for (int k = 0; k < ns; k++) if (sx[k].ia == w.ia && sx[k].ib == w.ib) dup = 1;
+      if (dup || vv - vw <= (real)1e-6 * vv + (real)1e-7 * vn) break;  /* no support point nearer along v: v is the closest point */
+    }
+    sx[ns] = w;
+    real ln[4]; int in = hh_closest_simplex(sx, ns + 1, ln);
+    if (in) { inside = 1; break; }
+    v3 nv = V(0, 0, 0); for (int k = 0; k <= ns; k++) nv = vadd(nv, vscale(sx[k].w, ln[k]));
+    real nvv = vdot(nv, nv);
+    if (ns > 0 && !(nvv < vv)) break;  /* (rounding: no progress -- keep the previous simplex) */
+    int m = 0; for (int k = 0; k <= ns; k++) if (ln[k] > 0) { sx[m] = sx[k]; l[m] = ln[k]; m++; }
+    ns = m; v = nv; vv = nvv;
+    if (vv <= HH_SWITCH * HH_SWITCH) break;
+  }
+  if (stats) { stats[0] = it + 1; stats[1] = inside || vv <= HH_SWITCH * HH_SWITCH; }
+  g_hh_gjk_iters += it + 1;
+  if (inside || vv <= HH_SWITCH * HH_SWITCH) {
+    g_hh_epa++;
+    v3 nf; real d = hh_epa(h, seed, &nf, pa, pb, stats ? &stats[2] : NULL);
+    *n = vscale(nf, -1.0); *dist = -d; return 1;
+  }
+  real vn = sqrt(vv); *n = vscale(v, 1.0 / vn); *dist = vn;
+  *pa = V(0, 0, 0); *pb = V(0, 0, 0);
+  for (int k = 0; k < ns; k++) { *pa = vadd(*pa, vscale(sx[k].a, l[k])); *pb = vadd(*pb, vscale(sx[k].b, l[k])); }
+  return 1;
+}
+/* diagnostic: [calls of the hull-hull routine, of them left early as too far apart, decided by the polytope search, GJK iterations in all] since the last reset */
+void dgo_hull_tallies(int64_t* out4, int32_t reset) {
+  out4[0] = g_hh_calls; out4[1] = g_hh_far; out4[2] = g_hh_epa; out4[3] = g_hh_gjk_iters;
+  if (reset) g_hh_calls = g_hh_far = g_hh_epa = g_hh_gjk_iters = 0;
+}
+/* test entry (tests/test_oracle_kat.py): two point sets with poses [R 9 row-major | t 3]; out = [pa 3, pb 3, n 3, dist]; stats
+ * = [GJK iterations, 1 if the polytope search decided, support points it added]; returns 0 when the hulls are farther apart than max_dist */
+int32_t dgo_hull_hull(const real* pts_a, int32_t na, const real* pose_a, const real* pts_b, int32_t nb, const real* pose_b, real max_dist, real* out10, int32_t* stats3) {
+  HullPair h; h.pa = pts_a; h.pb = pts_b; h.na = na; h.nb = nb; h.RA = mfrom9(pose_a); h.RB = mfrom9(pose_b);
+  v3 ta = V(pose_a[9], pose_a[10], pose_a[11]), tb = V(pose_b[9], pose_b[10], pose_b[11]); h.tBA = vsub(tb, ta);
+  v3 ca = V(0, 0, 0), cb = V(0, 0, 0);
+  for (int k = 0; k < na; k++) ca = vadd(ca, V(pts_a[3 * k], pts_a[3 * k + 1], pts_a[3 * k + 2]));
+  for (int k = 0; k < nb; k++) cb = vadd(cb, V(pts_b[3 * k], pts_b[3 * k + 1], pts_b[3 * k + 2]));
+  v3 seed = vsub(mv(&h.RA, vscale(ca, 1.0 / na)), vadd(mv(&h.RB, vscale(cb, 1.0 / nb)), h.tBA));
+  v3 pa, pb, n; real dist; int st[3] = {0, 0, 0};
+  int hit = hull_hull(&h, seed, max_dist, &pa, &pb, &n, &dist, st);
+  if (stats3) { stats3[0] = st[0]; stats3[1] = st[1]; stats3[2] = st[2]; }
+  if (!hit) return 0;
+  pa = vadd(pa, ta); pb = vadd(pb, ta);
+  out10[0] = pa.x; out10[1] = pa.y; out10[2] = pa.z; out10[3] = pb.x; out10[4] = pb.y; out10[5] = pb.z; out10[6] = n.x; out10[7] = n.y; out10[8] = n.z; out10[9] = dist;
+  return 1;
+}
+
 static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
   int nc = 0; real margin = s->F[DG_HF_CONTACT_MARGIN];
   for (int pi = 0; pi < s->npairs; pi++) {
@@ -653,8 +886,17 @@ static int collide(const Scene* s, const BodyWS* wsb, Contact* cs) {
     } else if (a->type == DG_SHAPE_SPHERE && (b->type == DG_SHAPE_CAPSULE || b->type == DG_SHAPE_POINTS)) {
       v3 e0, e1; seg_ends(b, &e0, &e1); v3 cb = closest_on_seg(e0, e1, a->p);
       if (sphere_sphere(a->p, a->prm[0], cb, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
+    } else if (a->type == DG_SHAPE_POINTS && b->type == DG_SHAPE_POINTS && s->F[DG_HF_HULL_CONTACTS] > 0) {
+      /* hull against hull (DG_HF_HULL_CONTACTS): bounding spheres around the fitted capsules' centres first (prm[2]) */
+      const real hm = s->F[DG_HF_HULL_MARGIN], reach = margin + 2 * hm;
+      if (vnorm(vsub(a->p, b->p)) - a->prm[2] - b->prm[2] < reach) {
+        HullPair h; h.pa = s->PF + 3 * a->poff; h.na = a->npts; h.pb = s->PF + 3 * b->poff; h.nb = b->npts; h.RA = a->Rl; h.RB = b->Rl; h.tBA = vsub(b->pl, a->pl);
+        if (hull_hull(&h, vsub(a->p, b->p), reach, &pa, &pb, &n, &dist, NULL) && dist - 2 * hm < margin) {
+          dist -= 2 * hm; pa = vsub(vadd(pa, a->pl), vscale(n, hm)); pb = vadd(vadd(pb, a->pl), vscale(n, hm)); EMIT();
+        }
+      }
     } else if ((a->type == DG_SHAPE_CAPSULE || a->type == DG_SHAPE_POINTS) && (b->type == DG_SHAPE_CAPSULE || b->type == DG_SHAPE_POINTS)) {
-      /* mesh-vs-mesh uses the capsule fitted to each hull (documented approximation) */
+      /* hull against capsule, and hull against hull with DG_HF_HULL_CONTACTS off: the capsule fitted to each hull (documented approximation) */
       v3 a0, a1, b0, b1, ca, cb; seg_ends(a, &a0, &a1); seg_ends(b, &b0, &b1); seg_seg(a0, a1, b0, b1, &ca, &cb);
       if (sphere_sphere(ca, a->prm[0], cb, b->prm[0], margin, &pa, &pb, &n, &dist)) EMIT();
     } else if (a->type == DG_SHAPE_CAPSULE && b->type == DG_SHAPE_BOX) {

@@ -72,8 +72,18 @@ int dgo_render(dgo_world* w, int32_t camera, real* rgb, real* depth, int32_t* se
 int dgo_apply_wrench(dgo_world* w, int32_t body, int32_t frame, int32_t link_frame, const real* force, const real* pos, const real* torque);
 
 /* diagnostics from the most recent substep of env `env` */
+/* diagnostic tallies of the hull-hull routine since the last reset: [calls, left early as too far apart, decided by the expanding
+ * polytope, GJK iterations in all] (serial builds only) */
+void dgo_hull_tallies(int64_t* out4, int32_t reset);
+/* narrow phase of two convex hulls on its own (test entry): point sets [n][3] with poses [R 9 row-major | t 3]; out10 = [witness
+ * on A 3, witness on B 3, unit normal from B towards A 3, signed distance]; stats3 = [GJK iterations, 1 if the expanding-polytope
+ * search decided, support points that search added]; returns 0 (out untouched) when the hulls are farther apart than max_dist */
+int32_t dgo_hull_hull(const real* pts_a, int32_t na, const real* pose_a, const real* pts_b, int32_t nb, const real* pose_b, real max_dist, real* out10, int32_t* stats3);
 int32_t dgo_last_contact_count(const dgo_world* w, int32_t env);
 int32_t dgo_last_iterations(const dgo_world* w, int32_t env);
+/* contact k (< dgo_last_contact_count) of env's most recent substep: out8 = [point 3, normal 3 (from B towards A), signed distance,
+ * normal impulse]; returns 0 when there is no such contact */
+int32_t dgo_last_contact(const dgo_world* w, int32_t env, int32_t k, real* out8);
 
 /* stand-alone pieces exposed for known-answer tests */
 /* joint-space inverse dynamics check: returns qdd for body `body` of env `env`

@@ -27,12 +27,28 @@ SCENES = {  # name: (config, envs, steps, action scale)
     'maze': ('examples/r2d2_maze/r2d2_maze.yaml', 2, 12, 10.0),
     'admittance': ('tests/golden/ur_admittance.yaml', 3, 30, 1.0),
     'readme': ('examples/from_the_readme/from_the_readme.yaml', 2, 30, 0.2),   # R2D2 lands on the table: 25 contacts
-    'touching': ('tests/golden/ur_arms_touching.yaml', 3, 30, 0.3),            # crossed forearms: contacts between two arms
+    # crossed forearms driven THROUGH each other: contacts between two arms in every form of the sweeps, with the narrow phase that
+    # is smooth in the poses (the capsule fitted to each hull; tests/test_parity_gpu.py SMOOTH_CONTACTS says why)
+    'touching': ('tests/golden/ur_arms_touching.yaml', 3, 30, 0.3, dict(hull_contacts=0.0)),
+    # the same arms holding that pose and turning one shoulder by 0.06 / 0.10 / 0.14 rad: the forearms meet at ~0.2 rad/s and stay
+    # pressed against each other -- the hulls colliding as hulls (the default narrow phase), resting contact under load
+    'pressing': ('tests/golden/ur_arms_touching.yaml', 3, 60, 'press'),
     'gripper': ('tests/golden/ur5_gripper.yaml', 3, 30, 0.5),                  # UR5 + two-finger gripper, 12-DoF tree
 }
 
 
+CROSSED = [1.35, -1.08, 1.03, -0.01, 0.09, 0.86]   # rest_position of ur_arms_touching.yaml
+
+
+def press_actions(env, steps):
+    act = torch.tensor(CROSSED * 2, dtype=torch.float32)[None].repeat(env.num_envs, 1)
+    act[:, 0] += 0.06 + 0.08 * torch.arange(env.num_envs) / max(env.num_envs - 1, 1)
+    return act[None].repeat(steps, 1, 1)
+
+
 def actions_for(env, steps, scale, seed=123):
+    if scale == 'press':
+        return press_actions(env, steps)
     from diy_gym_amd.utils import flatten, get_bounds_for_space
     lo = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, True)), dtype=torch.float32)
     hi = torch.as_tensor(flatten(get_bounds_for_space(env.action_space, False)), dtype=torch.float32)
@@ -45,16 +61,17 @@ def actions_for(env, steps, scale, seed=123):
 # contact normal rows warm started with Bullet's factor 0.85 -- instead of this build's production defaults (motor_guess 1,
 # warmstart 1).  Scenes with motors and / or contacts.
 REFERENCE_SETTINGS = dict(motor_guess=0.0, warmstart=0.85)
-REF_SCENES = ('ur_ik', 'ur_joint', 'cart_tree', 'maze', 'readme', 'touching', 'gripper', 'marbles')
+REF_SCENES = ('ur_ik', 'ur_joint', 'cart_tree', 'maze', 'readme', 'touching', 'pressing', 'gripper', 'marbles')
 
 
 def run(name, backend_factory=None, device=None, engine=None):
     import diy_gym_amd.examples  # noqa: F401
     from diy_gym_amd import DIYGym
-    cfg, B, steps, scale = SCENES[name]
+    cfg, B, steps, scale = SCENES[name][:4]
     kw = dict(backend_factory=backend_factory) if backend_factory else dict(device=device)
+    engine = dict(SCENES[name][4] if len(SCENES[name]) > 4 else {}, **(engine or {}))
     if engine:
-        kw['engine'] = dict(engine)
+        kw['engine'] = engine
     env = DIYGym(os.path.join(ROOT, cfg), num_envs=B, seed=11, **kw)
     acts = actions_for(env, steps, scale)
     obs = []

@@ -43,6 +43,8 @@ def lib(path=None):
         L.dgo_last_contact_count.argtypes = [vp, i32]
         L.dgo_last_iterations.restype = i32
         L.dgo_last_iterations.argtypes = [vp, i32]
+        L.dgo_last_contact.restype = i32
+        L.dgo_last_contact.argtypes = [vp, i32, i32, vp]
         L.dgo_forward_dynamics.argtypes = [vp, i32, i32, vp, vp]
         L.dgo_unit_response.argtypes = [vp, i32, i32, i32, vp]
         L.dgo_ik.argtypes = [vp, i32, i32, vp, vp]
@@ -197,6 +199,13 @@ class OracleBackend:
 
     def contacts(self, env=0):
         return self.L.dgo_last_contact_count(self.handle, env)
+
+    def contact(self, env, k):
+        """[point 3, normal 3 (B -> A), signed distance, normal impulse] of contact k of the env's most recent substep."""
+        out = np.zeros(8, dtype=self.real)
+        if not self.L.dgo_last_contact(self.handle, env, k, _p(out)):
+            raise IndexError(k)
+        return out.astype(np.float64)
 
     def iterations(self, env=0):
         return self.L.dgo_last_iterations(self.handle, env)

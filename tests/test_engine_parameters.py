@@ -43,13 +43,16 @@ OVERRIDES = {
     'motor_guess': (0.0, 'ur_ik', 5, 1.0, False),
     'limit_guess': (0.0, 'cart_tree', 60, 1.0, True),
     'motor_impulse_timebase': ('step', 'touching', 10, 0.3, False),
+    'hull_contacts': (0.0, 'touching', 10, 0.3, False),   # (the capsule fitted to each hull instead of the hull)
+    'hull_margin': (0.004, 'touching', 10, 0.3, False),
 }
 HF_SLOT = {'residual_threshold': 'HF_RESIDUAL_THRESHOLD', 'contact_erp': 'HF_CONTACT_ERP', 'limit_erp': 'HF_LIMIT_ERP', 'linear_slop': 'HF_LINEAR_SLOP',
            'linear_damping': 'HF_LIN_DAMPING', 'angular_damping': 'HF_ANG_DAMPING', 'max_coordinate_velocity': 'HF_MAX_COORD_VEL',
            'default_motor_impulse': 'HF_DEFAULT_MOTOR_IMPULSE', 'ik_lambda_sq': 'HF_IK_LAMBDA_SQ', 'ik_joint_damping': 'HF_IK_JOINT_DAMPING',
            'ik_residual': 'HF_IK_RESIDUAL', 'ik_max_angle': 'HF_IK_MAX_ANGLE', 'ik_null_rest_gain': 'HF_IK_NULL_REST_GAIN', 'ik_null_limit_gain': 'HF_IK_NULL_LIMIT_GAIN',
            'contact_margin': 'HF_CONTACT_MARGIN', 'warmstart': 'HF_WARMSTART', 'warmstart_friction': 'HF_WARMSTART_FRICTION', 'motor_guess': 'HF_MOTOR_GUESS',
-           'limit_guess': 'HF_LIMIT_GUESS', 'motor_impulse_timebase': 'HF_MOTOR_IMPULSE_SCALE'}
+           'limit_guess': 'HF_LIMIT_GUESS', 'motor_impulse_timebase': 'HF_MOTOR_IMPULSE_SCALE', 'hull_contacts': 'HF_HULL_CONTACTS',
+           'hull_margin': 'HF_HULL_MARGIN'}
 BLOB_ONLY = ('ik_joint_damping', 'ik_null_limit_gain')
 
 

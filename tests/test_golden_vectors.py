@@ -37,7 +37,7 @@ def test_oracle_reproduces_golden_at_reference_solver_settings(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,tol', [('marbles', 2e-3), ('ur_ik', 5e-4), ('ur_joint', 5e-4), ('cart_tree', 5e-3), ('maze', 5e-3), ('readme', 2e-3),
-                                      ('touching', 3e-3), ('gripper', 3e-3)])
+                                      ('touching', 3e-3), ('pressing', 2e-3), ('gripper', 3e-3)])
 def test_hip_matches_golden_at_reference_solver_settings(name, tol):
     r = make_vectors.run(name, device='cuda:0', engine=make_vectors.REFERENCE_SETTINGS)
     obs, ref = r['obs'], V['ref/' + name + '/obs']
@@ -54,7 +54,7 @@ def test_hip_matches_golden_at_reference_solver_settings(name, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,tol', [('marbles', 2e-3), ('drone', 2e-3), ('ur_ik', 5e-4), ('ur_joint', 5e-4), ('cart_tree', 5e-3), ('maze', 5e-3),
-                                      ('admittance', 3e-3), ('readme', 2e-3), ('touching', 3e-3), ('gripper', 3e-3)])
+                                      ('admittance', 3e-3), ('readme', 2e-3), ('touching', 3e-3), ('pressing', 2e-3), ('gripper', 3e-3)])
 def test_hip_matches_golden(name, tol):
     r = make_vectors.run(name, device='cuda:0')
     obs, ref = r['obs'], V[name + '/obs']

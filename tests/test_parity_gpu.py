@@ -33,10 +33,24 @@ CART_STATE_TOL = 1e-3                                     # measured 1.3e-4
 MAZE_VEL_TOL, MAZE_Q_TOL, MAZE_QD_TOL = 3e-1, 4e-2, 3e-1   # measured 1.2e-1, 1.5e-2, 1.0e-1 (|qd| up to 5 rad/s, iteration-capped sweeps)
 
 
+# ur_arms_touching / _ft drive two arms THROUGH each other at ~10 rad/s under joint-position control: scenes built to put contact
+# rows into every form of the sweeps (the cases below are a matrix over kernel forms, not over narrow phases).  They keep the
+# narrow phase they were tuned on -- the capsule fitted to each hull (hull_contacts = 0), whose contact normal moves smoothly
+# with the poses.  With the hulls colliding as hulls (the default since round 4) interpenetrating polytopes have a DISCONTINUOUS
+# minimum-translation direction: two faces a micrometre apart in depth, fp32 and fp64 pick different ones, the normal jumps by
+# degrees and a free-running comparison of such a rollout measures that, not the kernels.  The hull narrow phase has its own
+# tests (tests/test_hull_contacts.py: the device routine against the checker and a brute-force Minkowski difference pose by
+# pose, arms pressed together gently free-running, the fly-through scene step by step from the checker's state); the IK-driven
+# scenes (ur_arms_touching_ik, also at 16 384 envs) run with the default.
+SMOOTH_CONTACTS = ('touching', 'touching_ft')
+
+
 def make_pair(name, B, seed=5, **engine):
     import diy_gym_amd.examples  # noqa: F401  registers propellor / fell_over
     from diy_gym_amd import DIYGym
     from oracle_backend import OracleBackend
+    if name in SMOOTH_CONTACTS:
+        engine.setdefault('hull_contacts', 0.0)
     gpu = DIYGym(CONFIGS[name], num_envs=B, device='cuda:0', seed=seed, engine=engine)
     cpu = DIYGym(CONFIGS[name], num_envs=B, seed=seed, backend_factory=OracleBackend, engine=engine)
     return gpu, cpu
@@ -1043,10 +1057,10 @@ def test_arms_touching_under_ik_control_at_the_size_the_bench_ships():
 # ---- the ledger of recollected constants: every one of them moved at once ------------------------------------------------------
 MOVED = dict(residual_threshold=3e-8, contact_erp=0.15, limit_erp=0.2, linear_slop=1e-4, linear_damping=0.1, angular_damping=0.02, max_coordinate_velocity=50.0,
              default_motor_impulse=0.5, ik_iterations=12, ik_lambda_sq=0.2, ik_joint_damping=0.2, ik_residual=2e-4, ik_max_angle=0.3, ik_null_rest_gain=0.01,
-             ik_null_limit_gain=5.0, contact_margin=0.03, warmstart=0.85, warmstart_friction=0.3, motor_impulse_timebase='step')
+             ik_null_limit_gain=5.0, contact_margin=0.03, warmstart=0.85, warmstart_friction=0.3, motor_impulse_timebase='step', hull_margin=0.003)
 
 
-@pytest.mark.parametrize('name,steps,tol,scale', [('ur_ik', 40, 5e-4, 1.0), ('touching', 20, 5e-3, 0.3), ('marbles', 60, 2e-3, 1.0), ('readme', 20, 3e-3, 0.2), ('drone', 40, 2e-3, 1.0),
+@pytest.mark.parametrize('name,steps,tol,scale', [('ur_ik', 40, 5e-4, 1.0), ('touching', 20, 5e-3, 0.3), ('touching_ik', 20, 5e-3, 1.0), ('marbles', 60, 2e-3, 1.0), ('readme', 20, 3e-3, 0.2), ('drone', 40, 2e-3, 1.0),
                                                    ('cart_tree', 12, 2e-2, 1.0), ('maze', 12, 1e-2, 10.0)])
 def test_every_engine_parameter_overridden_at_once(name, steps, tol, scale):
     """DESIGN.md 4 lists the Bullet constants this build restates from recollection, each behind an engine parameter

@@ -268,6 +268,7 @@ def quantiles(t):
 # default N = 1 run adds short legs for the other tail of the headline scene and for the other BASELINE configs:
 #   in_contact   ur_high_5, every env started from the crossed-forearms pose of tests/golden/ur_arms_touching_ik.yaml
 #   mixed        ur_high_5, every 100th env started from that pose (one touching env per 1.6 wavefronts)
+#   in_contact_capsule_contacts   in_contact with hull_contacts = 0 (hulls collide through their fitted capsules, as in rounds 1-3)
 #   reference_solver_settings   ur_high_5 with motor_guess = 0, warmstart = 0.85: zero-started sweeps as the reference runs them [R]
 #   configs.*    r2d2_maze x 4 096, drone_pilot x 16 384, from_the_readme x 1 024 (BASELINE.json cfg 2, 4, 5)
 CROSSED = [1.35, -1.08, 1.03, -0.01, 0.09, 0.86]   # rest_position of tests/golden/ur_arms_touching_ik.yaml
@@ -276,6 +277,9 @@ LEGS = {
     # name: (workload, envs or None (BASELINE size), engine overrides, fraction of envs put into the crossed pose, steps timed)
     'in_contact': ('ur_high_5', None, None, 1.0, 200),
     'mixed': ('ur_high_5', None, None, 0.01, 200),
+    # the same start with the narrow phase of rounds 1-3 (the capsule fitted to each hull instead of GJK / EPA on the hulls): what the
+    # hull-hull contacts of round 4 cost in this regime
+    'in_contact_capsule_contacts': ('ur_high_5', None, {'hull_contacts': 0.0}, 1.0, 200),
     'reference_solver_settings': ('ur_high_5', None, REFERENCE_SETTINGS, 0.0, 304),
     'r2d2_maze': ('r2d2_maze', None, None, 0.0, 200),
     'drone_pilot': ('drone_pilot', None, None, 0.0, 304),
@@ -283,7 +287,7 @@ LEGS = {
     # not part of 'all' (no BASELINE config): the arm + gripper tree of SURVEY 8f N2, `--legs ur5_child_gripper`
     'ur5_child_gripper': ('ur5_child_gripper', None, None, 0.0, 200),
 }
-DEFAULT_LEGS = ('in_contact', 'mixed', 'reference_solver_settings', 'r2d2_maze', 'drone_pilot', 'from_the_readme')
+DEFAULT_LEGS = ('in_contact', 'mixed', 'in_contact_capsule_contacts', 'reference_solver_settings', 'r2d2_maze', 'drone_pilot', 'from_the_readme')
 CONFIG_LEGS = ('r2d2_maze', 'drone_pilot', 'from_the_readme')
 KERNEL_OF = {'from_the_readme': 'render_kernel'}   # dominant kernel quoted in a leg's roofline (default: the step kernel)
 
@@ -785,6 +789,7 @@ def run_rank(args, argv):
             'config': {'workload': '%s x %d envs per GPU' % (args.workload, B), 'what': main.desc, 'envs_total': total_envs,
                        'timestep': 1.0 / 240.0, 'substeps': env.layout.substeps, 'solver_iteration_cap': int(env.builder.solver_iterations),
                        'solver_start': {k: env.builder.params[k] for k in ('motor_guess', 'limit_guess', 'warmstart', 'warmstart_friction')},
+                       'narrow_phase': {k: env.builder.params[k] for k in ('hull_contacts', 'hull_margin', 'contact_margin')},
                        'auto_reset': auto_reset, 'timed_path': 'backend entry points dg_world_step%s + dg_world_reset(term_flag); env.step() rates are in api_eager' % (' + dg_world_render' if main.cameras else ''),
                        'launch': 'hipGraph replay of %d-step segments' % R if main.graph is not None else 'eager',
                        'untimed_steps_before_the_timed_region': untimed,

@@ -53,11 +53,18 @@ DGD void hull_tables(HullPairD& h, bool tabled) {
 struct HullHit { V3 pa, pb, n; float dist; bool hit; };
 struct HV { V3 w, a, b; int id; };
 
+// (four points per round, their loads in flight together)
 DGD int hh_argmax(hh_cfp p, int n, V3 d, V3& pt) {
   int bi = 0; float best = -3.0e38f; V3 bp = v3(0.f, 0.f, 0.f);
-  for (int k = 0; k < n; k++) {
-    const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2], sd = x * d.x + y * d.y + z * d.z; const bool g = sd > best;
-    best = g ? sd : best; bi = g ? k : bi; bp.x = g ? x : bp.x; bp.y = g ? y : bp.y; bp.z = g ? z : bp.z;
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    float q[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int k = min(k0 + j, n - 1); q[j][0] = p[3 * k]; q[j][1] = p[3 * k + 1]; q[j][2] = p[3 * k + 2]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // (a round's spare slots repeat the last point: never strictly better)
+      const float sd = q[j][0] * d.x + q[j][1] * d.y + q[j][2] * d.z; const bool g = sd > best;
+      best = g ? sd : best; bi = g ? min(k0 + j, n - 1) : bi; bp.x = g ? q[j][0] : bp.x; bp.y = g ? q[j][1] : bp.y; bp.z = g ? q[j][2] : bp.z;
+    }
   }
   pt = bp; return bi;
 }
@@ -154,9 +161,12 @@ struct HEpa {
 };
 // signed distance of the origin from the boundary of C along its nearest face (> 0: inside, the penetration depth), that face's
 // outward normal and the witness points of the origin's projection onto it
-HH_FN float hh_epa(const HullPairD& h, V3 seed, V3& n_out, V3& pa, V3& pb) {
+HH_FN float hh_epa(const HullPairD& h, V3 seed, bool have_start, const V3 (&sw)[4], const int (&sid)[4], V3& n_out, V3& pa, V3& pb) {
   const HEpa E = {h.ew}; int nv = 0, nf = 0;
-  // a tetrahedron of C: two opposite support points, the one farthest from their line, the one farthest from their plane
+  // start: the tetrahedron GJK ended with when it found the origin inside one (it already has a face near the origin); else a
+  // tetrahedron of C built here: two opposite support points, the one farthest from their line, the one farthest from their plane
+  if (have_start) { hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; HV s; s.w = sw[k]; s.id = sid[k]; s.a = s.w; s.b = s.w; E.put(k, s); }); }
+  else {
   const V3 d0 = dot(seed, seed) > 1e-12f ? seed * frsq(dot(seed, seed)) : v3(1.f, 0.f, 0.f);
   const HV s0 = hh_support<false>(h, d0), s1 = hh_support<false>(h, -d0); E.put(0, s0); E.put(1, s1);
   const V3 e = s1.w - s0.w;
@@ -165,13 +175,20 @@ HH_FN float hh_epa(const HullPairD& h, V3 seed, V3& n_out, V3& pa, V3& pb) {
   { const HV c1 = hh_support<false>(h, d1), c2 = hh_support<false>(h, -d1); E.put(2, fabsf(dot(c1.w - s0.w, d1)) >= fabsf(dot(c2.w - s0.w, d1)) ? c1 : c2); }
   V3 nn = cross(e, E.W(2) - s0.w); nn = nn * frcp(norm(nn) + 1e-37f);
   { const HV c1 = hh_support<false>(h, nn), c2 = hh_support<false>(h, -nn); E.put(3, fabsf(dot(c1.w - s0.w, nn)) >= fabsf(dot(c2.w - s0.w, nn)) ? c1 : c2); }
+  }
   nv = 4;
   const V3 g = ((E.W(0) + E.W(1)) + (E.W(2) + E.W(3))) * 0.25f;
   E.face(0, 0, 1, 2, g); E.face(1, 0, 1, 3, g); E.face(2, 0, 2, 3, g); E.face(3, 1, 2, 3, g); nf = 4;
   int best = 0;
   for (int it = 0; it < HH_EPA_ITERS; it++) {
     best = -1; float bd = 3.0e38f;
-    for (int f = 0; f < nf; f++) { const float fd = E.F(HW_FD + f); if ((E.I(HW_FV + f) >> 24) && fd < bd) { bd = fd; best = f; } }
+    for (int f0 = 0; f0 < nf; f0 += 4) {  // (four faces per round, their loads issued together: a load at a time is a memory round trip per face)
+      float fd4[4]; int fv4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int f = min(f0 + j, nf - 1); fd4[j] = E.F(HW_FD + f); fv4[j] = E.I(HW_FV + f); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (f0 + j < nf && (fv4[j] >> 24) && fd4[j] < bd) { bd = fd4[j]; best = f0 + j; }
+    }
     if (best < 0) { best = 0; break; }
     const V3 bn = E.N(best);
     const HV w = hh_support<false>(h, bn);
@@ -253,7 +270,7 @@ HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, H
       hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; const bool nw = k == ns; tw[k] = nw ? w.w : sw[k]; ta[k] = nw ? w.a : sa[k]; tb[k] = nw ? w.b : sb[k]; ti[k] = nw ? w.id : sid[k]; });
       float ln[4]; const bool in = hh_closest_simplex(tw, ns + 1, ln);
       const V3 nv = tw[0] * ln[0] + tw[1] * ln[1] + tw[2] * ln[2] + tw[3] * ln[3]; const float nvv = dot(nv, nv);
-      if (in) { inside = true; done = true; }
+      if (in) { inside = true; done = true; hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; sw[k] = tw[k]; sid[k] = ti[k]; }); }  // (the tetrahedron the polytope search starts from)
       else if (ns > 0 && !(nvv < vv)) done = true;  // (rounding: no progress -- keep the previous simplex)
       else {
         // keep the vertices that carry weight, in their order (slot m takes the m-th of them)
@@ -273,7 +290,7 @@ HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, H
   const bool deep = active && !far && (inside || vv <= HH_SWITCH * HH_SWITCH);
   out.hit = active && !far;
   if (__any(deep)) {
-    if (deep && h.ew) { V3 nf, pa, pb; const float d = hh_epa(h, seed, nf, pa, pb); out.n = -nf; out.dist = -d; out.pa = pa; out.pb = pb; }
+    if (deep && h.ew) { V3 nf, pa, pb; const float d = hh_epa(h, seed, inside, sw, sid, nf, pa, pb); out.n = -nf; out.dist = -d; out.pa = pa; out.pb = pb; }
   }
   if (!deep || !h.ew) {  // (no polytope workspace -- a world without hull pairs never gets here: the GJK answer, ~0 along the last direction)
     const float vn = fsqrt(vv), iv = vn > 0.f ? frcp(vn) : 0.f; out.n = v * iv; out.dist = vn;

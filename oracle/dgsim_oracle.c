@@ -654,7 +654,8 @@ static int sphere_sphere(v3 ca, real ra, v3 cb, real rb, real margin, v3* pa, v3
  *        Collision Detection 5.1.5 / 5.1.6; distance |v|, normal v / |v| (from B to A), witness points from the barycentric
  *        weights; gives up early once v . w / |v| (a lower bound of the distance) exceeds `max_dist`;
  *   EPA: when the origin is inside C or nearer than HH_SWITCH to it -- an expanding polytope inside C, started from a
- *        tetrahedron of four support points chosen independently of the GJK simplex, its faces kept with SIGNED plane
+ *        tetrahedron of four support points (the one GJK ended with, if it ended inside one; else two opposite support points,
+ *        the one farthest from their line and the one farthest from their plane), its faces kept with SIGNED plane
  *        distances of the origin (so a start polytope that does not yet hold the origin is fine): the face with the smallest
  *        one is pushed out to its support point until it is a face of C; depth = that distance, normal = minus its normal.
  * Coordinates are relative to A's frame origin (fp32 build: world coordinates of ~1 m would cost three digits).
@@ -734,8 +735,11 @@ static void hh_face(HF* f, const HV* vs, int i, int j, int k, v3 g) {
 }
 /* signed distance of the origin from the boundary of C along its nearest face (> 0: inside, the penetration depth), that
  * face's outward normal and the witness points of the origin's projection onto it */
-static real hh_epa(const HullPair* h, v3 seed, v3* n_out, v3* pa, v3* pb, int* iters_out) {
+static real hh_epa(const HullPair* h, v3 seed, const HV* start, v3* n_out, v3* pa, v3* pb, int* iters_out) {
   HV vs[HH_EPA_MAXV]; HF fs[HH_EPA_MAXF]; int nv = 0, nf = 0;
+  /* start: the tetrahedron GJK ended with when it found the origin inside one (it already has a face near the origin: a shallow
+   * overlap then takes 4 further support points at the median instead of 6); else one built here */
+  if (start) { for (int k = 0; k < 4; k++) vs[k] = start[k]; } else {
   /* a tetrahedron of C: two opposite support points, the one farthest from their line, the one farthest from their plane */
   v3 d0 = vdot(seed, seed) > (real)1e-12 ? vscale(seed, 1.0 / vnorm(seed)) : V(1, 0, 0);
   vs[0] = hh_support(h, d0); vs[1] = hh_support(h, vscale(d0, -1.0));
@@ -747,6 +751,7 @@ static real hh_epa(const HullPair* h, v3 seed, v3* n_out, v3* pa, v3* pb, int* i
   v3 nn = vcross(e, vsub(vs[2].w, vs[0].w)); nn = vscale(nn, 1.0 / (vnorm(nn) + TINY_R));
   c1 = hh_support(h, nn); c2 = hh_support(h, vscale(nn, -1.0));
   vs[3] = fabs(vdot(vsub(c1.w, vs[0].w), nn)) >= fabs(vdot(vsub(c2.w, vs[0].w), nn)) ? c1 : c2;
+  }
   nv = 4;
   v3 g = vscale(vadd(vadd(vs[0].w, vs[1].w), vadd(vs[2].w, vs[3].w)), 0.25);
   hh_face(&fs[0], vs, 0, 1, 2, g); hh_face(&fs[1], vs, 0, 1, 3, g); hh_face(&fs[2], vs, 0, 2, 3, g); hh_face(&fs[3], vs, 1, 2, 3, g); nf = 4;
@@ -837,7 +842,7 @@ static int hull_hull(const HullPair* h, v3 seed, real max_dist, v3* pa, v3* pb, 
   g_hh_gjk_iters += it + 1;
   if (inside || vv <= HH_SWITCH * HH_SWITCH) {
     g_hh_epa++;
-    v3 nf; real d = hh_epa(h, seed, &nf, pa, pb, stats ? &stats[2] : NULL);
+    v3 nf; real d = hh_epa(h, seed, inside ? sx : NULL, &nf, pa, pb, stats ? &stats[2] : NULL);
     *n = vscale(nf, -1.0); *dist = -d; return 1;
   }
   real vn = sqrt(vv); *n = vscale(v, 1.0 / vn); *dist = vn;

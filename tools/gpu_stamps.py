@@ -10,6 +10,12 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'ur_ik'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 eng = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in os.environ.get('ENGINE', '').split(',') if kv}  # e.g. ENGINE=motor_guess=0,warmstart=0
 env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0', engine=eng)
+if os.environ.get('CROSSED'):  # ur_ik from the crossed-forearms pose (bench.py's in_contact leg)
+    from diy_gym_amd.scene import K
+    for arm in range(2):
+        for j, q in enumerate([1.35, -1.08, 1.03, -0.01, 0.09, 0.86]):
+            o = env.layout.link_state_off[6 * arm + j]
+            env.sim.state[o + K.LS_Q, :] = q; env.sim.state[o + K.LS_QD, :] = 0.0; env.sim.state[o + K.LS_TARGET_POS, :] = q
 lo, hi = T.action_bounds(env)
 gen = torch.Generator().manual_seed(1)
 ring = [(lo + (hi - lo) * torch.rand((B, lo.numel()), generator=gen)).to('cuda:0') for _ in range(8)]

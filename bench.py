@@ -42,9 +42,9 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (config file, metric config description)
-    'ur_high_5': ('examples/ur_high_5/ur_high_5.yaml', 'ur_high_5.yaml as in the reference: 2x UR5, ik_controller(use_orientation) + joint_state_sensor + object_state_sensor + reach_target'),
+    'ur_high_5': ('examples/ur_high_5/ur_high_5.yaml', "ur_high_5.yaml, semantically equal to the reference's (yaml.load gives the same tree; key order and layout differ): 2x UR5, ik_controller(use_orientation) + joint_state_sensor + object_state_sensor + reach_target"),
     'ur_high_5_joint': ('examples/ur_high_5/ur_high_5_joint.yaml', 'VARIANT of ur_high_5 with joint_controller(position) instead of ik_controller'),
-    'drone_pilot': ('examples/drone_pilot/drone_pilot.yaml', 'drone_pilot.yaml as in the reference: quadrotor + 4 propellor + fell_over + reach_target'),
+    'drone_pilot': ('examples/drone_pilot/drone_pilot.yaml', "drone_pilot.yaml, semantically equal to the reference's: quadrotor + 4 propellor + fell_over + reach_target"),
     'r2d2_maze': ('examples/r2d2_maze/r2d2_maze.yaml', 'r2d2_maze: R2D2 stand-in (mass 50, 4 velocity-driven wheels) among 119 fixed walls, tools/generate_maze.py --seed 7'),
     'from_the_readme': ('examples/from_the_readme/from_the_readme.yaml', 'from_the_readme.yaml: Jaco + table + 1:10 R2D2; the 200x200 gripper camera (rgb + depth) is rendered inside every timed step'),
     'marbles': ('tests/golden/basic_env_nocam.yaml', 'reference test fixture basic_env.yaml minus the camera: 3 marbles + plane + external_force'),

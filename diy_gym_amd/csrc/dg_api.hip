@@ -552,8 +552,8 @@ int32_t dg_debug_render_counters(uint64_t* out16, int32_t reset) {
 
 // diagnostics: the hull-against-hull narrow phase (dg_hull.h) on its own, one pair of poses per lane -- tests/test_hull_contacts.py
 // compares it with the CPU checker and a brute-force Minkowski difference; host pointers; not part of the public header.
-// poses [n][24] = A: rotation (9, row-major), position (3); B: the same.  out [n][11] = witness on A, witness on B, normal from B
-// towards A, signed distance, 1 if the pair is nearer than max_dist (else the rest is undefined).
+// poses [n][24] = A: rotation (9, row-major), position (3); B: the same.  out [n][12] = witness on A, witness on B, normal from B
+// towards A, signed distance, 1 if the pair is nearer than max_dist (else the rest is undefined), GJK iterations the lane needed.
 __global__ __launch_bounds__(64) void hull_pair_kernel(cfp pts, int na, int nb, const float* poses, int n, float max_dist, float* out, float* ws) {
   const int i = blockIdx.x * 64 + threadIdx.x; const bool have = i < n; const float* p = poses + 24 * (size_t)(have ? i : n - 1);
   HullPairD h; h.pa = pts; h.na = na; h.pb = pts + 3 * na; h.nb = nb;
@@ -566,19 +566,19 @@ __global__ __launch_bounds__(64) void hull_pair_kernel(cfp pts, int na, int nb, 
   const V3 seed = mul(h.RA, ca * (1.0f / (float)na)) - (mul(h.RB, cb * (1.0f / (float)nb)) + h.tBA);
   h.ew = hull_ws_of(ws); hull_tables(h, na <= 64 && nb <= 64);  // (every lane of the wavefront is here)
   HullHit r; hull_hull(h, seed, max_dist, have, r);
-  if (have) { float* o = out + 11 * (size_t)i; const V3 pa = r.pa + ta, pb = r.pb + ta;
+  if (have) { float* o = out + 12 * (size_t)i; o[11] = (float)r.iters; const V3 pa = r.pa + ta, pb = r.pb + ta;
     o[0] = pa.x; o[1] = pa.y; o[2] = pa.z; o[3] = pb.x; o[4] = pb.y; o[5] = pb.z; o[6] = r.n.x; o[7] = r.n.y; o[8] = r.n.z; o[9] = r.dist; o[10] = r.hit ? 1.f : 0.f; }
 }
-int32_t dg_debug_hull_hull(const float* pts_a, int32_t na, const float* pts_b, int32_t nb, const float* poses, int32_t n, float max_dist, float* out11) {
+int32_t dg_debug_hull_hull(const float* pts_a, int32_t na, const float* pts_b, int32_t nb, const float* poses, int32_t n, float max_dist, float* out11 /* [n][12] */) {
   if (!pts_a || !pts_b || !poses || !out11 || na < 1 || nb < 1 || na > 256 || nb > 256 || n < 1) return fail(DG_ERR_ARG, "dg_debug_hull_hull: bad argument");
   float *d_pts = nullptr, *d_poses = nullptr, *d_out = nullptr, *d_ws = nullptr; const size_t blocks = (size_t)((n + 63) / 64);
   HIP_TRY(hipMalloc(&d_ws, sizeof(float) * blocks * (size_t)HH_WS_SLOTS * 64));
-  HIP_TRY(hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)(na + nb))); HIP_TRY(hipMalloc(&d_poses, sizeof(float) * 24 * (size_t)n)); HIP_TRY(hipMalloc(&d_out, sizeof(float) * 11 * (size_t)n));
+  HIP_TRY(hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)(na + nb))); HIP_TRY(hipMalloc(&d_poses, sizeof(float) * 24 * (size_t)n)); HIP_TRY(hipMalloc(&d_out, sizeof(float) * 12 * (size_t)n));
   HIP_TRY(hipMemcpy(d_pts, pts_a, sizeof(float) * 3 * (size_t)na, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(d_pts + 3 * na, pts_b, sizeof(float) * 3 * (size_t)nb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_poses, poses, sizeof(float) * 24 * (size_t)n, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(hull_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)0, (cfp)d_pts, na, nb, (const float*)d_poses, n, max_dist, d_out, d_ws);
   HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out11, d_out, sizeof(float) * 11 * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out11, d_out, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost));
   (void)hipFree(d_pts); (void)hipFree(d_poses); (void)hipFree(d_out); (void)hipFree(d_ws);
   return DG_OK;
 }

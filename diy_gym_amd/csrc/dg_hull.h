@@ -50,8 +50,13 @@ DGD void hull_tables(HullPairD& h, bool tabled) {
     h.tax = h.pa[3 * ka]; h.tay = h.pa[3 * ka + 1]; h.taz = h.pa[3 * ka + 2]; h.tbx = h.pb[3 * kb]; h.tby = h.pb[3 * kb + 1]; h.tbz = h.pb[3 * kb + 2];
   }
 }
-struct HullHit { V3 pa, pb, n; float dist; bool hit; };
+struct HullHit { V3 pa, pb, n; float dist; bool hit; int iters /* GJK iterations this lane needed (diagnostics) */; };
 struct HV { V3 w, a, b; int id; };
+// component-wise selects: `c ? a : b` on two structs selects between their ADDRESSES, which keeps both (and every array one of them
+// is an element of) in scratch memory -- the simplex arrays of the GJK loop were, 84 scratch round trips per iteration: 28 k cycles
+// an iteration instead of 7 k
+DGD V3 hh_sel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+DGD HV hh_sel(bool c, const HV& a, const HV& b) { HV r; r.w = hh_sel(c, a.w, b.w); r.a = hh_sel(c, a.a, b.a); r.b = hh_sel(c, a.b, b.b); r.id = c ? a.id : b.id; return r; }
 
 // (four points per round, their loads in flight together)
 DGD int hh_argmax(hh_cfp p, int n, V3 d, V3& pt) {
@@ -172,9 +177,9 @@ HH_FN float hh_epa(const HullPairD& h, V3 seed, bool have_start, const V3 (&sw)[
   const V3 e = s1.w - s0.w;
   const V3 ax = (fabsf(e.x) <= fabsf(e.y) && fabsf(e.x) <= fabsf(e.z)) ? v3(1.f, 0.f, 0.f) : (fabsf(e.y) <= fabsf(e.z) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f));
   V3 d1 = cross(e, ax); d1 = d1 * frcp(norm(d1) + 1e-37f);
-  { const HV c1 = hh_support<false>(h, d1), c2 = hh_support<false>(h, -d1); E.put(2, fabsf(dot(c1.w - s0.w, d1)) >= fabsf(dot(c2.w - s0.w, d1)) ? c1 : c2); }
+  { const HV c1 = hh_support<false>(h, d1), c2 = hh_support<false>(h, -d1); E.put(2, hh_sel(fabsf(dot(c1.w - s0.w, d1)) >= fabsf(dot(c2.w - s0.w, d1)), c1, c2)); }
   V3 nn = cross(e, E.W(2) - s0.w); nn = nn * frcp(norm(nn) + 1e-37f);
-  { const HV c1 = hh_support<false>(h, nn), c2 = hh_support<false>(h, -nn); E.put(3, fabsf(dot(c1.w - s0.w, nn)) >= fabsf(dot(c2.w - s0.w, nn)) ? c1 : c2); }
+  { const HV c1 = hh_support<false>(h, nn), c2 = hh_support<false>(h, -nn); E.put(3, hh_sel(fabsf(dot(c1.w - s0.w, nn)) >= fabsf(dot(c2.w - s0.w, nn)), c1, c2)); }
   }
   nv = 4;
   const V3 g = ((E.W(0) + E.W(1)) + (E.W(2) + E.W(3))) * 0.25f;
@@ -254,9 +259,10 @@ HH_FN float hh_epa(const HullPairD& h, V3 seed, bool have_start, const V3 (&sw)[
 HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, HullHit& out) {
   V3 sw[4], sa[4], sb[4]; int sid[4]; float l[4] = {0.f, 0.f, 0.f, 0.f}; int ns = 0;
   hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; sw[k] = v3(0.f, 0.f, 0.f); sa[k] = sw[k]; sb[k] = sw[k]; sid[k] = -1; });
-  V3 v = dot(seed, seed) > 1e-12f ? seed : v3(1.f, 0.f, 0.f); float vv = 3.0e38f; bool inside = false, far = false, done = !active;
+  V3 v = dot(seed, seed) > 1e-12f ? seed : v3(1.f, 0.f, 0.f); float vv = 3.0e38f; bool inside = false, far = false, done = !active; int my_iters = 0;
   for (int it = 0; it < HH_GJK_ITERS; it++) {
     if (!__any(!done)) break;
+    my_iters += done ? 0 : 1;
     const HV w = hh_support(h, -v);
     if (!done && ns > 0) {
       const float vw = dot(v, w.w), vn = fsqrt(vv);
@@ -267,10 +273,11 @@ HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, H
     }
     if (!done) {
       V3 tw[4], ta[4], tb[4]; int ti[4];
-      hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; const bool nw = k == ns; tw[k] = nw ? w.w : sw[k]; ta[k] = nw ? w.a : sa[k]; tb[k] = nw ? w.b : sb[k]; ti[k] = nw ? w.id : sid[k]; });
+      hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; const bool nw = k == ns; tw[k] = hh_sel(nw, w.w, sw[k]); ta[k] = hh_sel(nw, w.a, sa[k]); tb[k] = hh_sel(nw, w.b, sb[k]); ti[k] = nw ? w.id : sid[k]; });
       float ln[4]; const bool in = hh_closest_simplex(tw, ns + 1, ln);
       const V3 nv = tw[0] * ln[0] + tw[1] * ln[1] + tw[2] * ln[2] + tw[3] * ln[3]; const float nvv = dot(nv, nv);
-      if (in) { inside = true; done = true; hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; sw[k] = tw[k]; sid[k] = ti[k]; }); }  // (the tetrahedron the polytope search starts from)
+      hh_for<0, 4>([&](auto K) { constexpr int k = decltype(K)::value; sw[k] = hh_sel(in, tw[k], sw[k]); sid[k] = in ? ti[k] : sid[k]; });  // (inside: the tetrahedron the polytope search starts from)
+      if (in) { inside = true; done = true; }
       else if (ns > 0 && !(nvv < vv)) done = true;  // (rounding: no progress -- keep the previous simplex)
       else {
         // keep the vertices that carry weight, in their order (slot m takes the m-th of them)
@@ -278,7 +285,7 @@ HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, H
         hh_for<0, 4>([&](auto K) {
           constexpr int k = decltype(K)::value; const bool keep = k <= ns && ln[k] > 0.f;
           hh_for<0, k + 1>([&](auto J) { constexpr int j = decltype(J)::value; const bool here = keep && m == j;
-            sw[j] = here ? tw[k] : sw[j]; sa[j] = here ? ta[k] : sa[j]; sb[j] = here ? tb[k] : sb[j]; sid[j] = here ? ti[k] : sid[j]; l[j] = here ? ln[k] : l[j]; });
+            sw[j] = hh_sel(here, tw[k], sw[j]); sa[j] = hh_sel(here, ta[k], sa[j]); sb[j] = hh_sel(here, tb[k], sb[j]); sid[j] = here ? ti[k] : sid[j]; l[j] = here ? ln[k] : l[j]; });
           m += keep ? 1 : 0;
         });
         hh_for<0, 4>([&](auto J) { constexpr int j = decltype(J)::value; l[j] = j < m ? l[j] : 0.f; });  // (slots beyond the simplex keep stale vertices: no weight)
@@ -288,7 +295,7 @@ HH_FN void hull_hull(const HullPairD& h, V3 seed, float max_dist, bool active, H
     }
   }
   const bool deep = active && !far && (inside || vv <= HH_SWITCH * HH_SWITCH);
-  out.hit = active && !far;
+  out.hit = active && !far; out.iters = my_iters;
   if (__any(deep)) {
     if (deep && h.ew) { V3 nf, pa, pb; const float d = hh_epa(h, seed, inside, sw, sid, nf, pa, pb); out.n = -nf; out.dist = -d; out.pa = pa; out.pb = pb; }
   }

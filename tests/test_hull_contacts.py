@@ -200,14 +200,15 @@ def test_the_capsule_narrow_phase_is_still_there_and_the_hulls_are_the_default()
 
 # ---- the device routine (dg_hull.h) on its own, through the library's diagnostic entry ------------------------------------
 def device_pairs(pa, pb, poses, max_dist=10.0):
-    """poses [n][24] (A: R 9, t 3; B: R 9, t 3) -> [n][11] from dg_debug_hull_hull (one pair of poses per lane)."""
+    """poses [n][24] (A: R 9, t 3; B: R 9, t 3) -> [n][12] from dg_debug_hull_hull (one pair of poses per lane): witness points,
+    normal, distance, hit flag, GJK iterations."""
     from diy_gym_amd import backend
     lib = backend.load_library()
     vp = ctypes.c_void_p
     lib.dg_debug_hull_hull.restype = ctypes.c_int32
     lib.dg_debug_hull_hull.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_float, vp]
     pa = np.ascontiguousarray(pa, np.float32); pb = np.ascontiguousarray(pb, np.float32); poses = np.ascontiguousarray(poses, np.float32)
-    out = np.zeros((len(poses), 11), np.float32)
+    out = np.zeros((len(poses), 12), np.float32)
     p = lambda a: a.ctypes.data_as(vp)
     rc = lib.dg_debug_hull_hull(p(pa), len(pa), p(pb), len(pb), p(poses), len(poses), max_dist, p(out))
     lib.dg_last_error.restype = ctypes.c_char_p

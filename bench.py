@@ -294,6 +294,7 @@ KERNEL_OF = {'from_the_readme': 'render_kernel'}   # dominant kernel quoted in a
 
 class Leg:
     R = 8  # action batches in the ring = steps per replayed graph segment
+    WHOLE_MAX = 96  # a timed region of at most this many steps is captured as one graph
 
     def __init__(self, name, workload, device, rank=0, envs=None, engine=None, crossed_frac=0.0, auto_reset=True):
         import torch
@@ -327,7 +328,7 @@ class Leg:
                     self.sim.state[o + K.LS_QD, idx] = 0.0
                     self.sim.state[o + K.LS_TARGET_POS, idx] = q
             self.crossed_envs = int(idx.numel())
-        self.graph = self.graph_rest = self.graph_kernel = None
+        self.graph = self.graph_rest = self.graph_kernel = self.graph_whole = None; self.graph_whole_steps = 0
         self.kernel_name = KERNEL_OF.get(workload, 'step_kernel_par' if getattr(self.sim, 'par', False) else 'step_kernel')
         self.step_launches = 0   # step-kernel launches so far (eager or replayed): the profiled child's manifest counts them
 
@@ -377,11 +378,17 @@ class Leg:
             if steps % R:
                 self.graph_rest = cap(steps % R, self.one_step)
             self.graph_kernel = cap(R, lambda i: self.sim.step(self.slots, self.ring[i % R]))
+            # a SHORT timed region (the driver's --steps 20 is 2 ms) as ONE graph: every replay starts ~25 us after its launch, and
+            # three of them (8 + 8 + 4 steps) were 3 % of such a region -- 0.1004 ms per step where 304 steps give 0.0972
+            if R < steps <= self.WHOLE_MAX:
+                self.graph_whole = cap(steps, self.one_step); self.graph_whole_steps = steps
         except Exception as exc:  # pragma: no cover
             print('graph capture failed (%s); timing the eager loop' % exc, file=sys.stderr)
-            self.graph = self.graph_rest = self.graph_kernel = None
+            self.graph = self.graph_rest = self.graph_kernel = self.graph_whole = None
             return 0
         n = 0
+        if self.graph_whole is not None:
+            self.graph_whole.replay(); n += steps
         self.graph.replay(); n += R
         if self.graph_rest is not None:
             self.graph_rest.replay(); n += steps % R
@@ -393,7 +400,9 @@ class Leg:
     def run(self, steps):
         """EXACTLY `steps` steps, no synchronisation (the caller brackets it)."""
         R = self.R
-        if self.graph is not None:
+        if self.graph_whole is not None and steps == self.graph_whole_steps:
+            self.graph_whole.replay()
+        elif self.graph is not None:
             for _ in range(steps // R):
                 self.graph.replay()
             if steps % R:
@@ -476,7 +485,7 @@ class Leg:
         return self.image_bytes if self.kernel_name == 'render_kernel' else algorithmic_bytes_per_env_step(self.env.layout)
 
     def close(self):
-        self.graph = self.graph_rest = self.graph_kernel = None
+        self.graph = self.graph_rest = self.graph_kernel = self.graph_whole = None
         self.env.close()
 
 
@@ -791,7 +800,7 @@ def run_rank(args, argv):
                        'solver_start': {k: env.builder.params[k] for k in ('motor_guess', 'limit_guess', 'warmstart', 'warmstart_friction')},
                        'narrow_phase': {k: env.builder.params[k] for k in ('hull_contacts', 'hull_margin', 'contact_margin')},
                        'auto_reset': auto_reset, 'timed_path': 'backend entry points dg_world_step%s + dg_world_reset(term_flag); env.step() rates are in api_eager' % (' + dg_world_render' if main.cameras else ''),
-                       'launch': 'hipGraph replay of %d-step segments' % R if main.graph is not None else 'eager',
+                       'launch': ('one hipGraph of the %d timed steps' % args.steps if main.graph_whole is not None else 'hipGraph replay of %d-step segments' % R) if main.graph is not None else 'eager',
                        'untimed_steps_before_the_timed_region': untimed,
                        'episodes_finished_rank0': episodes_main, 'parallelism': 'independent env shards x%d, no collective' % world,
                        'envs_per_wavefront': sim.lanes, 'lds_bytes_per_workgroup': sim.lds_bytes,

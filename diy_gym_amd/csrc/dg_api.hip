@@ -571,7 +571,9 @@ __global__ __launch_bounds__(64) void hull_pair_kernel(cfp pts, int na, int nb, 
 }
 int32_t dg_debug_hull_hull(const float* pts_a, int32_t na, const float* pts_b, int32_t nb, const float* poses, int32_t n, float max_dist, float* out11 /* [n][12] */) {
   if (!pts_a || !pts_b || !poses || !out11 || na < 1 || nb < 1 || na > 256 || nb > 256 || n < 1) return fail(DG_ERR_ARG, "dg_debug_hull_hull: bad argument");
-  float *d_pts = nullptr, *d_poses = nullptr, *d_out = nullptr, *d_ws = nullptr; const size_t blocks = (size_t)((n + 63) / 64);
+  struct Bufs { float *pts = nullptr, *poses = nullptr, *out = nullptr, *ws = nullptr;
+                ~Bufs() { (void)hipFree(pts); (void)hipFree(poses); (void)hipFree(out); (void)hipFree(ws); } } b;  // (freed on every way out)
+  float *&d_pts = b.pts, *&d_poses = b.poses, *&d_out = b.out, *&d_ws = b.ws; const size_t blocks = (size_t)((n + 63) / 64);
   HIP_TRY(hipMalloc(&d_ws, sizeof(float) * blocks * (size_t)HH_WS_SLOTS * 64));
   HIP_TRY(hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)(na + nb))); HIP_TRY(hipMalloc(&d_poses, sizeof(float) * 24 * (size_t)n)); HIP_TRY(hipMalloc(&d_out, sizeof(float) * 12 * (size_t)n));
   HIP_TRY(hipMemcpy(d_pts, pts_a, sizeof(float) * 3 * (size_t)na, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(d_pts + 3 * na, pts_b, sizeof(float) * 3 * (size_t)nb, hipMemcpyHostToDevice));
@@ -579,7 +581,6 @@ int32_t dg_debug_hull_hull(const float* pts_a, int32_t na, const float* pts_b, i
   hipLaunchKernelGGL(hull_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)0, (cfp)d_pts, na, nb, (const float*)d_poses, n, max_dist, d_out, d_ws);
   HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out11, d_out, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost));
-  (void)hipFree(d_pts); (void)hipFree(d_poses); (void)hipFree(d_out); (void)hipFree(d_ws);
   return DG_OK;
 }
 

@@ -7,7 +7,7 @@ import diy_gym_amd.examples  # noqa: F401
 from diy_gym_amd import DIYGym
 import test_parity_gpu as T
 for name, B, steps in (('ur_ik', 16384, 20000), ('ur_joint', 16384, 10000), ('drone', 16384, 5000), ('marbles', 4096, 5000), ('maze', 4096, 1500),
-                       ('readme', 1024, 400), ('gripper', 1024, 1000), ('touching', 4096, 2000)):
+                       ('readme', 1024, 400), ('gripper', 1024, 1000), ('touching', 4096, 2000), ('touching_ik', 16384, 2000)):  # (touching*: the hull narrow phase, polytope search included)
     env = DIYGym(T.CONFIGS[name], num_envs=B, device='cuda:0', seed=7)
     lo, hi = T.action_bounds(env)
     gen = torch.Generator().manual_seed(5)
